@@ -1,0 +1,221 @@
+/*
+ * mi355x_refiners.h -- C ABI of libmi355x_refiners.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * refiners SDXL-UNet hot path.
+ *
+ * refiners (finegrain-ai/refiners @ 2025-06-14) has no FFI of its own: every FLOP of the hot path is a stock ATen
+ * call made from a `fl.Chain` leaf.  Each entry point below therefore replaces one (or a fused group of) those call
+ * sites; the citation on every function is the reference file:line whose arithmetic it takes over.  The host side
+ * (refiners_amd/, Python, mirrors fluxion.Chain / Adapter.inject) is the only caller; INTEGRATION.md shows the
+ * ctypes binding a refiners maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, int32/int64 sizes, strides in ELEMENTS, no torch / hip types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the null stream).
+ *   - all tensors are owned by the caller; outputs are pre-allocated; nothing is allocated, freed, synchronised or
+ *     retained inside a call; kernels are enqueued on `stream` and the call returns immediately.
+ *   - dtype selects the storage type of activations / weights / outputs (accumulation is always f32 on the matrix
+ *     cores: v_mfma_f32_16x16x32_bf16 for MI355X_BF16, v_mfma_f32_16x16x4_f32 for MI355X_F32, the parity mode).
+ *   - every 16-byte-vectorised pointer (all activations, weights, outputs) must be 16-byte aligned and its leading
+ *     stride a multiple of 16 bytes, unless a field says otherwise.
+ *   - return value: 0 on success, a negative MI355X_E* code otherwise (never throws, never aborts).
+ *   - results are bit-reproducible run to run (no atomics-ordered reductions), as the reference's
+ *     tests/foundationals/latent_diffusion/test_sd15_unet.py:21-37 requires.
+ */
+#ifndef MI355X_REFINERS_H
+#define MI355X_REFINERS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_ABI_VERSION 1
+
+enum { MI355X_F32 = 0, MI355X_BF16 = 1 };
+
+enum {
+    MI355X_OK = 0,
+    MI355X_EDTYPE = -1,   /* unknown dtype */
+    MI355X_ESHAPE = -2,   /* unsupported shape / stride / alignment for this kernel */
+    MI355X_ELAUNCH = -3,  /* the HIP runtime refused the launch (hipGetLastError != hipSuccess) */
+    MI355X_EARG = -4      /* NULL where a pointer is required, bad enum, ... */
+};
+
+/* Library / device probes (no reference counterpart). */
+int mi355x_abi_version(void);
+/* Writes a NUL-terminated description ("gfx950 ... CUs") of the current device; returns MI355X_OK or a negative code. */
+int mi355x_device_info(char* buf, int32_t buflen);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * mi355x_gemm -- out[M,N] = epilogue( sum_s X_s[M,K_s] . W_s[N,K_s]^T )
+ *
+ * Replaces, in one launch:
+ *   fl.Linear                      src/refiners/fluxion/layers/linear.py:9-56      (F.linear, bias)
+ *   fl.Conv2d 3x3 / 1x1            src/refiners/fluxion/layers/conv.py:6-61        (implicit GEMM over NHWC)
+ *   LoraAdapter = Sum(target, loras) src/refiners/fluxion/adapters/lora.py:383-397 (second K segment = [x.A^T | s.B])
+ *   fl.GLU(fl.GeLU())              src/refiners/fluxion/layers/activations.py:83-160 (geglu epilogue)
+ *   fl.Residual / fl.Sum adds      src/refiners/fluxion/layers/chain.py:891-927    (res / rowbias epilogue)
+ *   ResidualConcatenator cat       src/refiners/foundationals/latent_diffusion/unet.py:69-79 (two X segments)
+ *   Upsample's nearest interpolate src/refiners/fluxion/layers/sampling.py:112-161 (ups = 2 gather)
+ *
+ * Up to three K segments are accumulated into the same output tile.  A segment is either
+ *   conv == 0 : X_s rows are plain rows, row m at x + m*ldx, K_s = k elements (multiple of 128 bytes);
+ *   conv == 1 : X_s is an NHWC image [B][H][W][k channels] (pixel stride ldx); output row m = (b, oy, ox) of a
+ *               ksize x ksize cross-correlation with zero padding ksize/2, stride `stride`, applied to the image
+ *               nearest-upsampled by `ups`; K_s = ksize*ksize*k ordered (ky, kx, channel); W_s rows are [N][K_s].
+ * Weight rows W_s[n] must be "N-packed" by the caller exactly as refiners_amd.native.pack does (identity order
+ * unless geglu, where value/gate rows are interleaved in groups of 32 so that one lane holds both).
+ * Epilogue order: + bias[n] ; + rowbias[(m / rows_per_group)*ld_rowbias + n] ; geglu: v = a * gelu_erf(g) ;
+ * + res[m*ldres + n] ; convert to dtype ; store out[m*ldo + n].
+ */
+#define MI355X_MAX_SEG 3
+
+typedef struct {
+    const void* x;
+    int64_t ldx;     /* row stride (conv == 0) or pixel stride (conv == 1), elements */
+    const void* w;
+    int64_t ldw;     /* weight row stride, elements */
+    int32_t k;       /* conv == 0: K of the segment; conv == 1: channels of the segment */
+    int32_t ksize;   /* conv == 1: 1 or 3 */
+    int32_t stride;  /* conv == 1: 1 or 2 */
+    int32_t ups;     /* conv == 1: 1 or 2 */
+    int32_t H, W;    /* conv == 1: stored input height / width (before `ups`) */
+} mi355x_gemm_seg;
+
+typedef struct {
+    int32_t dtype;
+    int32_t M, N;      /* N = number of weight rows (for geglu: 2x the output width) */
+    int32_t nseg;
+    int32_t conv;      /* 0 or 1, applies to every segment */
+    int32_t B, OH, OW; /* conv == 1: M == B*OH*OW */
+    mi355x_gemm_seg seg[MI355X_MAX_SEG];
+    void* out;
+    int64_t ldo;
+    const void* bias;       /* [N] or NULL */
+    const void* rowbias;    /* [M / rows_per_group][ld_rowbias] or NULL (RangeAdapter2d time-embedding bias) */
+    int64_t ld_rowbias;
+    int32_t rows_per_group;
+    int32_t geglu;          /* 0 / 1 */
+    const void* res;        /* [M][ldres] or NULL */
+    int64_t ldres;
+    const void* zeros;      /* >= 256 zero bytes in device memory; required when conv == 1 */
+} mi355x_gemm_args;
+
+int mi355x_gemm(const mi355x_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * mi355x_attention -- out = sum_s out_scale_s * softmax(scale * Q K_s^T) V_s      (flash style, no mask, non causal)
+ *
+ * Replaces ScaledDotProductAttention.forward (src/refiners/fluxion/layers/attentions.py:60-202: head split :177-192,
+ * F.scaled_dot_product_attention :15-34, head merge :194-202) and, with nstream == 2, the IP-Adapter
+ * Sum(SDPA, ImageCrossAttention) of src/refiners/foundationals/latent_diffusion/image_prompt.py:237-309.
+ *
+ * Q, K, out are token-major: element (b, token, h*D + d) at base + b*batch_stride + token*ld + h*D + d.
+ * V is passed TRANSPOSED (produced that way by mi355x_gemm with the operands swapped): element (h*D + d, b, key) at
+ * vt + (h*D + d)*ldvt + b*vt_batch_stride + key; every V^T row must be readable (and finite) up to the next
+ * multiple of 64 keys.  D must be 64 (SDXL; SD1.5's 40/80/160 are zero-padded by the host to 64/96.. not yet built).
+ */
+typedef struct {
+    const void* k;
+    int64_t ldk;
+    int64_t k_batch_stride;
+    const void* vt;
+    int64_t ldvt;
+    int64_t vt_batch_stride;
+    int32_t Lk;
+    float out_scale;
+} mi355x_kv_stream;
+
+typedef struct {
+    int32_t dtype;
+    int32_t B, H, D, Lq;
+    int32_t nstream; /* 1 or 2 */
+    const void* q;
+    int64_t ldq;
+    int64_t q_batch_stride;
+    void* out;
+    int64_t ldo;
+    int64_t o_batch_stride;
+    float scale;
+    mi355x_kv_stream kv[2];
+} mi355x_attn_args;
+
+int mi355x_attention(const mi355x_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * mi355x_layernorm -- rows of C: out = (x - mean) * rsqrt(var + eps) * gamma + beta
+ * Replaces fl.LayerNorm (src/refiners/fluxion/layers/norm.py:13-46 -> F.layer_norm). C*sizeof(dtype) % 16 == 0,
+ * C <= 4096.
+ */
+typedef struct {
+    int32_t dtype;
+    int32_t M, C;
+    const void* x;
+    int64_t ldx;
+    const void* gamma;
+    const void* beta;
+    float eps;
+    void* out;
+    int64_t ldo;
+} mi355x_layernorm_args;
+
+int mi355x_layernorm(const mi355x_layernorm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * mi355x_groupnorm -- NHWC GroupNorm (+ optional SiLU), three launches (partial sums, finalize, apply).
+ * Replaces fl.GroupNorm (src/refiners/fluxion/layers/norm.py:49-93 -> F.group_norm) and the fl.SiLU that follows it
+ * in ResidualBlock (src/refiners/foundationals/latent_diffusion/unet.py:29-44) / OutputBlock.
+ * x, out: [B][HW][C] with pixel stride ldx / ldo.  `ws` is float scratch of at least mi355x_groupnorm_ws_floats()
+ * elements.  Statistics use a per-channel pivot and a fixed reduction order (deterministic, no atomics).
+ */
+typedef struct {
+    int32_t dtype;
+    int32_t B, HW, C, G;
+    const void* x;
+    int64_t ldx;
+    const void* gamma;
+    const void* beta;
+    float eps;
+    int32_t silu;
+    void* out;
+    int64_t ldo;
+    float* ws;
+} mi355x_groupnorm_args;
+
+int64_t mi355x_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C);
+int mi355x_groupnorm(const mi355x_groupnorm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Layout / glue kernels (HBM-bound, 16-byte vectorised).
+ */
+/* NCHW [B][C][HW] -> NHWC [B][HW][ldo] (first `C` channels of each pixel are written). */
+int mi355x_nchw_to_nhwc(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t HW, int64_t ldo, void* stream);
+/* NHWC [B][HW][ldx] -> NCHW [B][C][HW]. */
+int mi355x_nhwc_to_nchw(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t HW, int64_t ldx, void* stream);
+/* im2col of a small-channel NCHW image for the UNet's first 3x3 conv (src/refiners/foundationals/latent_diffusion/
+ * stable_diffusion_xl/unet.py:118-121): out[M = B*H*W][ldo], column (ky*3+kx)*C + c, zero elsewhere up to ldo. */
+int mi355x_im2col3x3_nchw(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, int64_t ldo, void* stream);
+/* out[m][0:C1] = a[m][0:C1]; out[m][C1:C1+C2] = b[m][0:C2]   (ResidualConcatenator, unet.py:69-79, NHWC). */
+int mi355x_concat2(int32_t dtype, const void* a, int64_t lda, int32_t C1, const void* b, int64_t ldb, int32_t C2,
+                   void* out, int64_t ldo, int64_t M, void* stream);
+/* out = alpha*a + beta*b elementwise over n elements (fl.Sum / Residual glue, ControlLora residual injection). */
+int mi355x_axpby(int32_t dtype, const void* a, float alpha, const void* b, float beta, void* out, int64_t n, void* stream);
+/* out = silu(x) over n elements. */
+int mi355x_silu(int32_t dtype, const void* x, void* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * mi355x_cfg_ddim_step -- classifier-free-guidance combine + DDIM update in one launch, no host sync.
+ * Replaces LatentDiffusionModel.forward's chunk/combine (src/refiners/foundationals/latent_diffusion/model.py:142-145)
+ * and DDIM.__call__ (src/refiners/foundationals/latent_diffusion/solvers/ddim.py:56-95):
+ *   eps = uncond + cfg*(cond - uncond);  x0 = (x - sqrt(1-a_t)*eps)/sqrt(a_t);  x' = sqrt(a_prev)*x0 + sqrt(1-a_prev)*eps
+ * `unet_out` holds [uncond ; cond] as two consecutive blocks of n elements.  coef = {cfg, sqrt(a_t), sqrt(1-a_t),
+ * sqrt(a_prev), sqrt(1-a_prev)} is read from DEVICE memory (f32[5]) so that a captured graph can be replayed with new
+ * step coefficients.  x is updated in place (f32 or bf16 per dtype; arithmetic in f32).
+ */
+int mi355x_cfg_ddim_step(int32_t dtype, void* x, const void* unet_out, const float* coef, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_REFINERS_H */

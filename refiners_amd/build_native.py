@@ -1,0 +1,64 @@
+"""Build libmi355x_refiners.so (hand-written gfx950 kernels + C ABI) in-tree with hipcc.
+
+The library is built next to its sources (refiners_amd/csrc/) so that it travels with the repository snapshot to
+the GPU box; nothing is installed into site-packages and nothing is JIT-cached under ~/.cache.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB = CSRC / "libmi355x_refiners.so"
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+HEADERS = ["common.cuh", "../../include/mi355x_refiners.h"]
+ARCH = "gfx950"
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
+
+
+def is_stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + [(CSRC / h).resolve() for h in HEADERS] + [Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 and link the shared library. Returns the library path."""
+    if not force and not is_stale():
+        return LIB
+    hipcc = hipcc_path()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = CSRC / (src.replace(".hip", ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out:
+            print(out, file=sys.stderr)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,371 @@
+// mi355x_attention: flash-style scaled-dot-product attention for gfx950, head_dim 64, optional second K/V stream.
+//
+//   out[b, q, h*D + :] = sum_s out_scale_s * softmax_k( scale * Q[b,q,h] . K_s[b,k,h] ) V_s[b,k,h]
+//
+// Design (MI355X-first, not a port of a warp-32 flash kernel):
+//   * "swapped" orientation: the wave computes S^T = K Q^T (MFMA A = K rows from LDS, B = Q rows held in registers),
+//     so every lane owns ONE query column (c16) and 16 of the 64 keys of a tile: the online-softmax max / sum are
+//     15 local ops + 2 cross-group shuffles, the rescale factor is a per-lane scalar, and P^T is already in the
+//     register layout the second MFMA wants as its B operand (no LDS round trip, no permutes);
+//   * V arrives TRANSPOSED from the projection GEMM (the GEMM is run with its operands swapped, which costs
+//     nothing), so the V^T tile is K-contiguous like every other operand: plain swizzled LDS rows, 8/16-byte
+//     conflict-free reads, identical code for bf16 and f32 (no ds_read_tr needed);
+//   * the V^T tile rows are loaded in the permuted order R = 16j + 4a + b <-> d = 16a + 4j + b, so each lane ends up
+//     with 16 CONSECUTIVE head-dim outputs per query: the O store is 32/64 contiguous bytes per lane;
+//   * K and V^T tiles (64 keys) are staged with global_load_lds_dwordx4, source-swizzled, double buffered, one barrier
+//     per tile; Q, K, V are read in place from the (B, L, H*D) projection outputs: no head split / merge copies
+//     (reference: attentions.py:177-202).
+//   * softmax in base 2 with the scale folded into one FMA; running max starts at -inf; keys beyond Lk are masked to
+//     -inf in the last tile only; deterministic (no atomics).
+#include "common.cuh"
+#include "../../include/mi355x_refiners.h"
+
+namespace {
+
+struct KvP {
+    const char* k;
+    const char* vt;
+    int64_t ldkb, kbsb;    // bytes
+    int64_t ldvtb, vtbsb;  // bytes
+    int Lk;
+    float out_scale;
+};
+
+struct AttnP {
+    int B, H, Lq, nstream;
+    const char* q;
+    int64_t ldqb, qbsb;
+    char* out;
+    int64_t ldob, obsb;
+    float c;  // scale * log2(e)
+    KvP kv[2];
+    int qtiles;
+};
+
+template <typename T, int NW, int NSTREAM, bool GLDS>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
+    constexpr int D = 64, BKV = 64, BQW = 32;
+    constexpr int ES = sizeof(T);
+    constexpr int ROWB = D * ES;  // K rows and V^T rows have the same byte length (D == BKV)
+    constexpr int CPR = ROWB / 16;
+    constexpr int NTHR = NW * 64;
+    constexpr int TILEB = 64 * ROWB;
+    constexpr int STAGE = 2 * TILEB;
+    constexpr int LI = 64 * CPR / NTHR;  // loader iterations per tile
+    constexpr int NS = D / DT<T>::KSTEP;  // MMA steps over head dim
+    constexpr bool IS_BF16 = (ES == 2);
+    static_assert(64 * CPR % NTHR == 0, "loader mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    const int g = lane >> 4, c16 = lane & 15;
+    // grid: x = q tile (fastest), then head, then batch
+    int bid = blockIdx.x;
+    const int qt = bid % p.qtiles;
+    bid /= p.qtiles;
+    const int h = bid % p.H;
+    const int b = bid / p.H;
+    const int q0 = qt * (BQW * NW) + wid * BQW;
+
+    // ---- Q fragments (B operand), straight from global ----
+    frag_t qf[2][NS];
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        int qr = q0 + 16 * jq + c16;
+        qr = qr < p.Lq ? qr : p.Lq - 1;
+        const char* qp = p.q + (int64_t)b * p.qbsb + (int64_t)qr * p.ldqb + (int64_t)h * ROWB;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[jq][s] = *reinterpret_cast<const frag_t*>(qp + (4 * s + g) * 16);
+    }
+
+    // ---- loader coordinates ----
+    int lrow[LI], lcoff[LI], vrowd[LI];
+#pragma unroll
+    for (int it = 0; it < LI; ++it) {
+        const int q = it * NTHR + tid, row = q / CPR, pch = q % CPR;
+        lrow[it] = row;
+        lcoff[it] = (pch ^ swz<ROWB>(row)) << 4;
+        const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
+        vrowd[it] = 16 * a + 4 * j + bb;  // head-dim index stored in LDS row `row` of the V^T tile
+    }
+    frag_t kr[LI], vr[LI];
+
+    f32x4 res[4][2];
+    if constexpr (NSTREAM > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) res[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll
+    for (int sidx = 0; sidx < NSTREAM; ++sidx) {
+        const KvP& kv = p.kv[sidx];
+        const int Lk = kv.Lk;
+        const int ntile = (Lk + BKV - 1) / BKV;
+        const char* kbase = kv.k + (int64_t)b * kv.kbsb + (int64_t)h * ROWB;
+        const char* vbase = kv.vt + (int64_t)h * D * kv.ldvtb + (int64_t)b * kv.vtbsb;
+
+        auto issue = [&](int tile, int buf) {
+            char* ks = smem + buf * STAGE;
+            char* vs = ks + TILEB;
+            const int kv0 = tile * BKV;
+#pragma unroll
+            for (int it = 0; it < LI; ++it) {
+                int kr_ = kv0 + lrow[it];
+                kr_ = kr_ < Lk ? kr_ : Lk - 1;
+                const char* src = kbase + (int64_t)kr_ * kv.ldkb + lcoff[it];
+                if constexpr (GLDS) glds16(src, ks + (it * NTHR + wid * 64) * 16);
+                else kr[it] = *reinterpret_cast<const frag_t*>(src);
+            }
+#pragma unroll
+            for (int it = 0; it < LI; ++it) {
+                const char* src = vbase + (int64_t)vrowd[it] * kv.ldvtb + (int64_t)kv0 * ES + lcoff[it];
+                if constexpr (GLDS) glds16(src, vs + (it * NTHR + wid * 64) * 16);
+                else vr[it] = *reinterpret_cast<const frag_t*>(src);
+            }
+        };
+        auto commit = [&](int buf) {
+            if constexpr (!GLDS) {
+                char* ks = smem + buf * STAGE;
+                char* vs = ks + TILEB;
+#pragma unroll
+                for (int it = 0; it < LI; ++it) *reinterpret_cast<frag_t*>(ks + (it * NTHR + tid) * 16) = kr[it];
+#pragma unroll
+                for (int it = 0; it < LI; ++it) *reinterpret_cast<frag_t*>(vs + (it * NTHR + tid) * 16) = vr[it];
+            }
+        };
+
+        f32x4 o[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float mrun[2] = {-INFINITY, -INFINITY};
+        float lsum[2] = {0.f, 0.f};
+
+        // all waves must be done reading LDS of the previous stream before it is overwritten
+        __syncthreads();
+        issue(0, 0);
+        commit(0);
+        wait_vm0();
+        __syncthreads();
+
+        for (int tile = 0; tile < ntile; ++tile) {
+            const int cur = tile & 1;
+            const bool more = tile + 1 < ntile;
+            if (more) issue(tile + 1, cur ^ 1);
+            const char* ks = smem + cur * STAGE;
+            const char* vs = ks + TILEB;
+
+            // ---- S^T = K Q^T ----
+            f32x4 st[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                st[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                st[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const frag_t kf = lds_read_frag(ks, tile_off<ROWB>(16 * t + c16, 4 * s + g));
+                    mma_step<T>(st[t][0], kf, qf[0][s]);
+                    mma_step<T>(st[t][1], kf, qf[1][s]);
+                }
+            }
+            // ---- mask the tail tile ----
+            const int kv0 = tile * BKV;
+            if (kv0 + BKV > Lk) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (kv0 + 16 * t + 4 * g + r >= Lk) {
+                            st[t][0][r] = -INFINITY;
+                            st[t][1][r] = -INFINITY;
+                        }
+                    }
+            }
+            // ---- online softmax (per lane: one query column per jq) ----
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) {
+                float mx = st[0][jq][0];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][jq][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mnew = fmaxf(mrun[jq], mx);
+                const float alpha = exp2f((mrun[jq] - mnew) * p.c);
+                const float mc = mnew * p.c;
+                float ps = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = exp2f(st[t][jq][r] * p.c - mc);
+                        st[t][jq][r] = e;
+                        ps += e;
+                    }
+                lsum[jq] = lsum[jq] * alpha + ps;
+                mrun[jq] = mnew;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
+            }
+            // ---- O^T += V^T P^T ----
+            if constexpr (IS_BF16) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    frag_t pb[2];
+#pragma unroll
+                    for (int jq = 0; jq < 2; ++jq) {
+                        bf16x8 pk;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pk[r] = (bf16_t)st[2 * s2][jq][r];
+                            pk[4 + r] = (bf16_t)st[2 * s2 + 1][jq][r];
+                        }
+                        pb[jq] = __builtin_bit_cast(frag_t, pk);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 16 * i + c16;
+                        const int chunk = 4 * s2 + (g >> 1);
+                        const int sw = swz<ROWB>(row);
+                        const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
+                        const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
+                        const frag_t vf = frag_t{va[0], va[1], vb[0], vb[1]};
+                        mma_step<T>(o[i][0], vf, pb[0]);
+                        mma_step<T>(o[i][1], vf, pb[1]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const frag_t p0 = __builtin_bit_cast(frag_t, st[t][0]);
+                    const frag_t p1 = __builtin_bit_cast(frag_t, st[t][1]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const frag_t vf = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * t + g));
+                        mma_step<T>(o[i][0], vf, p0);
+                        mma_step<T>(o[i][1], vf, p1);
+                    }
+                }
+            }
+            if (more) commit(cur ^ 1);
+            wait_vm0();
+            __syncthreads();
+        }
+
+        // ---- finish this stream ----
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+            float l = lsum[jq];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv = kv.out_scale / l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (NSTREAM > 1) res[i][jq] += o[i][jq] * inv;
+                else res[i][jq] = o[i][jq] * inv;
+            }
+        }
+    }
+
+    // ---- store: lane owns d = 16g + 4i + r (16 consecutive) of query 16jq + c16 ----
+    constexpr int EPC = DT<T>::EPC;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        const int qr = q0 + 16 * jq + c16;
+        if (qr >= p.Lq) continue;
+        T* op = reinterpret_cast<T*>(p.out + (int64_t)b * p.obsb + (int64_t)qr * p.ldob + (int64_t)h * ROWB) + 16 * g;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * i + r] = res[i][jq][r];
+#pragma unroll
+        for (int c = 0; c < 16 / EPC; ++c) {
+            Vec16<T> ov;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
+            store16<T>(op + c * EPC, ov);
+        }
+    }
+}
+
+int g_attn_glds = 1;
+
+template <typename T, int NW, int NSTREAM, bool GLDS>
+int launch_attn(const AttnP& p0, hipStream_t stream) {
+    constexpr int LDS = 2 * 2 * 64 * 64 * sizeof(T);
+    auto kfn = attn_kernel<T, NW, NSTREAM, GLDS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    AttnP p = p0;
+    p.qtiles = (p.Lq + 32 * NW - 1) / (32 * NW);
+    const int grid = p.qtiles * p.H * p.B;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
+}
+
+template <typename T>
+int launch_attn_t(const AttnP& p, hipStream_t stream) {
+    if (g_attn_glds) {
+        if (p.nstream == 2) return launch_attn<T, 4, 2, true>(p, stream);
+        return launch_attn<T, 4, 1, true>(p, stream);
+    }
+    if (p.nstream == 2) return launch_attn<T, 4, 2, false>(p, stream);
+    return launch_attn<T, 4, 1, false>(p, stream);
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int mi355x_attention_set_glds(int v) {
+    g_attn_glds = v;
+    return MI355X_OK;
+}
+
+extern "C" int mi355x_attention(const mi355x_attn_args* a, void* stream) {
+    if (!a || !a->q || !a->out) return MI355X_EARG;
+    if (a->dtype != MI355X_F32 && a->dtype != MI355X_BF16) return MI355X_EDTYPE;
+    if (a->D != 64 || a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->nstream < 1 || a->nstream > 2) return MI355X_ESHAPE;
+    const int es = a->dtype == MI355X_F32 ? 4 : 2;
+    if (!al16(a->q) || !al16(a->out) || (a->ldq * es) % 16 || (a->ldo * es) % 16 || (a->q_batch_stride * es) % 16 ||
+        (a->o_batch_stride * es) % 16)
+        return MI355X_ESHAPE;
+    AttnP p{};
+    p.B = a->B;
+    p.H = a->H;
+    p.Lq = a->Lq;
+    p.nstream = a->nstream;
+    p.q = static_cast<const char*>(a->q);
+    p.ldqb = a->ldq * es;
+    p.qbsb = a->q_batch_stride * es;
+    p.out = static_cast<char*>(a->out);
+    p.ldob = a->ldo * es;
+    p.obsb = a->o_batch_stride * es;
+    p.c = a->scale * 1.44269504088896340736f;
+    for (int s = 0; s < a->nstream; ++s) {
+        const mi355x_kv_stream& k = a->kv[s];
+        if (!k.k || !k.vt || k.Lk <= 0) return MI355X_ESHAPE;
+        if (!al16(k.k) || !al16(k.vt) || (k.ldk * es) % 16 || (k.ldvt * es) % 16 || (k.k_batch_stride * es) % 16 ||
+            (k.vt_batch_stride * es) % 16)
+            return MI355X_ESHAPE;
+        p.kv[s].k = static_cast<const char*>(k.k);
+        p.kv[s].vt = static_cast<const char*>(k.vt);
+        p.kv[s].ldkb = k.ldk * es;
+        p.kv[s].kbsb = k.k_batch_stride * es;
+        p.kv[s].ldvtb = k.ldvt * es;
+        p.kv[s].vtbsb = k.vt_batch_stride * es;
+        p.kv[s].Lk = k.Lk;
+        p.kv[s].out_scale = k.out_scale;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (a->dtype == MI355X_F32) return launch_attn_t<float>(p, st);
+    return launch_attn_t<bf16_t>(p, st);
+}

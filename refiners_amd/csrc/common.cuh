@@ -1,0 +1,125 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the refiners hot path.
+//
+// Conventions used by every kernel in this directory
+//   * wavefront = 64 lanes; "g" = lane >> 4 (16-lane group), "c16" = lane & 15.
+//   * operand fragments are 16-byte chunks ("frag_t"): 8 bf16 or 4 f32 consecutive along K.
+//   * one "MMA step" multiplies two 16-row fragment sets over 4 chunks of K (one chunk per lane group):
+//       bf16 : 1 x v_mfma_f32_16x16x32_bf16          (K = 32)
+//       f32  : 4 x v_mfma_f32_16x16x4_f32            (K = 16, element e of the chunk feeds MFMA e)
+//     so the SAME LDS image / fragment addressing serves both dtypes (only the bytes per element differ).
+//   * MFMA operand roles: A rows come from the first fragment, B columns from the second; result lane layout
+//       D[row = 4*g + r][col = c16],  r = 0..3  (MI355X guide, cdna_hip_programming.md section 3).
+//   * LDS tiles are rows of 128 B or 256 B, 16-B chunks XOR-swizzled by row so that ds_read_b128 fragment reads and
+//     ds_read_b64 half-chunk reads are bank-conflict free; the global->LDS copy is `global_load_lds_dwordx4`
+//     (LDS destination lane-linear), so the swizzle is applied to the per-lane SOURCE address (guide rule 21).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MI_DEV __device__ __forceinline__
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) int frag_t;   // one 16-byte operand chunk
+typedef __attribute__((ext_vector_type(2))) int half_frag_t;  // 8 bytes
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    static constexpr int KSTEP = 16;  // K covered by one MMA step (4 chunks)
+};
+template <> struct DT<bf16_t> {
+    static constexpr int EPC = 8;
+    static constexpr int KSTEP = 32;
+};
+
+MI_DEV float to_f32(float v) { return v; }
+MI_DEV float to_f32(bf16_t v) { return (float)v; }
+template <typename T> MI_DEV T from_f32(float v);
+template <> MI_DEV float from_f32<float>(float v) { return v; }
+template <> MI_DEV bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// One MMA step: acc += A(16 rows x Kstep) * B(16 cols x Kstep)^T, fragments as described above.
+template <typename T> MI_DEV void mma_step(f32x4& acc, frag_t a, frag_t b);
+template <> MI_DEV void mma_step<bf16_t>(f32x4& acc, frag_t a, frag_t b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> MI_DEV void mma_step<float>(f32x4& acc, frag_t a, frag_t b) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+}
+
+// ---- swizzled LDS tiles ------------------------------------------------------------------------------------
+// A tile is `rows` rows of ROWB bytes (ROWB = 128 or 256), i.e. CPR = ROWB/16 chunks per row.
+// Physical chunk = logical chunk XOR swz(row).  For ROWB = 128 two rows share one 256-B bank row, so the swizzle uses
+// row>>1 (3 bits); for ROWB = 256 it uses row (4 bits).  Either way 16 consecutive rows at one logical chunk hit 16
+// distinct 16-B slots of the 64-bank window.
+template <int ROWB> MI_DEV int swz(int row) {
+    if constexpr (ROWB == 128) return (row >> 1) & 7;
+    else return row & 15;
+}
+template <int ROWB> MI_DEV int tile_off(int row, int chunk) {  // byte offset of logical (row, chunk)
+    return row * ROWB + ((chunk ^ swz<ROWB>(row)) << 4);
+}
+
+MI_DEV frag_t lds_read_frag(const char* lds, int byte_off) {
+    return *reinterpret_cast<const frag_t*>(lds + byte_off);
+}
+MI_DEV half_frag_t lds_read_half(const char* lds, int byte_off) {
+    return *reinterpret_cast<const half_frag_t*>(lds + byte_off);
+}
+
+// Asynchronous 16-byte-per-lane global -> LDS copy.  `lds_wave_base` must be wave-uniform: lane i lands at
+// lds_wave_base + 16*i.  Completion is tracked by vmcnt (wait with wait_vm0()).
+MI_DEV void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+MI_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+MI_DEV int lane_id() { return threadIdx.x & 63; }
+MI_DEV int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// Bijective XCD-aware remap of a 1-D block id (guide 5.5 T1): blocks that are adjacent after the remap run on the
+// same XCD (hardware places block b on XCD b % 8) and therefore share that XCD's L2.
+MI_DEV int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+MI_DEV float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+MI_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// 16-byte vector of T, for epilogues and elementwise kernels.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    f32x4 v;
+    static constexpr int N = 4;
+    MI_DEV float get(int i) const { return v[i]; }
+    MI_DEV void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16_t> {
+    bf16x8 v;
+    static constexpr int N = 8;
+    MI_DEV float get(int i) const { return (float)v[i]; }
+    MI_DEV void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+template <typename T> MI_DEV Vec16<T> load16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T> MI_DEV void store16(T* p, const Vec16<T>& x) {
+    *reinterpret_cast<decltype(x.v)*>(p) = x.v;
+}

@@ -1,0 +1,216 @@
+// Layout / glue kernels of the UNet step: all HBM-bound, grid-stride, 16-byte vectorised where the layout allows.
+#include "common.cuh"
+#include "../../include/mi355x_refiners.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+inline int grid_for(int64_t work, int per_block = 256, int cap = 4096) {
+    int64_t b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// NCHW -> NHWC through an LDS transpose tile: 64 pixels x 64 channels per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__ x, T* __restrict__ out, int C, int HW, int64_t ldo) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, px = p0 + tx;
+        tile[cc][tx] = (c < C && px < HW) ? to_f32(x[((int64_t)b * C + c) * HW + px]) : 0.f;
+    }
+    __syncthreads();
+    for (int pp = ty; pp < 64; pp += 4) {
+        const int px = p0 + pp, c = c0 + tx;
+        if (px < HW && c < C) out[((int64_t)b * HW + px) * ldo + c] = from_f32<T>(tile[tx][pp]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, T* __restrict__ out, int C, int HW, int64_t ldx) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int pp = ty; pp < 64; pp += 4) {
+        const int px = p0 + pp, c = c0 + tx;
+        tile[pp][tx] = (c < C && px < HW) ? to_f32(x[((int64_t)b * HW + px) * ldx + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, px = p0 + tx;
+        if (px < HW && c < C) out[((int64_t)b * C + c) * HW + px] = from_f32<T>(tile[tx][cc]);
+    }
+}
+
+// im2col for a tiny-channel NCHW image (the UNet's 4 -> 320 input conv): one thread per (pixel, column)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int C, int H, int W,
+                                                         int64_t ldo) {
+    const int64_t total = (int64_t)B * H * W * ldo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % ldo);
+        const int64_t m = i / ldo;
+        float v = 0.f;
+        if (col < 9 * C) {
+            const int tap = col / C, c = col - tap * C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int b = (int)(m / (H * W));
+            const int rem = (int)(m - (int64_t)b * H * W);
+            const int oy = rem / W, ox = rem - oy * W;
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = to_f32(x[(((int64_t)b * C + c) * H + iy) * W + ix]);
+        }
+        out[i] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void concat2_kernel(const T* __restrict__ a, int64_t lda, int V1, const T* __restrict__ b, int64_t ldb,
+                                                       int V2, T* __restrict__ out, int64_t ldo, int64_t M) {
+    constexpr int EPC = DT<T>::EPC;
+    const int NV = V1 + V2;
+    const int64_t total = M * NV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / NV;
+        const int v = (int)(i - m * NV);
+        Vec16<T> t = v < V1 ? load16<T>(a + m * lda + v * EPC) : load16<T>(b + m * ldb + (v - V1) * EPC);
+        store16<T>(out + m * ldo + v * EPC, t);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ a, float alpha, const T* __restrict__ b, float beta,
+                                                     T* __restrict__ out, int64_t n) {
+    constexpr int EPC = DT<T>::EPC;
+    const int64_t nv = n / EPC;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        Vec16<T> x = load16<T>(a + i * EPC), y = load16<T>(b + i * EPC), o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, alpha * x.get(e) + beta * y.get(e));
+        store16<T>(out + i * EPC, o);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - nv * EPC)) {
+        const int64_t i = nv * EPC + threadIdx.x;
+        out[i] = from_f32<T>(alpha * to_f32(a[i]) + beta * to_f32(b[i]));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void silu_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = from_f32<T>(silu_f(to_f32(x[i])));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(T* __restrict__ x, const T* __restrict__ uo, const float* __restrict__ coef,
+                                                        int64_t n) {
+    const float cfg = coef[0], sa = coef[1], s1a = coef[2], sap = coef[3], s1ap = coef[4];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float u = to_f32(uo[i]), c = to_f32(uo[n + i]);
+        const float eps = u + cfg * (c - u);
+        const float xv = to_f32(x[i]);
+        const float x0 = (xv - s1a * eps) / sa;
+        x[i] = from_f32<T>(sap * x0 + s1ap * eps);
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                          \
+    do {                                                 \
+        if ((dtype) == MI355X_F32) {                     \
+            using T = float;                             \
+            CALL;                                        \
+        } else if ((dtype) == MI355X_BF16) {             \
+            using T = bf16_t;                            \
+            CALL;                                        \
+        } else                                           \
+            return MI355X_EDTYPE;                        \
+    } while (0)
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH)
+
+extern "C" int mi355x_abi_version(void) { return MI355X_ABI_VERSION; }
+
+extern "C" int mi355x_device_info(char* buf, int32_t buflen) {
+    if (!buf || buflen <= 0) return MI355X_EARG;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MI355X_ELAUNCH;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MI355X_ELAUNCH;
+    snprintf(buf, (size_t)buflen, "%s %s CUs=%d LDS/block=%zu clock=%dkHz mem=%zuMiB", prop.name, prop.gcnArchName,
+             prop.multiProcessorCount, (size_t)prop.sharedMemPerBlock, prop.clockRate, (size_t)(prop.totalGlobalMem >> 20));
+    return MI355X_OK;
+}
+
+extern "C" int mi355x_nchw_to_nhwc(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t HW, int64_t ldo, void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || HW <= 0 || ldo < C) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((HW + 63) / 64, (C + 63) / 64, B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), grid, dim3(256), 0, st, static_cast<const T*>(x), static_cast<T*>(out), C, HW, ldo));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_nhwc_to_nchw(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t HW, int64_t ldx, void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || HW <= 0 || ldx < C) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((HW + 63) / 64, (C + 63) / 64, B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), grid, dim3(256), 0, st, static_cast<const T*>(x), static_cast<T*>(out), C, HW, ldx));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_im2col3x3_nchw(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, int64_t ldo,
+                                      void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldo < 9 * C) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((int64_t)B * H * W * ldo);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((im2col3x3_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), static_cast<T*>(out), B, C, H, W, ldo));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_concat2(int32_t dtype, const void* a, int64_t lda, int32_t C1, const void* b, int64_t ldb, int32_t C2, void* out,
+                               int64_t ldo, int64_t M, void* stream) {
+    if (!a || !b || !out || M <= 0 || C1 <= 0 || C2 <= 0) return MI355X_EARG;
+    if (dtype != MI355X_F32 && dtype != MI355X_BF16) return MI355X_EDTYPE;
+    const int es = dtype == MI355X_F32 ? 4 : 2;
+    if ((C1 * es) % 16 || (C2 * es) % 16 || (lda * es) % 16 || (ldb * es) % 16 || (ldo * es) % 16 || !al16(a) || !al16(b) || !al16(out))
+        return MI355X_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int epc = 16 / es;
+    const int grid = grid_for(M * ((C1 + C2) / epc));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((concat2_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(a), lda, C1 / epc,
+                                         static_cast<const T*>(b), ldb, C2 / epc, static_cast<T*>(out), ldo, M));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_axpby(int32_t dtype, const void* a, float alpha, const void* b, float beta, void* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0) return MI355X_EARG;
+    if (!al16(a) || !al16(b) || !al16(out)) return MI355X_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(a), alpha,
+                                         static_cast<const T*>(b), beta, static_cast<T*>(out), n));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_silu(int32_t dtype, const void* x, void* out, int64_t n, void* stream) {
+    if (!x || !out || n <= 0) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((silu_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), static_cast<T*>(out), n));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_cfg_ddim_step(int32_t dtype, void* x, const void* unet_out, const float* coef, int64_t n, void* stream) {
+    if (!x || !unet_out || !coef || n <= 0) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((cfg_ddim_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<T*>(x), static_cast<const T*>(unet_out), coef, n));
+    return LAUNCH_OK();
+}

@@ -1,0 +1,292 @@
+// LayerNorm and NHWC GroupNorm(+SiLU) for gfx950: HBM-bound streaming kernels, 16-byte vectorised, deterministic.
+//
+// LayerNorm: one wave per row, the row lives in registers (two-pass mean / variance like F.layer_norm), 4 rows per
+// workgroup.  GroupNorm works on the NHWC activations the conv / attention kernels use (no NCHW detour):
+//   1. gn_partial : each workgroup reduces a pixel range of one sample into per-CHANNEL shifted sums (pivot = the
+//                   channel's value at pixel 0, which removes the E[x^2]-E[x]^2 cancellation), fixed order;
+//   2. gn_finalize: per sample, channel partials -> (mean_c, M2_c) -> Chan merge into the 32 groups -> per-channel
+//                   (mean_g, rstd_g * gamma_c) table;
+//   3. gn_apply   : y = (x - mean) * a + beta, optional SiLU, one read + one write of the activation.
+#include "common.cuh"
+#include "../../include/mi355x_refiners.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ gamma,
+                                                         const T* __restrict__ beta, T* __restrict__ out, int64_t ldo, int M,
+                                                         int C, float eps) {
+    constexpr int EPC = DT<T>::EPC;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= M) return;
+    const int nvec = C / EPC;
+    const T* xp = x + (int64_t)row * ldx;
+    float v[MAXV][EPC];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nvec) {
+            Vec16<T> t = load16<T>(xp + vi * EPC);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                v[k][e] = t.get(e);
+                s += v[k][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float d = v[k][e] - mean;
+                ss += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rstd = rsqrtf(ss / (float)C + eps);
+    T* op = out + (int64_t)row * ldo;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nvec) {
+            Vec16<T> gm = load16<T>(gamma + vi * EPC), bt = load16<T>(beta + vi * EPC), o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.set(e, (v[k][e] - mean) * rstd * gm.get(e) + bt.get(e));
+            store16<T>(op + vi * EPC, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm
+// ws layout (floats): part[B][nchunk][C][2] | tab[B][C][2]
+constexpr int GN_MAXVPT = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int64_t ldx, int HW, int C, int ppc,
+                                                          int nchunk, float* __restrict__ part) {
+    constexpr int EPC = DT<T>::EPC;
+    __shared__ float red[256 * EPC * 2];
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int NV = C / EPC;
+    const int tid = threadIdx.x;
+    const int PL = NV >= 256 ? 1 : 256 / NV;             // pixel lanes
+    const int VPT = NV >= 256 ? (NV + 255) / 256 : 1;    // vectors per thread
+    const int pl = NV >= 256 ? 0 : tid / NV;
+    const int v0 = NV >= 256 ? tid : tid % NV;
+    const bool active = pl < PL;
+    const T* xb = x + (int64_t)b * HW * ldx;
+    const int p0 = chunk * ppc;
+    const int p1 = min(p0 + ppc, HW);
+    for (int k = 0; k < VPT; ++k) {
+        const int v = v0 + 256 * k;
+        const bool on = active && v < NV;
+        float s1[EPC], s2[EPC], piv[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = piv[e] = 0.f;
+        if (on) {
+            Vec16<T> pv = load16<T>(xb + v * EPC);  // pixel 0 of this sample = pivot
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) piv[e] = pv.get(e);
+            for (int px = p0 + pl; px < p1; px += PL) {
+                Vec16<T> t = load16<T>(xb + (int64_t)px * ldx + v * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float d = t.get(e) - piv[e];
+                    s1[e] += d;
+                    s2[e] += d * d;
+                }
+            }
+        }
+        float* dst = part + (((int64_t)b * nchunk + chunk) * C) * 2;
+        if (PL > 1) {
+            // reduce over pixel lanes through LDS in a fixed order
+            __syncthreads();
+            if (on) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    red[(tid * EPC + e) * 2 + 0] = s1[e];
+                    red[(tid * EPC + e) * 2 + 1] = s2[e];
+                }
+            }
+            __syncthreads();
+            if (on && pl == 0) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    float a1 = 0.f, a2 = 0.f;
+                    for (int q = 0; q < PL; ++q) {
+                        a1 += red[((q * NV + v) * EPC + e) * 2 + 0];
+                        a2 += red[((q * NV + v) * EPC + e) * 2 + 1];
+                    }
+                    dst[(v * EPC + e) * 2 + 0] = a1;
+                    dst[(v * EPC + e) * 2 + 1] = a2;
+                }
+            }
+        } else if (on) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                dst[(v * EPC + e) * 2 + 0] = s1[e];
+                dst[(v * EPC + e) * 2 + 1] = s2[e];
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ x, int64_t ldx, int HW, int C, int G,
+                                                           int nchunk, const float* __restrict__ part,
+                                                           const T* __restrict__ gamma, float eps, float* __restrict__ tab) {
+    extern __shared__ float sm[];  // mean_c[C], m2_c[C]
+    float* mean_c = sm;
+    float* m2_c = sm + C;
+    const int b = blockIdx.x;
+    const float n = (float)HW;
+    const T* xb = x + (int64_t)b * HW * ldx;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        const float* pp = part + ((int64_t)b * nchunk * C + c) * 2;
+        for (int k = 0; k < nchunk; ++k) {
+            s1 += pp[(int64_t)k * C * 2 + 0];
+            s2 += pp[(int64_t)k * C * 2 + 1];
+        }
+        const float piv = to_f32(xb[c]);
+        mean_c[c] = piv + s1 / n;
+        m2_c[c] = fmaxf(s2 - s1 * s1 / n, 0.f);
+    }
+    __syncthreads();
+    const int cg = C / G;
+    float* tb = tab + (int64_t)b * C * 2;
+    for (int gi = threadIdx.x; gi < G; gi += 256) {
+        float mg = 0.f;
+        for (int c = gi * cg; c < (gi + 1) * cg; ++c) mg += mean_c[c];
+        mg /= (float)cg;
+        float m2 = 0.f;
+        for (int c = gi * cg; c < (gi + 1) * cg; ++c) {
+            const float d = mean_c[c] - mg;
+            m2 += m2_c[c] + n * d * d;
+        }
+        const float rstd = rsqrtf(m2 / (n * (float)cg) + eps);
+        for (int c = gi * cg; c < (gi + 1) * cg; ++c) {
+            tb[c * 2 + 0] = mg;
+            tb[c * 2 + 1] = rstd * to_f32(gamma[c]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
+                                                        int HW, int C, const float* __restrict__ tab,
+                                                        const T* __restrict__ beta, int silu, int64_t nvec_total) {
+    constexpr int EPC = DT<T>::EPC;
+    const int NV = C / EPC;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec_total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / NV;  // global pixel index over B*HW
+        const int v = (int)(i - pix * NV);
+        const int b = (int)(pix / HW);
+        Vec16<T> t = load16<T>(x + pix * ldx + v * EPC), bt = load16<T>(beta + v * EPC), o;
+        const float* tb = tab + ((int64_t)b * C + v * EPC) * 2;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float y = (t.get(e) - tb[e * 2]) * tb[e * 2 + 1] + bt.get(e);
+            if (silu) y = silu_f(y);
+            o.set(e, y);
+        }
+        store16<T>(out + pix * ldo + v * EPC, o);
+    }
+}
+
+inline int gn_ppc(int B, int HW, int C, int es) {
+    const int nv = C * es / 16;
+    const int pl = nv >= 256 ? 1 : 256 / nv;
+    int64_t target = ((int64_t)B * HW + 1023) / 1024;  // ~1024 workgroups
+    int ppc = (int)(target < pl ? pl : target);
+    ppc = ((ppc + pl - 1) / pl) * pl;
+    if (ppc < 4 * pl) ppc = 4 * pl;
+    return ppc;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+int run_layernorm(const mi355x_layernorm_args* a, hipStream_t st) {
+    constexpr int EPC = DT<T>::EPC;
+    const int nvec = a->C / EPC;
+    const int grid = (a->M + 3) / 4;
+    const T* x = static_cast<const T*>(a->x);
+    const T* gm = static_cast<const T*>(a->gamma);
+    const T* bt = static_cast<const T*>(a->beta);
+    T* o = static_cast<T*>(a->out);
+    if (nvec <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(grid), dim3(256), 0, st, x, a->ldx, gm, bt, o, a->ldo, a->M, a->C, a->eps);
+    else if (nvec <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(grid), dim3(256), 0, st, x, a->ldx, gm, bt, o, a->ldo, a->M, a->C, a->eps);
+    else if (nvec <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(grid), dim3(256), 0, st, x, a->ldx, gm, bt, o, a->ldo, a->M, a->C, a->eps);
+    else if (nvec <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(grid), dim3(256), 0, st, x, a->ldx, gm, bt, o, a->ldo, a->M, a->C, a->eps);
+    else if (nvec <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 16>), dim3(grid), dim3(256), 0, st, x, a->ldx, gm, bt, o, a->ldo, a->M, a->C, a->eps);
+    else return MI355X_ESHAPE;
+    return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
+}
+
+template <typename T>
+int run_groupnorm(const mi355x_groupnorm_args* a, hipStream_t st) {
+    constexpr int EPC = DT<T>::EPC;
+    const int es = sizeof(T);
+    const int ppc = gn_ppc(a->B, a->HW, a->C, es);
+    const int nchunk = (a->HW + ppc - 1) / ppc;
+    float* part = a->ws;
+    float* tab = a->ws + (int64_t)a->B * nchunk * a->C * 2;
+    const T* x = static_cast<const T*>(a->x);
+    hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, ppc, nchunk, part);
+    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->B), dim3(256), a->C * 2 * sizeof(float), st, x, a->ldx, a->HW, a->C, a->G,
+                       nchunk, part, static_cast<const T*>(a->gamma), a->eps, tab);
+    const int64_t nvec_total = (int64_t)a->B * a->HW * (a->C / EPC);
+    int64_t blocks = (nvec_total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3((int)blocks), dim3(256), 0, st, x, a->ldx, static_cast<T*>(a->out), a->ldo, a->HW,
+                       a->C, tab, static_cast<const T*>(a->beta), a->silu, nvec_total);
+    return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int mi355x_layernorm(const mi355x_layernorm_args* a, void* stream) {
+    if (!a || !a->x || !a->out || !a->gamma || !a->beta) return MI355X_EARG;
+    if (a->dtype != MI355X_F32 && a->dtype != MI355X_BF16) return MI355X_EDTYPE;
+    const int es = a->dtype == MI355X_F32 ? 4 : 2;
+    if (a->M <= 0 || a->C <= 0 || (a->C * es) % 16 || (a->ldx * es) % 16 || (a->ldo * es) % 16) return MI355X_ESHAPE;
+    if (!al16(a->x) || !al16(a->out) || !al16(a->gamma) || !al16(a->beta)) return MI355X_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return a->dtype == MI355X_F32 ? run_layernorm<float>(a, st) : run_layernorm<bf16_t>(a, st);
+}
+
+extern "C" int64_t mi355x_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C) {
+    // worst case over both dtypes: the smaller ppc (more chunks) wins, so take the max of the two
+    int64_t best = 0;
+    for (int es = 2; es <= 4; es += 2) {
+        const int ppc = gn_ppc(B, HW, C, es);
+        const int64_t nchunk = (HW + ppc - 1) / ppc;
+        const int64_t need = (int64_t)B * nchunk * C * 2 + (int64_t)B * C * 2;
+        if (need > best) best = need;
+    }
+    return best;
+}
+
+extern "C" int mi355x_groupnorm(const mi355x_groupnorm_args* a, void* stream) {
+    if (!a || !a->x || !a->out || !a->gamma || !a->beta || !a->ws) return MI355X_EARG;
+    if (a->dtype != MI355X_F32 && a->dtype != MI355X_BF16) return MI355X_EDTYPE;
+    const int es = a->dtype == MI355X_F32 ? 4 : 2;
+    if (a->B <= 0 || a->HW <= 0 || a->C <= 0 || a->G <= 0 || a->C % a->G) return MI355X_ESHAPE;
+    if ((a->C * es) % 16 || (a->ldx * es) % 16 || (a->ldo * es) % 16) return MI355X_ESHAPE;
+    if ((a->C * es) / 16 > 256 * GN_MAXVPT) return MI355X_ESHAPE;
+    if (!al16(a->x) || !al16(a->out) || !al16(a->beta)) return MI355X_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return a->dtype == MI355X_F32 ? run_groupnorm<float>(a, st) : run_groupnorm<bf16_t>(a, st);
+}

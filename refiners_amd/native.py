@@ -1,0 +1,476 @@
+"""ctypes binding of libmi355x_refiners.so (the C ABI declared in include/mi355x_refiners.h).
+
+This module is the ONLY place where Python touches the native library.  It deliberately passes nothing but raw
+device pointers, sizes, strides and scalars; torch is used as the owner of device memory and of the current HIP
+stream.  There is no CPU or PyTorch fallback here: if the library is missing or a kernel refuses a shape, the call
+raises `NativeError` (the fused fluxion nodes decide, *before* calling, whether a sub-tree is eligible).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor
+
+MI355X_F32 = 0
+MI355X_BF16 = 1
+MAX_SEG = 3
+
+_ERR = {0: "OK", -1: "EDTYPE", -2: "ESHAPE", -3: "ELAUNCH", -4: "EARG"}
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libmi355x_refiners.so"
+
+
+class NativeError(RuntimeError):
+    """Raised when the native library is unavailable or a native call returns a negative status."""
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("w", C.c_void_p),
+        ("ldw", C.c_int64),
+        ("k", C.c_int32),
+        ("ksize", C.c_int32),
+        ("stride", C.c_int32),
+        ("ups", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+    ]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("M", C.c_int32),
+        ("N", C.c_int32),
+        ("nseg", C.c_int32),
+        ("conv", C.c_int32),
+        ("B", C.c_int32),
+        ("OH", C.c_int32),
+        ("OW", C.c_int32),
+        ("seg", GemmSeg * MAX_SEG),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
+        ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p),
+        ("ld_rowbias", C.c_int64),
+        ("rows_per_group", C.c_int32),
+        ("geglu", C.c_int32),
+        ("res", C.c_void_p),
+        ("ldres", C.c_int64),
+        ("zeros", C.c_void_p),
+    ]
+
+
+class KvStream(C.Structure):
+    _fields_ = [
+        ("k", C.c_void_p),
+        ("ldk", C.c_int64),
+        ("k_batch_stride", C.c_int64),
+        ("vt", C.c_void_p),
+        ("ldvt", C.c_int64),
+        ("vt_batch_stride", C.c_int64),
+        ("Lk", C.c_int32),
+        ("out_scale", C.c_float),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("D", C.c_int32),
+        ("Lq", C.c_int32),
+        ("nstream", C.c_int32),
+        ("q", C.c_void_p),
+        ("ldq", C.c_int64),
+        ("q_batch_stride", C.c_int64),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
+        ("o_batch_stride", C.c_int64),
+        ("scale", C.c_float),
+        ("kv", KvStream * 2),
+    ]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("M", C.c_int32),
+        ("C", C.c_int32),
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("gamma", C.c_void_p),
+        ("beta", C.c_void_p),
+        ("eps", C.c_float),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
+    ]
+
+
+class GroupNormArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("B", C.c_int32),
+        ("HW", C.c_int32),
+        ("C", C.c_int32),
+        ("G", C.c_int32),
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("gamma", C.c_void_p),
+        ("beta", C.c_void_p),
+        ("eps", C.c_float),
+        ("silu", C.c_int32),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
+        ("ws", C.c_void_p),
+    ]
+
+
+#: every symbol include/mi355x_refiners.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "mi355x_abi_version",
+    "mi355x_device_info",
+    "mi355x_gemm",
+    "mi355x_attention",
+    "mi355x_layernorm",
+    "mi355x_groupnorm_ws_floats",
+    "mi355x_groupnorm",
+    "mi355x_nchw_to_nhwc",
+    "mi355x_nhwc_to_nchw",
+    "mi355x_im2col3x3_nchw",
+    "mi355x_concat2",
+    "mi355x_axpby",
+    "mi355x_silu",
+    "mi355x_cfg_ddim_step",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: Optional[Path] = None) -> C.CDLL:
+    """Load the shared library (once). Raises NativeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise NativeError(
+            f"{p} is missing: build it with `python -m refiners_amd.build_native` (or __graft_entry__.build()). "
+            "There is no fallback path for the MI355X kernels."
+        )
+    try:
+        lib = C.CDLL(str(p))
+    except OSError as e:  # e.g. no HIP runtime on this machine
+        raise NativeError(f"cannot load {p}: {e}") from e
+    lib.mi355x_abi_version.restype = C.c_int
+    lib.mi355x_device_info.argtypes = [C.c_char_p, C.c_int32]
+    lib.mi355x_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+    lib.mi355x_attention.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
+    lib.mi355x_layernorm.argtypes = [C.POINTER(LayerNormArgs), C.c_void_p]
+    lib.mi355x_groupnorm.argtypes = [C.POINTER(GroupNormArgs), C.c_void_p]
+    lib.mi355x_groupnorm_ws_floats.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.mi355x_groupnorm_ws_floats.restype = C.c_int64
+    lib.mi355x_nchw_to_nhwc.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    lib.mi355x_nhwc_to_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    lib.mi355x_im2col3x3_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    lib.mi355x_concat2.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.mi355x_axpby.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mi355x_silu.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mi355x_cfg_ddim_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.mi355x_attention_set_glds.argtypes = [C.c_int]
+    if lib.mi355x_abi_version() != 1:
+        raise NativeError("libmi355x_refiners.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def available() -> bool:
+    try:
+        load()
+        return True
+    except NativeError:
+        return False
+
+
+def loaded_library_path() -> Optional[str]:
+    return str(LIB_PATH) if _lib is not None else None
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise NativeError(f"{what} failed with MI355X_{_ERR.get(status, status)}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return MI355X_F32
+    if dt == torch.bfloat16:
+        return MI355X_BF16
+    raise NativeError(f"unsupported dtype {dt} (the MI355X path computes in float32 or bfloat16)")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_info() -> str:
+    buf = C.create_string_buffer(256)
+    check(load().mi355x_device_info(buf, 256), "mi355x_device_info")
+    return buf.value.decode()
+
+
+_zeros: dict[int, Tensor] = {}
+
+
+def zero_page(device: torch.device) -> Tensor:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    z = _zeros.get(idx)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        _zeros[idx] = z
+    return z
+
+
+# ------------------------------------------------------------------------------------------------ weight packing
+def geglu_pack_index(n_out: int, device: torch.device | str = "cpu") -> Tensor:
+    """Row order of a GEGLU-fused Linear(C -> 2*n_out): packed row p holds reference row index[p].
+
+    Packed rows come in blocks of 64 = 32 value rows + 32 gate rows of the same 32 output columns, arranged so that the
+    lane that owns packed columns 16g+4j+r (j = 0..3, r = 0..3) of a block holds value columns 8g+4j+r (j < 2) and
+    the matching gate columns (j >= 2): see gemm.hip's epilogue.
+    """
+    assert n_out % 32 == 0, "GEGLU fusion needs the output width to be a multiple of 32"
+    p = torch.arange(2 * n_out, device=device)
+    blk, q = p // 64, p % 64
+    g, j, r = q // 16, (q // 4) % 4, q % 4
+    u = 8 * g + 4 * (j % 2) + r
+    return torch.where(j >= 2, n_out + 32 * blk + u, 32 * blk + u)
+
+
+def pack_conv_weight(w: Tensor) -> Tensor:
+    """OIHW conv weight -> [O][kh*kw*I] rows with K ordered (ky, kx, channel), as conv mode of mi355x_gemm expects."""
+    o, i, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ call wrappers
+def _seg_plain(x: Tensor, w: Tensor) -> tuple:
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1], (x.shape, w.shape)
+    assert x.stride(1) == 1 and w.stride(1) == 1
+    return (x, x.stride(0), w, w.stride(0), x.shape[1], 1, 1, 1, 0, 0)
+
+
+def gemm(
+    segs: Sequence[tuple[Tensor, Tensor]],
+    out: Tensor,
+    *,
+    bias: Optional[Tensor] = None,
+    rowbias: Optional[Tensor] = None,
+    rows_per_group: int = 1,
+    res: Optional[Tensor] = None,
+    geglu: bool = False,
+    M: Optional[int] = None,
+    N: Optional[int] = None,
+) -> Tensor:
+    """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s])."""
+    a = GemmArgs()
+    x0, w0 = segs[0]
+    a.dtype = dtype_code(x0.dtype)
+    a.M = M if M is not None else x0.shape[0]
+    a.N = N if N is not None else w0.shape[0]
+    a.nseg = len(segs)
+    a.conv = 0
+    keep = []
+    for s, (x, w) in enumerate(segs):
+        t = _seg_plain(x, w)
+        sg = a.seg[s]
+        sg.x, sg.ldx, sg.w, sg.ldw, sg.k = t[0].data_ptr(), t[1], t[2].data_ptr(), t[3], t[4]
+        sg.ksize, sg.stride, sg.ups, sg.H, sg.W = 1, 1, 1, 0, 0
+        keep.append((x, w))
+    _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, geglu)
+    check(load().mi355x_gemm(C.byref(a), stream_ptr()), "mi355x_gemm")
+    return out
+
+
+def conv_gemm(
+    segs: Sequence[tuple[Tensor, Tensor, int, int, int]],
+    out: Tensor,
+    B: int,
+    OH: int,
+    OW: int,
+    *,
+    bias: Optional[Tensor] = None,
+    rowbias: Optional[Tensor] = None,
+    rows_per_group: int = 1,
+    res: Optional[Tensor] = None,
+) -> Tensor:
+    """Implicit-GEMM convolution over NHWC images.
+
+    segs: (image [B,H,W,C] NHWC-contiguous or channel-sliced view, packed weight [N, ksize*ksize*C], ksize, stride, ups).
+    out: [B*OH*OW, N] rows (i.e. NHWC output).
+    """
+    a = GemmArgs()
+    img0, w0 = segs[0][0], segs[0][1]
+    a.dtype = dtype_code(img0.dtype)
+    a.M = B * OH * OW
+    a.N = w0.shape[0]
+    a.nseg = len(segs)
+    a.conv = 1
+    a.B, a.OH, a.OW = B, OH, OW
+    for s, (img, w, ksize, stride, ups) in enumerate(segs):
+        assert img.dim() == 4 and img.stride(3) == 1, "conv segment must be an NHWC tensor [B,H,W,C]"
+        b, h, wd, c = img.shape
+        assert img.stride(1) == wd * img.stride(2) and img.stride(0) == h * img.stride(1), "pixels must be uniformly strided"
+        assert w.shape[1] == ksize * ksize * c and w.stride(1) == 1
+        sg = a.seg[s]
+        sg.x, sg.ldx, sg.w, sg.ldw, sg.k = img.data_ptr(), img.stride(2), w.data_ptr(), w.stride(0), c
+        sg.ksize, sg.stride, sg.ups, sg.H, sg.W = ksize, stride, ups, h, wd
+    a.zeros = zero_page(img0.device).data_ptr()
+    _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, False)
+    check(load().mi355x_gemm(C.byref(a), stream_ptr()), "mi355x_gemm(conv)")
+    return out
+
+
+def _fill_epilogue(a: GemmArgs, out: Tensor, bias, rowbias, rows_per_group, res, geglu) -> None:
+    assert out.dim() == 2 and out.stride(1) == 1
+    a.out, a.ldo = out.data_ptr(), out.stride(0)
+    a.bias = bias.data_ptr() if bias is not None else None
+    if rowbias is not None:
+        assert rowbias.dim() == 2 and rowbias.stride(1) == 1
+        a.rowbias, a.ld_rowbias, a.rows_per_group = rowbias.data_ptr(), rowbias.stride(0), rows_per_group
+    else:
+        a.rowbias, a.ld_rowbias, a.rows_per_group = None, 0, 1
+    if res is not None:
+        assert res.dim() == 2 and res.stride(1) == 1
+        a.res, a.ldres = res.data_ptr(), res.stride(0)
+    else:
+        a.res, a.ldres = None, 0
+    a.geglu = 1 if geglu else 0
+
+
+def attention(
+    q: Tensor,
+    out: Tensor,
+    num_heads: int,
+    streams: Sequence[tuple[Tensor, Tensor, int, float]],
+    scale: Optional[float] = None,
+) -> Tensor:
+    """q, out: [B, Lq, H*D] views (last dim contiguous). streams: (k [B, Lk(+), H*D] view, vt [H*D, B, Lkp] view, Lk, out_scale)."""
+    a = AttnArgs()
+    B, Lq, HD = q.shape
+    D = HD // num_heads
+    a.dtype = dtype_code(q.dtype)
+    a.B, a.H, a.D, a.Lq, a.nstream = B, num_heads, D, Lq, len(streams)
+    assert q.stride(2) == 1 and out.stride(2) == 1
+    a.q, a.ldq, a.q_batch_stride = q.data_ptr(), q.stride(1), q.stride(0)
+    a.out, a.ldo, a.o_batch_stride = out.data_ptr(), out.stride(1), out.stride(0)
+    a.scale = scale if scale is not None else D ** -0.5
+    for s, (k, vt, Lk, osc) in enumerate(streams):
+        assert k.dim() == 3 and vt.dim() == 3 and k.stride(2) == 1 and vt.stride(2) == 1
+        kv = a.kv[s]
+        kv.k, kv.ldk, kv.k_batch_stride = k.data_ptr(), k.stride(1), k.stride(0)
+        kv.vt, kv.ldvt, kv.vt_batch_stride = vt.data_ptr(), vt.stride(0), vt.stride(1)
+        kv.Lk, kv.out_scale = Lk, osc
+    check(load().mi355x_attention(C.byref(a), stream_ptr()), "mi355x_attention")
+    return out
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Tensor) -> Tensor:
+    a = LayerNormArgs()
+    assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
+    a.dtype = dtype_code(x.dtype)
+    a.M, a.C = x.shape
+    a.x, a.ldx, a.gamma, a.beta, a.eps = x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps
+    a.out, a.ldo = out.data_ptr(), out.stride(0)
+    check(load().mi355x_layernorm(C.byref(a), stream_ptr()), "mi355x_layernorm")
+    return out
+
+
+_gn_ws: dict[tuple[int, int], Tensor] = {}
+
+
+def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool, out: Tensor) -> Tensor:
+    """x, out: [B, HW, C] views with contiguous channels."""
+    a = GroupNormArgs()
+    B, HW, Cc = x.shape
+    assert x.stride(2) == 1 and out.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and out.stride(0) == HW * out.stride(1)
+    need = load().mi355x_groupnorm_ws_floats(B, HW, Cc)
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)
+        _gn_ws[key] = ws
+    a.dtype = dtype_code(x.dtype)
+    a.B, a.HW, a.C, a.G = B, HW, Cc, groups
+    a.x, a.ldx, a.gamma, a.beta, a.eps, a.silu = x.data_ptr(), x.stride(1), gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
+    a.out, a.ldo, a.ws = out.data_ptr(), out.stride(1), ws.data_ptr()
+    check(load().mi355x_groupnorm(C.byref(a), stream_ptr()), "mi355x_groupnorm")
+    return out
+
+
+def nchw_to_nhwc(x: Tensor, out: Tensor) -> Tensor:
+    B, Cc, H, W = x.shape
+    assert x.is_contiguous() and out.stride(-1) == 1
+    check(load().mi355x_nchw_to_nhwc(dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, Cc, H * W, out.stride(-2), stream_ptr()), "mi355x_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: Tensor, out: Tensor, C_: int) -> Tensor:
+    """x: [B, HW, ld] rows; out: [B, C, H, W] contiguous."""
+    B, HW = x.shape[0], x.shape[1]
+    assert out.is_contiguous() and x.stride(-1) == 1
+    check(load().mi355x_nhwc_to_nchw(dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, C_, HW, x.stride(1), stream_ptr()), "mi355x_nhwc_to_nchw")
+    return out
+
+
+def im2col3x3_nchw(x: Tensor, out: Tensor) -> Tensor:
+    B, Cc, H, W = x.shape
+    assert x.is_contiguous() and out.dim() == 2 and out.is_contiguous()
+    check(load().mi355x_im2col3x3_nchw(dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, Cc, H, W, out.shape[1], stream_ptr()), "mi355x_im2col3x3_nchw")
+    return out
+
+
+def concat2(a_: Tensor, b_: Tensor, out: Tensor) -> Tensor:
+    """Channel concat of two row-major 2-D tensors [M, C1] ++ [M, C2] -> out [M, C1+C2]."""
+    M = a_.shape[0]
+    check(
+        load().mi355x_concat2(dtype_code(a_.dtype), a_.data_ptr(), a_.stride(0), a_.shape[1], b_.data_ptr(), b_.stride(0), b_.shape[1],
+                              out.data_ptr(), out.stride(0), M, stream_ptr()),
+        "mi355x_concat2",
+    )
+    return out
+
+
+def axpby(a_: Tensor, alpha: float, b_: Tensor, beta: float, out: Tensor) -> Tensor:
+    assert a_.is_contiguous() and b_.is_contiguous() and out.is_contiguous() and a_.numel() == b_.numel() == out.numel()
+    check(load().mi355x_axpby(dtype_code(a_.dtype), a_.data_ptr(), alpha, b_.data_ptr(), beta, out.data_ptr(), a_.numel(), stream_ptr()), "mi355x_axpby")
+    return out
+
+
+def silu(x: Tensor, out: Tensor) -> Tensor:
+    assert x.is_contiguous() and out.is_contiguous()
+    check(load().mi355x_silu(dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), x.numel(), stream_ptr()), "mi355x_silu")
+    return out
+
+
+def cfg_ddim_step(x: Tensor, unet_out: Tensor, coef: Tensor) -> Tensor:
+    """In-place: x <- ddim(x, cfg(unet_out)). unet_out = [uncond; cond] (2*x.numel() elements); coef: f32[5] on device."""
+    assert x.is_contiguous() and unet_out.is_contiguous() and unet_out.numel() == 2 * x.numel()
+    assert coef.dtype == torch.float32 and coef.numel() >= 5 and coef.is_cuda
+    check(load().mi355x_cfg_ddim_step(dtype_code(x.dtype), x.data_ptr(), unet_out.data_ptr(), coef.data_ptr(), x.numel(), stream_ptr()), "mi355x_cfg_ddim_step")
+    return x
+
+
+def set_glds(enabled: bool) -> None:
+    """A/B switch: global_load_lds staging (default) vs register staging, for the GEMM and attention tile loaders."""
+    lib = load()
+    lib.mi355x_set_option(b"glds", int(enabled))
+    lib.mi355x_attention_set_glds(int(enabled))

@@ -1,0 +1,299 @@
+"""Kernel-level parity cases: every C-ABI kernel against a plain PyTorch fp32 reference of the same op.
+
+Each case is a function returning (max_abs_err, ref_scale, tol_rel) — the caller asserts err <= tol_rel * ref_scale.
+The references are computed with stock torch ops in float32 ON THE SAME DEVICE from the same (dtype-rounded) inputs,
+so the float32 cases check the 1e-3 contract of BASELINE.json and the bfloat16 cases check bf16-rounding-sized errors.
+Used by tests/test_kernels_gpu.py (pytest -m gpu) and tools/probe.py (first-contact diagnostics on a GPU box).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from refiners_amd import native
+
+DEV = "cuda"
+
+
+def _tol(dtype: torch.dtype) -> float:
+    # relative to the reference's max-abs; f32: the north-star 1e-3 bar (we are far inside it); bf16: output rounding
+    return 1e-3 if dtype == torch.float32 else 1.6e-2
+
+
+def _rand(*shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(device=DEV, dtype=dtype)
+
+
+def _cmp(out: torch.Tensor, ref: torch.Tensor, dtype) -> tuple[float, float, float]:
+    out = out.float()
+    assert torch.isfinite(out).all(), "non-finite values in kernel output"
+    err = (out - ref).abs().max().item()
+    return err, max(ref.abs().max().item(), 1e-6), _tol(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_case(M, K, N, dtype, *, bias=False, res=False, rowbias=0, seed=0):
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2) if bias else None
+    r = _rand(M, N, dtype=dtype, seed=seed + 3) if res else None
+    rb = _rand(M // rowbias, N, dtype=dtype, seed=seed + 4) if rowbias else None
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, w)], out, bias=b, res=r, rowbias=rb, rows_per_group=rowbias or 1)
+    ref = x.float() @ w.float().t()
+    if bias:
+        ref = ref + b.float()
+    if rowbias:
+        ref = ref + rb.float().repeat_interleave(rowbias, dim=0)
+    if res:
+        ref = ref + r.float()
+    return _cmp(out, ref, dtype)
+
+
+def gemm_lora_case(M, K, N, dtype, ranks=(16, 16), seed=10):
+    """y = x W^T + b + sum_i s_i (x A_i^T) B_i^T as ONE fused launch after the skinny down-projection launch."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2)
+    scales = [1.0, 0.8, 0.5][: len(ranks)]
+    downs = [_rand(r, K, dtype=dtype, seed=seed + 10 + i, scale=1.0 / r) for i, r in enumerate(ranks)]
+    ups = [_rand(N, r, dtype=dtype, seed=seed + 20 + i, scale=0.05) for i, r in enumerate(ranks)]
+    rt = sum(ranks)
+    es = 4 if dtype == torch.float32 else 2
+    bk = 128 // es
+    rpad = (rt + bk - 1) // bk * bk
+    a_cat = torch.zeros(rpad, K, dtype=dtype, device=DEV)
+    bs_cat = torch.zeros(N, rpad, dtype=dtype, device=DEV)
+    o = 0
+    for d, u, s in zip(downs, ups, scales):
+        a_cat[o : o + d.shape[0]] = d
+        bs_cat[:, o : o + d.shape[0]] = (u.float() * s).to(dtype)
+        o += d.shape[0]
+    t = torch.empty(M, rpad, dtype=dtype, device=DEV)
+    native.gemm([(x, a_cat)], t)
+    out = torch.empty(M, N, dtype=dtype, device=DEV)
+    native.gemm([(x, w), (t, bs_cat)], out, bias=b)
+    ref = x.float() @ w.float().t() + b.float()
+    for d, u, s in zip(downs, ups, scales):
+        ref = ref + s * ((x.float() @ d.float().t()) @ u.float().t())
+    return _cmp(out, ref, dtype)
+
+
+def gemm_geglu_case(M, K, n_out, dtype, seed=30):
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(2 * n_out, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(2 * n_out, dtype=dtype, seed=seed + 2)
+    idx = native.geglu_pack_index(n_out, device=DEV)
+    wp, bp = w[idx].contiguous(), b[idx].contiguous()
+    out = torch.empty(M, n_out, dtype=dtype, device=DEV)
+    native.gemm([(x, wp)], out, bias=bp, geglu=True)
+    y = x.float() @ w.float().t() + b.float()
+    a, g = y.chunk(2, dim=-1)
+    ref = a * F.gelu(g, approximate="none")
+    return _cmp(out, ref, dtype)
+
+
+def gemm_vt_case(L, K, Cc, dtype, B=2, seed=40):
+    """V^T projection: out[Cc, B*L] = W_v @ x^T (operands swapped) -- the layout mi355x_attention consumes."""
+    x = _rand(B * L, K, dtype=dtype, seed=seed)
+    w = _rand(Cc, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    out = torch.empty(Cc, B * L, dtype=dtype, device=DEV)
+    native.gemm([(w, x)], out)
+    ref = w.float() @ x.float().t()
+    return _cmp(out, ref, dtype)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def conv_case(B, Cin, Cout, H, W, dtype, *, ksize=3, stride=1, ups=1, split=0, bias=True, rowbias=False, res=False, seed=50):
+    x = _rand(B, Cin, H, W, dtype=dtype, seed=seed)
+    w = _rand(Cout, Cin, ksize, ksize, dtype=dtype, seed=seed + 1, scale=(Cin * ksize * ksize) ** -0.5)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2) if bias else None
+    xin = F.interpolate(x.float(), scale_factor=ups, mode="nearest") if ups > 1 else x.float()
+    ref = F.conv2d(xin, w.float(), b.float() if bias else None, stride=stride, padding=ksize // 2)
+    OH, OW = ref.shape[2], ref.shape[3]
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    if split:
+        xa, xb = x_nhwc[..., :split].contiguous(), x_nhwc[..., split:].contiguous()
+        segs = [
+            (xa, native.pack_conv_weight(w[:, :split]), ksize, stride, ups),
+            (xb, native.pack_conv_weight(w[:, split:]), ksize, stride, ups),
+        ]
+    else:
+        segs = [(x_nhwc, native.pack_conv_weight(w), ksize, stride, ups)]
+    rb = r = None
+    if rowbias:
+        rb = _rand(B, Cout, dtype=dtype, seed=seed + 3)
+        ref = ref + rb.float()[:, :, None, None]
+    if res:
+        r = _rand(B * OH * OW, Cout, dtype=dtype, seed=seed + 4)
+        ref = ref + r.float().reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
+    out = torch.empty(B * OH * OW, Cout, dtype=dtype, device=DEV)
+    native.conv_gemm(segs, out, B, OH, OW, bias=b, rowbias=rb, rows_per_group=OH * OW, res=r)
+    got = out.float().reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
+    return _cmp(got, ref, dtype)
+
+
+def conv_first_case(B, H, W, dtype, seed=60):
+    """4 -> 320 input conv through im2col (K = 36 padded to one 128-byte block)."""
+    Cin, Cout = 4, 320
+    x = _rand(B, Cin, H, W, dtype=dtype, seed=seed)
+    w = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=1 / 6)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2)
+    es = 4 if dtype == torch.float32 else 2
+    kp = 128 // es * ((36 * es + 127) // 128)
+    cols = torch.empty(B * H * W, kp, dtype=dtype, device=DEV)
+    native.im2col3x3_nchw(x, cols)
+    wp = torch.zeros(Cout, kp, dtype=dtype, device=DEV)
+    wp[:, :36] = native.pack_conv_weight(w)
+    out = torch.empty(B * H * W, Cout, dtype=dtype, device=DEV)
+    native.gemm([(cols, wp)], out, bias=b)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    got = out.float().reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+    return _cmp(got, ref, dtype)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _vt_from_v(v: torch.Tensor, Lkp: int) -> torch.Tensor:
+    B, Lk, Cc = v.shape
+    vt = torch.zeros(Cc, B, Lkp, dtype=v.dtype, device=v.device)
+    vt[:, :, :Lk] = v.permute(2, 0, 1)
+    return vt
+
+
+def _sdpa_ref(q, k, v, H):
+    B, Lq, Cc = q.shape
+    D = Cc // H
+    qh = q.float().reshape(B, Lq, H, D).transpose(1, 2)
+    kh = k.float().reshape(B, -1, H, D).transpose(1, 2)
+    vh = v.float().reshape(B, -1, H, D).transpose(1, 2)
+    att = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(D), dim=-1)
+    return (att @ vh).transpose(1, 2).reshape(B, Lq, Cc)
+
+
+def attention_case(B, H, Lq, Lk, dtype, *, ip_tokens=0, ip_scale=0.7, spike=False, seed=70):
+    D = 64
+    Cc = H * D
+    q = _rand(B, Lq, Cc, dtype=dtype, seed=seed)
+    k = _rand(B, Lk, Cc, dtype=dtype, seed=seed + 1)
+    v = _rand(B, Lk, Cc, dtype=dtype, seed=seed + 2)
+    if spike:  # force large running-max jumps late in the key sequence (online-softmax rescale path)
+        k[:, Lk - 3] *= 6.0
+        k[:, Lk // 2] *= 4.0
+    Lkp = (Lk + 63) // 64 * 64
+    streams = [(k, _vt_from_v(v, Lkp), Lk, 1.0)]
+    ref = _sdpa_ref(q, k, v, H)
+    if ip_tokens:
+        k2 = _rand(B, ip_tokens, Cc, dtype=dtype, seed=seed + 3)
+        v2 = _rand(B, ip_tokens, Cc, dtype=dtype, seed=seed + 4)
+        streams.append((k2, _vt_from_v(v2, 64), ip_tokens, ip_scale))
+        ref = ref + ip_scale * _sdpa_ref(q, k2, v2, H)
+    out = torch.full((B, Lq, Cc), float("nan"), dtype=dtype, device=DEV)
+    native.attention(q, out, H, streams)
+    return _cmp(out, ref, dtype)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def layernorm_case(M, Cc, dtype, seed=80):
+    x = _rand(M, Cc, dtype=dtype, seed=seed) * 2 + 0.5
+    g = (1 + 0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 1)).to(dtype)
+    b = (0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 2)).to(dtype)
+    out = torch.empty_like(x)
+    native.layernorm(x, g, b, 1e-5, out)
+    ref = F.layer_norm(x.float(), (Cc,), g.float(), b.float(), 1e-5)
+    return _cmp(out, ref, dtype)
+
+
+def groupnorm_case(B, Cc, HW, dtype, silu=True, eps=1e-5, seed=90):
+    x = _rand(B, HW, Cc, dtype=dtype, seed=seed) * 1.5 + 3.0  # large mean: stresses the variance computation
+    g = (1 + 0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 1)).to(dtype)
+    b = (0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 2)).to(dtype)
+    out = torch.empty_like(x)
+    native.groupnorm_nhwc(x, g, b, 32, eps, silu, out)
+    xr = x.float().permute(0, 2, 1)  # [B, C, HW]
+    ref = F.group_norm(xr, 32, g.float(), b.float(), eps)
+    if silu:
+        ref = F.silu(ref)
+    return _cmp(out.float().permute(0, 2, 1), ref, dtype)
+
+
+# ------------------------------------------------------------------------------------------------ glue
+def layout_case(B, Cc, H, W, dtype, seed=100):
+    x = _rand(B, Cc, H, W, dtype=dtype, seed=seed)
+    nhwc = torch.empty(B, H * W, Cc, dtype=dtype, device=DEV)
+    native.nchw_to_nhwc(x, nhwc)
+    e1 = (nhwc.float() - x.float().permute(0, 2, 3, 1).reshape(B, H * W, Cc)).abs().max().item()
+    back = torch.empty_like(x)
+    native.nhwc_to_nchw(nhwc, back, Cc)
+    e2 = (back.float() - x.float()).abs().max().item()
+    return max(e1, e2), 1.0, 0.0
+
+
+def concat_axpby_case(M, C1, C2, dtype, seed=110):
+    a = _rand(M, C1, dtype=dtype, seed=seed)
+    b = _rand(M, C2, dtype=dtype, seed=seed + 1)
+    out = torch.empty(M, C1 + C2, dtype=dtype, device=DEV)
+    native.concat2(a, b, out)
+    e1 = (out.float() - torch.cat([a, b], 1).float()).abs().max().item()
+    c = _rand(M, C1, dtype=dtype, seed=seed + 2)
+    o2 = torch.empty_like(a)
+    native.axpby(a, 1.0, c, 0.55, o2)
+    ref = a.float() + 0.55 * c.float()
+    e2 = (o2.float() - ref).abs().max().item() / ref.abs().max().item()
+    return max(e1, e2), 1.0, (0.0 if dtype == torch.float32 else 8e-3) + 1e-6
+
+
+def cfg_ddim_case(n, dtype, seed=120):
+    x = _rand(n, dtype=dtype, seed=seed)
+    uo = _rand(2 * n, dtype=dtype, seed=seed + 1)
+    coef = torch.tensor([5.0, 0.8, 0.6, 0.9, math.sqrt(1 - 0.81)], dtype=torch.float32, device=DEV)
+    xf, u, c = x.float(), uo[:n].float(), uo[n:].float()
+    eps = u + 5.0 * (c - u)
+    x0 = (xf - 0.6 * eps) / 0.8
+    ref = 0.9 * x0 + math.sqrt(1 - 0.81) * eps
+    native.cfg_ddim_step(x, uo, coef)
+    return _cmp(x, ref, dtype)
+
+
+def all_cases():
+    """(name, thunk) list; sizes chosen so the whole list runs in well under a minute on one MI355X."""
+    cases = []
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        cases += [
+            (f"gemm_{tag}_256x320x384", lambda dt=dt: gemm_case(256, 320, 384, dt)),
+            (f"gemm_{tag}_2048x1280x1280_bias_res", lambda dt=dt: gemm_case(2048, 1280, 1280, dt, bias=True, res=True)),
+            (f"gemm_{tag}_154x2048x640_Medge", lambda dt=dt: gemm_case(154, 2048, 640, dt, bias=True)),
+            (f"gemm_{tag}_8x2048x1280_tinyM", lambda dt=dt: gemm_case(8, 2048, 1280, dt)),
+            (f"gemm_{tag}_300x640x200_Nedge", lambda dt=dt: gemm_case(300, 640, 200, dt, bias=True, res=True)),
+            (f"gemm_{tag}_2x1280x320_rowbiasless", lambda dt=dt: gemm_case(2, 1280, 320, dt, bias=True)),
+            (f"gemm_{tag}_512x640x640_rowbias", lambda dt=dt: gemm_case(512, 640, 640, dt, bias=True, rowbias=256)),
+            (f"gemm_{tag}_lora_2048x640x640", lambda dt=dt: gemm_lora_case(2048, 640, 640, dt)),
+            (f"gemm_{tag}_lora_154x2048x1280", lambda dt=dt: gemm_lora_case(154, 2048, 1280, dt)),
+            (f"gemm_{tag}_geglu_1024x640x2560", lambda dt=dt: gemm_geglu_case(1024, 640, 2560, dt)),
+            (f"gemm_{tag}_vt_1024x1280", lambda dt=dt: gemm_vt_case(1024, 1280, 1280, dt)),
+            (f"conv_{tag}_3x3_320_32", lambda dt=dt: conv_case(2, 320, 320, 32, 32, dt, rowbias=True)),
+            (f"conv_{tag}_3x3_s2", lambda dt=dt: conv_case(2, 320, 320, 32, 32, dt, stride=2)),
+            (f"conv_{tag}_3x3_ups2", lambda dt=dt: conv_case(1, 640, 640, 16, 16, dt, ups=2)),
+            (f"conv_{tag}_1x1_res", lambda dt=dt: conv_case(2, 320, 640, 16, 16, dt, ksize=1, res=True)),
+            (f"conv_{tag}_3x3_split_960", lambda dt=dt: conv_case(1, 960, 320, 16, 16, dt, split=640, rowbias=True, res=True)),
+            (f"conv_{tag}_3x3_to4", lambda dt=dt: conv_case(2, 320, 4, 32, 32, dt)),
+            (f"conv_{tag}_first_4to320", lambda dt=dt: conv_first_case(2, 32, 32, dt)),
+            (f"attn_{tag}_self_1024", lambda dt=dt: attention_case(2, 4, 1024, 1024, dt)),
+            (f"attn_{tag}_self_spike", lambda dt=dt: attention_case(1, 2, 256, 512, dt, spike=True)),
+            (f"attn_{tag}_cross_77", lambda dt=dt: attention_case(2, 10, 1024, 77, dt)),
+            (f"attn_{tag}_cross_77_ip4", lambda dt=dt: attention_case(2, 10, 512, 77, dt, ip_tokens=4)),
+            (f"attn_{tag}_Lq_edge_200", lambda dt=dt: attention_case(1, 2, 200, 128, dt)),
+            (f"layernorm_{tag}_640", lambda dt=dt: layernorm_case(1000, 640, dt)),
+            (f"layernorm_{tag}_1280", lambda dt=dt: layernorm_case(2048, 1280, dt)),
+            (f"groupnorm_{tag}_320_4096", lambda dt=dt: groupnorm_case(2, 320, 4096, dt)),
+            (f"groupnorm_{tag}_1280_1024", lambda dt=dt: groupnorm_case(2, 1280, 1024, dt, eps=1e-6, silu=False)),
+            (f"groupnorm_{tag}_2560_1024", lambda dt=dt: groupnorm_case(2, 2560, 1024, dt)),
+            (f"groupnorm_{tag}_960_4096", lambda dt=dt: groupnorm_case(1, 960, 4096, dt)),
+            (f"layout_{tag}", lambda dt=dt: layout_case(2, 4, 32, 32, dt)),
+            (f"layout_{tag}_320", lambda dt=dt: layout_case(1, 320, 16, 24, dt)),
+            (f"concat_axpby_{tag}", lambda dt=dt: concat_axpby_case(1000, 640, 320, dt)),
+            (f"cfg_ddim_{tag}", lambda dt=dt: cfg_ddim_case(4 * 128 * 128, dt)),
+        ]
+    return cases
