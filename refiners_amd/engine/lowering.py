@@ -1,0 +1,687 @@
+"""Lowering of a fluxion UNet tree (with whatever adapters are injected in it) to a flat program of MI355X kernels.
+
+The Chain tree stays the user-facing model (weights, inject/eject, scales).  `Lowering` walks it ONCE, pattern-matches
+the sub-trees of SURVEY.md section 8(a) and emits native launches (through refiners_amd.native, in recording mode) into
+two lists:
+
+  prologue : everything that depends only on the prompt-side inputs (text K / V^T projections incl. their LoRAs,
+             IP-Adapter K' / V'^T, TextTimeEmbedding, ControlLora ConditionEncoder) -- the reference recomputes these on
+             every step although they are constant over the 50 steps;
+  step     : everything that depends on the latents / timestep.
+
+Data layout: every activation is token-major ("NHWC"): a 2-D view [B*H*W, C] whose rows are pixels == tokens, so the
+NCHW <-> (B, L, C) transposes around each transformer (cross_attention.py:120-144) and the head split / merge copies
+(attentions.py:177-202) do not exist here.  Skip tensors are concatenated by one streaming kernel; everything else is
+fused into GEMM prologues / epilogues (see include/mi355x_refiners.h for the kernels).
+
+What is matched (anything else inside a UNet stage falls back to the node's own torch forward on an NCHW view):
+  Linear-like  = fl.Linear | LoraAdapter(fl.Linear, LinearLora...)              -> one GEMM (+ one skinny GEMM per
+                 distinct input when LoRAs are present; the up-projections ride as an extra K segment)
+  Conv-like    = fl.Conv2d | LoraAdapter(fl.Conv2d, Conv2dLora...) | RangeAdapter2d(Conv-like)   -> implicit GEMM
+  SDPA-like    = ScaledDotProductAttention | Sum(SDPA, ImageCrossAttention)     -> one flash kernel, 1 or 2 KV streams
+  ResidualBlock, CrossAttentionBlock2d (Linear or Conv2d projections), CrossAttentionBlock, Downsample, Upsample,
+  ResidualAccumulator / ResidualConcatenator, TimestepEncoder (SDXL and SD1.5), ControlLora / ZeroConvolution.
+The matcher works on class NAMES, so it accepts trees built from refiners_amd.fluxion as well as from refiners itself.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any, Callable, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .. import native
+
+
+class Unsupported(Exception):
+    """A sub-tree does not have the shape this lowering knows; the caller falls back to the unfused path."""
+
+
+# ------------------------------------------------------------------------------------------------ tree matching helpers
+def isa(m: Any, *names: str) -> bool:
+    return any(c.__name__ in names for c in type(m).__mro__)
+
+
+def kids(m: Any) -> list[Any]:
+    return list(m._modules.values())
+
+
+def cname(m: Any) -> str:
+    return type(m).__name__
+
+
+def _expect(cond: bool, what: str) -> None:
+    if not cond:
+        raise Unsupported(what)
+
+
+@dataclass
+class Act:
+    """A token-major activation: `t` is a [B*H*W, C] view with unit channel stride."""
+
+    t: Tensor
+    B: int
+    H: int
+    W: int
+
+    @property
+    def C(self) -> int:
+        return self.t.shape[1]
+
+    @property
+    def M(self) -> int:
+        return self.t.shape[0]
+
+    @property
+    def HW(self) -> int:
+        return self.H * self.W
+
+    def image(self) -> Tensor:
+        ld = self.t.stride(0)
+        return self.t.as_strided((self.B, self.H, self.W, self.C), (self.HW * ld, self.W * ld, ld, 1))
+
+    def tokens(self) -> Tensor:
+        ld = self.t.stride(0)
+        return self.t.as_strided((self.B, self.HW, self.C), (self.HW * ld, ld, 1))
+
+
+@dataclass
+class LoraPack:
+    a_cat: Tensor  # [rpad, K(...)] stacked down weights, zero padded rows
+    bs_cat: Tensor  # [N, rpad] stacked (scale * up) columns
+    conv: Optional[tuple[int, int, int]] = None  # (down ksize, up ksize, stride) for Conv2dLora
+
+
+@dataclass
+class LinSpec:
+    w: Tensor  # [N, K]
+    b: Optional[Tensor]
+    lora: Optional[LoraPack] = None
+    geglu: bool = False
+
+    @property
+    def N(self) -> int:
+        return self.w.shape[0]
+
+    @property
+    def K(self) -> int:
+        return self.w.shape[1]
+
+
+@dataclass
+class ConvSpec:
+    w: Tensor  # packed [O, k*k*I]
+    b: Optional[Tensor]
+    cin: int
+    cout: int
+    ksize: int
+    stride: int
+    lora: Optional[LoraPack] = None
+    time: Optional[tuple[str, LinSpec]] = None  # (context key, Linear(1280 -> cout)) of a RangeAdapter2d
+
+
+class Pool:
+    """Static device buffers for the program, reused as soon as the emitting code gives them back."""
+
+    def __init__(self, device: torch.device, dtype: torch.dtype) -> None:
+        self.device, self.dtype = device, dtype
+        self.free_list: dict[int, list[Tensor]] = {}
+        self.all: list[Tensor] = []
+        self.pinned: set[int] = set()
+
+    def get(self, rows: int, cols: int, dtype: Optional[torch.dtype] = None) -> Tensor:
+        dtype = dtype or self.dtype
+        n = rows * cols
+        if dtype == self.dtype:
+            bucket = self.free_list.get(n)
+            if bucket:
+                return bucket.pop().view(rows, cols)
+        t = torch.empty(n, device=self.device, dtype=dtype)
+        self.all.append(t)
+        return t.view(rows, cols)
+
+    def put(self, t: Optional[Tensor]) -> None:
+        if t is None or t.dtype != self.dtype or not t.is_contiguous():
+            return
+        base = t.reshape(-1)
+        if base.data_ptr() in self.pinned:
+            return
+        self.free_list.setdefault(base.numel(), []).append(base)
+
+    def pin(self, t: Tensor) -> None:
+        self.pinned.add(t.data_ptr())
+
+    def bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.all)
+
+
+class PackCache:
+    """Packed / converted copies of leaf weights, keyed on the identity and version of the source tensors, so that a
+    re-lowering after inject / eject / scale change only re-packs what actually changed."""
+
+    def __init__(self) -> None:
+        self.store: dict[tuple, Any] = {}
+        self.hits = 0
+        self.used: set[tuple] = set()
+
+    @staticmethod
+    def ident(*tensors: Optional[Tensor]) -> tuple:
+        return tuple((id(t), t._version, t.data_ptr()) if t is not None else None for t in tensors)
+
+    def get(self, key: tuple, make: Callable[[], Any]) -> Any:
+        self.used.add(key)
+        if key in self.store:
+            self.hits += 1
+            return self.store[key]
+        v = make()
+        self.store[key] = v
+        return v
+
+    def sweep(self) -> None:
+        for k in list(self.store):
+            if k not in self.used:
+                del self.store[k]
+        self.used = set()
+
+
+# ------------------------------------------------------------------------------------------------ the lowering
+class Lowering:
+    def __init__(self, device: torch.device, dtype: torch.dtype, cache: Optional[PackCache] = None) -> None:
+        self.device, self.dtype = device, dtype
+        self.es = 4 if dtype == torch.float32 else 2
+        self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
+        self.cache = cache or PackCache()
+        self.pool = Pool(device, dtype)
+        self.prologue: list = []
+        self.step: list = []
+        self._target = self.step
+        self.stats = {"fallback_nodes": [], "lora_sites": 0, "ip_sites": 0}
+
+    # -- recording targets ---------------------------------------------------------------------------------
+    class _Section:
+        def __init__(self, low: "Lowering", ops: list) -> None:
+            self.low, self.ops = low, ops
+
+        def __enter__(self) -> None:
+            self.saved = self.low._target
+            self.low._target = self.ops
+            self.rec = native.recording(self.ops)
+            self.rec.__enter__()
+
+        def __exit__(self, *exc: object) -> None:
+            self.rec.__exit__(*exc)
+            self.low._target = self.saved
+
+    def in_prologue(self) -> "Lowering._Section":
+        return Lowering._Section(self, self.prologue)
+
+    def in_step(self) -> "Lowering._Section":
+        return Lowering._Section(self, self.step)
+
+    def python(self, fn: Callable[[], None], what: str) -> None:
+        self._target.append((None, fn, what, ()))
+
+    # -- weight access ---------------------------------------------------------------------------------------
+    def cvt(self, t: Tensor) -> Tensor:
+        """The leaf's own storage when it already is a contiguous tensor of the compute dtype on the device."""
+        if t.device == self.device and t.dtype == self.dtype and t.is_contiguous() and t.data_ptr() % 16 == 0:
+            return t.detach()
+        return t.detach().to(device=self.device, dtype=self.dtype).contiguous()
+
+    def _w(self, t: Optional[Tensor], tag: str = "cvt") -> Optional[Tensor]:
+        if t is None:
+            return None
+        return self.cache.get((tag,) + PackCache.ident(t), lambda: self.cvt(t))
+
+    def _unwrap_lora(self, node: Any, leaf_cls: str) -> tuple[Any, list[Any]]:
+        """node = leaf | LoraAdapter(leaf, lora...) -> (leaf, [lora...])."""
+        if isa(node, "LoraAdapter"):
+            ch = kids(node)
+            _expect(len(ch) >= 1 and isa(ch[0], leaf_cls), f"LoraAdapter target is {cname(ch[0]) if ch else None}, wanted {leaf_cls}")
+            loras = ch[1:]
+            for lr in loras:
+                c = kids(lr)
+                _expect(isa(lr, "Lora") and len(c) == 3 and isa(c[2], "Multiply") and c[2].bias == 0.0, "unexpected Lora layout")
+            return ch[0], loras
+        _expect(isa(node, leaf_cls), f"expected {leaf_cls}-like node, got {cname(node)}")
+        return node, []
+
+    def _lora_pack_linear(self, loras: list[Any], n_out: int, k_in: int, row_perm: Optional[Tensor]) -> Optional[LoraPack]:
+        if not loras:
+            return None
+        downs = [kids(lr)[0].weight for lr in loras]
+        ups = [kids(lr)[1].weight for lr in loras]
+        scales = tuple(float(kids(lr)[2].scale) for lr in loras)
+        key = ("lora",) + PackCache.ident(*downs, *ups) + scales + (None if row_perm is None else "geglu",)
+
+        def make() -> LoraPack:
+            rt = sum(d.shape[0] for d in downs)
+            rpad = (rt + self.kblk - 1) // self.kblk * self.kblk
+            a = torch.zeros(rpad, k_in, device=self.device, dtype=self.dtype)
+            bs = torch.zeros(n_out, rpad, device=self.device, dtype=self.dtype)
+            o = 0
+            for d, u, s in zip(downs, ups, scales):
+                r = d.shape[0]
+                _expect(tuple(d.shape) == (r, k_in) and tuple(u.shape) == (n_out, r), "LoRA shape does not match its target")
+                a[o : o + r] = d.detach().to(device=self.device, dtype=self.dtype)
+                bs[:, o : o + r] = (u.detach().to(device=self.device, dtype=torch.float32) * s).to(self.dtype)
+                o += r
+            if row_perm is not None:
+                bs = bs[row_perm].contiguous()
+            return LoraPack(a, bs)
+
+        self.stats["lora_sites"] += 1
+        return self.cache.get(key, make)
+
+    def linear_spec(self, node: Any, geglu: bool = False) -> LinSpec:
+        if isa(node, "Conv2d") and not isa(node, "LoraAdapter"):  # 1x1 conv used as a token projection (SD1.5)
+            _expect(node.kernel_size == (1, 1) and node.stride == (1, 1), "only 1x1 convs can act as Linear")
+            w = self.cache.get(("conv1x1",) + PackCache.ident(node.weight), lambda: self.cvt(node.weight.detach().reshape(node.out_channels, node.in_channels)))
+            return LinSpec(w, self._w(node.bias))
+        leaf, loras = self._unwrap_lora(node, "Linear")
+        w, b = leaf.weight, leaf.bias
+        n_out, k_in = w.shape
+        _expect(k_in % self.kblk == 0, f"Linear in_features {k_in} is not a multiple of {self.kblk}")
+        perm = None
+        if geglu:
+            _expect(n_out % 64 == 0, "GEGLU width must be a multiple of 64")
+            perm = self.cache.get(("geglu_idx", n_out), lambda: native.geglu_pack_index(n_out // 2, device=self.device))
+            wp = self.cache.get(("geglu_w",) + PackCache.ident(w), lambda: self.cvt(w)[perm].contiguous())
+            bp = None if b is None else self.cache.get(("geglu_b",) + PackCache.ident(b), lambda: self.cvt(b)[perm].contiguous())
+            return LinSpec(wp, bp, self._lora_pack_linear(loras, n_out, k_in, perm), geglu=True)
+        return LinSpec(self._w(w), self._w(b), self._lora_pack_linear(loras, n_out, k_in, None))
+
+    def conv_spec(self, node: Any) -> ConvSpec:
+        time = None
+        if isa(node, "RangeAdapter2d"):
+            ch = kids(node)
+            _expect(len(ch) == 2 and isa(ch[1], "Chain"), "unexpected RangeAdapter2d layout")
+            tc = kids(ch[1])
+            _expect(len(tc) == 4 and isa(tc[0], "UseContext") and isa(tc[1], "SiLU") and isa(tc[3], "Reshape"), "unexpected RangeAdapter2d time branch")
+            _expect(tc[0].context == "range_adapter", "RangeAdapter2d reads an unexpected context")
+            time = (tc[0].key, self.linear_spec(tc[2]))
+            node = ch[0]
+        leaf, loras = self._unwrap_lora(node, "Conv2d")
+        w = leaf.weight
+        o, i, kh, kw = w.shape
+        _expect(kh == kw and kh in (1, 3), f"conv kernel {kh}x{kw} not supported")
+        _expect(leaf.stride[0] == leaf.stride[1] and leaf.stride[0] in (1, 2), "conv stride not supported")
+        pad = leaf.padding if isinstance(leaf.padding, tuple) else (leaf.padding, leaf.padding)
+        _expect(tuple(pad) == (kh // 2, kh // 2), "only 'same'-style padding k//2 is supported")
+        _expect(leaf.groups == 1 and tuple(leaf.dilation) == (1, 1), "grouped / dilated conv not supported")
+        _expect((i * self.es) % 128 == 0, f"conv in_channels {i} not 128-byte aligned")
+        wp = self.cache.get(("convw",) + PackCache.ident(w), lambda: native.pack_conv_weight(self.cvt(w)))
+        lora = None
+        if loras:
+            downs = [kids(lr)[0] for lr in loras]
+            ups = [kids(lr)[1] for lr in loras]
+            kd, ku = downs[0].kernel_size[0], ups[0].kernel_size[0]
+            _expect(all(d.kernel_size == (kd, kd) and tuple(d.stride) == tuple(leaf.stride) for d in downs), "Conv2dLora down convs differ")
+            _expect(all(u.kernel_size == (ku, ku) and tuple(u.stride) == (1, 1) for u in ups), "Conv2dLora up convs differ")
+            _expect(kd in (1, 3) and ku in (1, 3), "Conv2dLora kernel not supported")
+            scales = tuple(float(kids(lr)[2].scale) for lr in loras)
+            key = ("convlora",) + PackCache.ident(*[d.weight for d in downs], *[u.weight for u in ups]) + scales
+
+            def make() -> LoraPack:
+                rt = sum(d.weight.shape[0] for d in downs)
+                rpad = (rt + self.kblk - 1) // self.kblk * self.kblk
+                a = torch.zeros(rpad, kd * kd * i, device=self.device, dtype=self.dtype)
+                bs4 = torch.zeros(o, rpad, ku, ku, device=self.device, dtype=torch.float32)
+                off = 0
+                for d, u, s in zip(downs, ups, scales):
+                    r = d.weight.shape[0]
+                    a[off : off + r] = native.pack_conv_weight(d.weight.detach().to(device=self.device, dtype=self.dtype))
+                    bs4[:, off : off + r] = u.weight.detach().to(device=self.device, dtype=torch.float32) * s
+                    off += r
+                return LoraPack(a, native.pack_conv_weight(bs4.to(self.dtype)), conv=(kd, ku, leaf.stride[0]))
+
+            lora = self.cache.get(key, make)
+            self.stats["lora_sites"] += 1
+        return ConvSpec(wp, self._w(leaf.bias), i, o, kh, leaf.stride[0], lora, time)
+
+    # -- emitters: GEMM family -------------------------------------------------------------------------------
+    def lora_down(self, x: Tensor, lora: LoraPack) -> Tensor:
+        t = self.pool.get(x.shape[0], lora.a_cat.shape[0])
+        native.gemm([(x, lora.a_cat)], t)
+        return t
+
+    def linear(self, x: Tensor, spec: LinSpec, *, res: Optional[Tensor] = None, out: Optional[Tensor] = None,
+               rows: Optional[int] = None, lora_t: Optional[Tensor] = None) -> Tensor:
+        """out[M, N(/2 if geglu)] = epi(x W^T + b (+ LoRA) (+ res)).  `lora_t` lets callers share one down-projection
+        launch between Linears that read the same x."""
+        M = x.shape[0]
+        n_cols = spec.N // 2 if spec.geglu else spec.N
+        if out is None:
+            out = self.pool.get(M, n_cols)
+        segs = [(x, spec.w)]
+        t = None
+        if spec.lora is not None:
+            t = lora_t if lora_t is not None else self.lora_down(x, spec.lora)
+            segs.append((t, spec.lora.bs_cat))
+        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu)
+        if t is not None and lora_t is None:
+            self.pool.put(t)
+        return out
+
+    def linear_T(self, x: Tensor, spec: LinSpec, out_t: Tensor) -> Tensor:
+        """out_t[N, M] = W x^T (+ LoRA): the V^T layout mi355x_attention consumes (operands swapped, no bias)."""
+        _expect(spec.b is None, "transposed projection with bias is not supported")
+        segs = [(spec.w, x)]
+        t = None
+        if spec.lora is not None:
+            t = self.lora_down(x, spec.lora)
+            segs.append((spec.lora.bs_cat, t))
+        native.gemm(segs, out_t)
+        self.pool.put(t)
+        return out_t
+
+    def conv(self, a: Act, spec: ConvSpec, *, rowbias: Optional[Tensor] = None, res: Optional[Tensor] = None, ups: int = 1,
+             shortcut: Optional[tuple[Act, ConvSpec]] = None, bias: Optional[Tensor] = "spec") -> Act:  # type: ignore[assignment]
+        """Implicit-GEMM convolution of a token-major image; optional fused extras:
+        rowbias = per-sample channel bias (time embedding), res = residual rows, ups = nearest upsampling of the input,
+        shortcut = a second (1x1) convolution of another image accumulated into the same output tile."""
+        H, W = a.H * ups, a.W * ups
+        OH, OW = (H + spec.stride - 1) // spec.stride, (W + spec.stride - 1) // spec.stride
+        out = self.pool.get(a.B * OH * OW, spec.cout)
+        segs = [(a.image(), spec.w, spec.ksize, spec.stride, ups)]
+        t = None
+        if spec.lora is not None:
+            kd, ku, st = spec.lora.conv  # type: ignore[misc]
+            t = self.pool.get(a.B * OH * OW, spec.lora.a_cat.shape[0])
+            native.conv_gemm([(a.image(), spec.lora.a_cat, kd, st, ups)], t, a.B, OH, OW)
+            segs.append((Act(t, a.B, OH, OW).image(), spec.lora.bs_cat, ku, 1, 1))
+        b = spec.b if isinstance(bias, str) else bias
+        if shortcut is not None:
+            sa, sspec = shortcut
+            _expect(sspec.lora is None and sspec.ksize == 1 and sspec.stride == 1, "unsupported shortcut convolution")
+            segs.append((sa.image(), sspec.w, 1, 1, 1))
+        _expect(len(segs) <= native.MAX_SEG, "too many K segments for one conv launch")
+        native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res)
+        self.pool.put(t)
+        return Act(out, a.B, OH, OW)
+
+    # -- emitters: norms / glue ------------------------------------------------------------------------------
+    def groupnorm(self, a: Act, gn: Any, silu: bool) -> Act:
+        _expect(isa(gn, "GroupNorm") and gn.num_channels == a.C, "GroupNorm channel mismatch")
+        out = self.pool.get(a.M, a.C)
+        native.groupnorm_nhwc(a.tokens(), self._w(gn.weight), self._w(gn.bias), gn.num_groups, gn.eps, silu, Act(out, a.B, a.H, a.W).tokens())
+        return Act(out, a.B, a.H, a.W)
+
+    def layernorm(self, x: Tensor, ln: Any) -> Tensor:
+        _expect(isa(ln, "LayerNorm") and tuple(ln.normalized_shape) == (x.shape[1],), "LayerNorm shape mismatch")
+        out = self.pool.get(x.shape[0], x.shape[1])
+        native.layernorm(x, self._w(ln.weight), self._w(ln.bias), ln.eps, out)
+        return out
+
+    # -- attention ---------------------------------------------------------------------------------------------
+    def _split_attention(self, att: Any) -> tuple[list[Any], Any, Any, Optional[Any]]:
+        """Attention | SelfAttention | CrossAttentionAdapter(Attention) -> ([q, k, v nodes], sdpa-like, out node, ip)."""
+        if isa(att, "CrossAttentionAdapter"):
+            att = kids(att)[0]
+        _expect(isa(att, "Attention"), f"expected an Attention chain, got {cname(att)}")
+        ch = kids(att)
+        if isa(att, "SelfAttention"):
+            _expect(len(ch) == 4 and isa(ch[0], "Parallel") and all(isa(c, "Identity") for c in kids(ch[0])), "unexpected SelfAttention layout")
+            ch = ch[1:]
+        _expect(len(ch) == 3 and isa(ch[0], "Distribute") and len(kids(ch[0])) == 3, "unexpected Attention layout")
+        sd = ch[1]
+        ip = None
+        if isa(sd, "Sum"):
+            sc = kids(sd)
+            _expect(len(sc) == 2 and isa(sc[0], "ScaledDotProductAttention") and isa(sc[1], "ImageCrossAttention"), "unexpected Sum around SDPA")
+            ip, sd = sc[1], sc[0]
+        _expect(isa(sd, "ScaledDotProductAttention") and not sd.is_causal, "causal or unknown SDPA node")
+        _expect(sd.num_heads == att.num_heads, "head count mismatch")
+        return kids(ch[0]), sd, ch[2], ip
+
+    def sdpa(self, q: Tensor, B: int, heads: int, streams: list[tuple[Tensor, Tensor, int, float]], v_plain: Optional[list[Tensor]] = None) -> Tensor:
+        """q: [B*Lq, C]; streams: (k [B*Lkp, C], vt [C, B*Lkp], Lk, out_scale) with Lkp = rows per sample."""
+        M, C = q.shape
+        Lq = M // B
+        out = self.pool.get(M, C)
+        d = C // heads
+        if d == 64:
+            q3 = q.view(B, Lq, C)
+            st = []
+            for k, vt, Lk, osc in streams:
+                lkp = k.shape[0] // B
+                st.append((k.view(B, lkp, C), vt.view(C, B, vt.shape[1] // B), Lk, osc))
+            native.attention(q3, out.view(B, Lq, C), heads, st)
+            return out
+        # head dims the flash kernel does not cover (SD1.5: 40 / 80 / 160): torch SDPA on the same token-major tensors
+        assert v_plain is not None
+
+        def run() -> None:
+            acc = None
+            for (k, _vt, Lk, osc), v in zip(streams, v_plain):
+                lkp = k.shape[0] // B
+                qh = q.view(B, Lq, heads, d).transpose(1, 2)
+                kh = k.view(B, lkp, heads, d)[:, :Lk].transpose(1, 2)
+                vh = v.view(B, lkp, heads, d)[:, :Lk].transpose(1, 2)
+                y = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(M, C)
+                acc = y * osc if acc is None else acc + y * osc
+            out.copy_(acc)
+
+        self.python(run, f"torch_sdpa_d{d}")
+        self.stats["fallback_nodes"].append(f"SDPA(head_dim={d})")
+        return out
+
+    @staticmethod
+    def _pad_keys(n: int) -> int:
+        return (n + 63) // 64 * 64
+
+    def project_kv(self, src: Tensor, B: int, k_node: Any, v_node: Any, heads: int) -> tuple[Tensor, Tensor, Optional[Tensor]]:
+        """K rows [B*Lp, C] and V^T [C, B*Lp] of a key/value source [B*Lp, Ck] (Lp = keys per sample, padded to 64)."""
+        ks, vs = self.linear_spec(k_node), self.linear_spec(v_node)
+        _expect(ks.b is None and vs.b is None, "key / value projections with bias are not supported")
+        C = ks.N
+        k = self.pool.get(src.shape[0], C)
+        self.pool.pin(k)
+        self.linear(src, ks, out=k)
+        if C // heads == 64:
+            vt = self.pool.get(C, src.shape[0])
+            self.pool.pin(vt)
+            self.linear_T(src, vs, vt)
+            return k, vt, None
+        v = self.pool.get(src.shape[0], C)
+        self.pool.pin(v)
+        self.linear(src, vs, out=v)
+        return k, v, v
+
+    def self_attention(self, x: Tensor, B: int, ln: Any, att: Any) -> Tensor:
+        """x += Wo SDPA(Wq h, Wk h, Wv h), h = LN(x)   (cross_attention.py:44-49; attentions.py:319-385)."""
+        (qn, kn, vn), sd, on, ip = self._split_attention(att)
+        _expect(ip is None, "image cross-attention on a self-attention")
+        heads = sd.num_heads
+        h = self.layernorm(x, ln)
+        qs, ks, vs = self.linear_spec(qn), self.linear_spec(kn), self.linear_spec(vn)
+        _expect(qs.b is None and ks.b is None and vs.b is None, "q/k/v bias not supported")
+        M, C = x.shape
+        native_path = (C // heads) == 64
+        if qs.lora is None and ks.lora is None:
+            wqk = self.cache.get(("qk",) + PackCache.ident(qs.w, ks.w), lambda: torch.cat([qs.w, ks.w], 0).contiguous())
+            qk = self.pool.get(M, 2 * C)
+            native.gemm([(h, wqk)], qk)
+            q, k = qk[:, :C], qk[:, C:]
+        else:
+            qk = None
+            q = self.linear(h, qs)
+            k = self.linear(h, ks)
+        if native_path:
+            vt = self.pool.get(C, M)
+            self.linear_T(h, vs, vt)
+            o = self.sdpa(q, B, heads, [(k, vt, M // B, 1.0)])
+            self.pool.put(vt)
+        else:
+            v = self.linear(h, vs)
+            o = self.sdpa(q, B, heads, [(k, v, M // B, 1.0)], v_plain=[v])
+            self.pool.put(v)
+        self.pool.put(h)
+        if qk is not None:
+            self.pool.put(qk)
+        else:
+            self.pool.put(q)
+            self.pool.put(k)
+        self.linear(o, self.linear_spec(on), res=x, out=x)
+        self.pool.put(o)
+        return x
+
+    def cross_attention(self, x: Tensor, B: int, ln: Any, par: Any, att: Any, ctx: "UNetContext") -> Tensor:
+        """x += Wo (SDPA(Wq LN(x), K_text, V_text) [+ s SDPA(q, K_img, V_img)])   (cross_attention.py:50-68,
+        image_prompt.py:237-309).  K / V^T of the text and image tokens are produced in the prologue."""
+        pc = kids(par)
+        _expect(len(pc) == 3 and isa(pc[0], "Identity") and all(isa(c, "UseContext") for c in pc[1:]), "unexpected cross-attention Parallel")
+        _expect(pc[1].context == pc[2].context and pc[1].key == pc[2].key, "key and value read different contexts")
+        (qn, kn, vn), sd, on, ip = self._split_attention(att)
+        heads = sd.num_heads
+        src, Lk = ctx.tokens(pc[1].context, pc[1].key)
+        with self.in_prologue():
+            k, v_or_vt, v_plain = self.project_kv(src, B, kn, vn, heads)
+        streams = [(k, v_or_vt, Lk, 1.0)]
+        plains = [v_plain]
+        if ip is not None:
+            ic = kids(ip)
+            _expect(len(ic) == 3 and isa(ic[0], "Distribute") and isa(ic[1], "ScaledDotProductAttention") and isa(ic[2], "Multiply"), "unexpected ImageCrossAttention layout")
+            dc = kids(ic[0])
+            _expect(len(dc) == 3 and isa(dc[0], "Identity"), "unexpected ImageCrossAttention Distribute")
+            kc, vc = kids(dc[1]), kids(dc[2])
+            _expect(len(kc) == 2 and len(vc) == 2 and isa(kc[0], "UseContext") and isa(vc[0], "UseContext"), "unexpected image K/V branch")
+            _expect(ic[2].bias == 0.0 and ic[1].num_heads == heads, "unexpected ImageCrossAttention parameters")
+            isrc, ilk = ctx.tokens(kc[0].context, kc[0].key)
+            with self.in_prologue():
+                k2, v2, vp2 = self.project_kv(isrc, B, kc[1], vc[1], heads)
+            streams.append((k2, v2, ilk, float(ic[2].scale)))
+            plains.append(vp2)
+            self.stats["ip_sites"] += 1
+        h = self.layernorm(x, ln)
+        q = self.linear(h, self.linear_spec(qn))
+        self.pool.put(h)
+        o = self.sdpa(q, B, heads, streams, v_plain=plains if plains[0] is not None else None)
+        self.pool.put(q)
+        self.linear(o, self.linear_spec(on), res=x, out=x)
+        self.pool.put(o)
+        return x
+
+    def feed_forward(self, x: Tensor, ln: Any, w1: Any, glu: Any, w2: Any) -> Tensor:
+        """x += W2 GEGLU(W1 LN(x))   (cross_attention.py:69-72): GEGLU is the epilogue of the first GEMM."""
+        _expect(isa(glu, "GLU") and isa(glu.activation, "GeLU") and glu.activation.approximation.value == "none", "only GLU(GeLU(exact)) is fused")
+        h = self.layernorm(x, ln)
+        ff = self.linear(h, self.linear_spec(w1, geglu=True))
+        self.pool.put(h)
+        self.linear(ff, self.linear_spec(w2), res=x, out=x)
+        self.pool.put(ff)
+        return x
+
+    def cross_attention_block(self, blk: Any, x: Tensor, B: int, ctx: "UNetContext") -> Tensor:
+        ch = kids(blk)
+        _expect(len(ch) == 3 and all(isa(c, "Residual") for c in ch), "unexpected CrossAttentionBlock layout")
+        r1, r2, r3 = (kids(c) for c in ch)
+        _expect(len(r1) == 2 and len(r2) == 3 and len(r3) == 4, "unexpected CrossAttentionBlock residual bodies")
+        x = self.self_attention(x, B, r1[0], r1[1])
+        x = self.cross_attention(x, B, r2[0], r2[1], r2[2], ctx)
+        return self.feed_forward(x, r3[0], r3[1], r3[2], r3[3])
+
+    def cross_attention_2d(self, node: Any, a: Act, ctx: "UNetContext") -> Act:
+        """CrossAttentionBlock2d (cross_attention.py:92-175).  Token-major layout makes flatten / transpose free."""
+        ch = kids(node)
+        _expect(len(ch) == 3 and all(isa(c, "Chain") for c in ch), "unexpected CrossAttentionBlock2d layout")
+        head, blocks, tail = kids(ch[0]), kids(ch[1]), kids(ch[2])
+        _expect(isa(head[0], "GroupNorm"), "CrossAttentionBlock2d must start with GroupNorm")
+        proj_in = next((m for m in head[1:] if isa(m, "Linear", "Conv2d", "LoraAdapter")), None)
+        proj_out = next((m for m in tail if isa(m, "Linear", "Conv2d", "LoraAdapter")), None)
+        _expect(proj_in is not None and proj_out is not None, "projection layers not found")
+        others = [m for m in head[1:] + tail if m is not proj_in and m is not proj_out]
+        _expect(all(isa(m, "StatefulFlatten", "Transpose", "Parallel", "Unflatten") for m in others), "unexpected layers around the transformer")
+        g = self.groupnorm(a, head[0], silu=False)
+        h = self.linear(g.t, self.linear_spec(proj_in))
+        self.pool.put(g.t)
+        for blk in blocks:
+            _expect(isa(blk, "CrossAttentionBlock"), f"unexpected {cname(blk)} among transformer layers")
+            h = self.cross_attention_block(blk, h, a.B, ctx)
+        out = self.linear(h, self.linear_spec(proj_out), res=a.t)
+        self.pool.put(h)
+        return Act(out, a.B, a.H, a.W)
+
+    # -- ResidualBlock -------------------------------------------------------------------------------------------
+    def residual_block(self, node: Any, a: Act, ctx: "UNetContext") -> Act:
+        """conv2(SiLU(GN(conv1(SiLU(GN(x))) + time))) + shortcut(x)   (unet.py:6-51 + range_adapter.py:47-86):
+        time bias and bias ride in conv1's epilogue, the shortcut (identity or 1x1 conv) in conv2's."""
+        ch = kids(node)
+        _expect(len(ch) == 2 and isa(ch[0], "Chain"), "unexpected ResidualBlock layout")
+        body = kids(ch[0])
+        _expect(len(body) == 6 and isa(body[0], "GroupNorm") and isa(body[1], "SiLU") and isa(body[3], "GroupNorm") and isa(body[4], "SiLU"), "unexpected ResidualBlock body")
+        c1, c2 = self.conv_spec(body[2]), self.conv_spec(body[5])
+        _expect(c1.stride == 1 and c2.stride == 1 and c2.time is None, "unexpected convolutions in ResidualBlock")
+        g1 = self.groupnorm(a, body[0], silu=True)
+        rb = ctx.time_bias(c1) if c1.time is not None else None
+        h1 = self.conv(g1, c1, rowbias=rb)
+        self.pool.put(g1.t)
+        g2 = self.groupnorm(h1, body[3], silu=True)
+        self.pool.put(h1.t)
+        if isa(ch[1], "Identity"):
+            out = self.conv(g2, c2, res=a.t)
+        else:
+            sc = self.conv_spec(ch[1])
+            _expect(sc.ksize == 1 and sc.time is None, "unexpected shortcut")
+            if sc.lora is None and c2.lora is None:
+                both = self.cache.get(("bias_sum",) + PackCache.ident(c2.b, sc.b), lambda: (c2.b.float() + sc.b.float()).to(self.dtype))
+                out = self.conv(g2, c2, shortcut=(a, sc), bias=both)
+            else:
+                s = self.conv(a, sc)
+                out = self.conv(g2, c2, res=s.t)
+                self.pool.put(s.t)
+        self.pool.put(g2.t)
+        return out
+
+    # -- generic fallback -------------------------------------------------------------------------------------------
+    def torch_node(self, node: Any, a: Act, out_channels: Optional[int] = None, out_hw: Optional[tuple[int, int]] = None, what: str = "") -> Act:
+        """Run an unrecognised sub-tree through its own torch forward on an NCHW copy (shape-preserving unless told)."""
+        C2 = out_channels or a.C
+        H2, W2 = out_hw or (a.H, a.W)
+        nchw = torch.empty(a.B, a.C, a.H, a.W, device=self.device, dtype=self.dtype)
+        res = torch.empty(a.B, C2, H2, W2, device=self.device, dtype=self.dtype)
+        out = self.pool.get(a.B * H2 * W2, C2)
+        native.nhwc_to_nchw(a.tokens(), nchw, a.C)
+
+        def run() -> None:
+            y = node(nchw)
+            assert tuple(y.shape) == tuple(res.shape), f"fallback node {cname(node)} produced {tuple(y.shape)}, planned {tuple(res.shape)}"
+            res.copy_(y)
+
+        self.python(run, f"torch:{cname(node)}")
+        oa = Act(out, a.B, H2, W2)
+        native.nchw_to_nhwc(res, oa.tokens())
+        self.stats["fallback_nodes"].append(what or cname(node))
+        return oa
+
+
+# ------------------------------------------------------------------------------------------------ UNet-level context
+@dataclass
+class UNetContext:
+    """Compile-time stand-in for the reference's context store during one UNet forward."""
+
+    low: Lowering
+    B: int
+    text: dict[tuple[str, str], tuple[Tensor, int]] = field(default_factory=dict)  # padded token buffers + true length
+    temb_silu: dict[str, Tensor] = field(default_factory=dict)  # context key -> SiLU(timestep embedding) [B, 1280]
+    residuals: list[Any] = field(default_factory=list)
+    shapes: list[tuple[int, int]] = field(default_factory=list)
+
+    def tokens(self, context: str, key: str) -> tuple[Tensor, int]:
+        got = self.text.get((context, key))
+        if got is None:
+            raise Unsupported(f"context {context}.{key} is not a registered token input")
+        return got
+
+    def time_bias(self, spec: ConvSpec) -> Tensor:
+        key, lin = spec.time  # type: ignore[misc]
+        src = self.temb_silu.get(key)
+        if src is None:
+            raise Unsupported(f"timestep embedding '{key}' has not been produced yet")
+        out = self.low.pool.get(self.B, lin.N)
+        self.low.pool.pin(out)
+        self.low.linear(src, lin, out=out)
+        return out

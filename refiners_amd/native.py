@@ -226,6 +226,59 @@ def device_info() -> str:
     return buf.value.decode()
 
 
+
+# ------------------------------------------------------------------------------------------------ launch / record
+_recorder: Optional[list] = None
+
+
+class recording:
+    """Context manager: native calls made inside are appended to `ops` instead of being launched.
+
+    The engine lowers a Chain tree once into such a list (all argument structs prebuilt, all buffers static) and then
+    replays it, directly or under HIP-graph capture.  An entry is (cfunc, args, name, keepalive)."""
+
+    def __init__(self, ops: list) -> None:
+        self.ops = ops
+
+    def __enter__(self) -> list:
+        global _recorder
+        self._saved = _recorder
+        _recorder = self.ops
+        return self.ops
+
+    def __exit__(self, *exc: object) -> None:
+        global _recorder
+        _recorder = self._saved
+
+
+def _launch(sym: str, args: tuple, what: str, keep: tuple = ()) -> None:
+    fn = getattr(load(), sym)
+    if _recorder is not None:
+        _recorder.append((fn, args, what, keep))
+        return
+    check(fn(*args, stream_ptr()), what)
+
+
+def record_python(fn, what: str = "python") -> bool:
+    """Record a Python callable (torch glue or an unfused fallback sub-tree) as a step of the program being recorded.
+    Returns False when nothing is recording (the caller then runs `fn` itself)."""
+    if _recorder is None:
+        return False
+    _recorder.append((None, fn, what, ()))
+    return True
+
+
+def replay(ops: list) -> None:
+    """Launch a recorded program on the current stream."""
+    s = stream_ptr()
+    for fn, args, what, _ in ops:
+        if fn is None:
+            args()
+            continue
+        st = fn(*args, s)
+        if st:
+            check(st, what)
+
 _zeros: dict[int, Tensor] = {}
 
 
@@ -295,7 +348,7 @@ def gemm(
         sg.ksize, sg.stride, sg.ups, sg.H, sg.W = 1, 1, 1, 0, 0
         keep.append((x, w))
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, geglu)
-    check(load().mi355x_gemm(C.byref(a), stream_ptr()), "mi355x_gemm")
+    _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm")
     return out
 
 
@@ -334,7 +387,7 @@ def conv_gemm(
         sg.ksize, sg.stride, sg.ups, sg.H, sg.W = ksize, stride, ups, h, wd
     a.zeros = zero_page(img0.device).data_ptr()
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, False)
-    check(load().mi355x_gemm(C.byref(a), stream_ptr()), "mi355x_gemm(conv)")
+    _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm(conv)")
     return out
 
 
@@ -378,7 +431,7 @@ def attention(
         kv.k, kv.ldk, kv.k_batch_stride = k.data_ptr(), k.stride(1), k.stride(0)
         kv.vt, kv.ldvt, kv.vt_batch_stride = vt.data_ptr(), vt.stride(0), vt.stride(1)
         kv.Lk, kv.out_scale = Lk, osc
-    check(load().mi355x_attention(C.byref(a), stream_ptr()), "mi355x_attention")
+    _launch("mi355x_attention", (C.byref(a),), "mi355x_attention")
     return out
 
 
@@ -389,7 +442,7 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Tensor) -
     a.M, a.C = x.shape
     a.x, a.ldx, a.gamma, a.beta, a.eps = x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps
     a.out, a.ldo = out.data_ptr(), out.stride(0)
-    check(load().mi355x_layernorm(C.byref(a), stream_ptr()), "mi355x_layernorm")
+    _launch("mi355x_layernorm", (C.byref(a),), "mi355x_layernorm")
     return out
 
 
@@ -412,14 +465,14 @@ def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: flo
     a.B, a.HW, a.C, a.G = B, HW, Cc, groups
     a.x, a.ldx, a.gamma, a.beta, a.eps, a.silu = x.data_ptr(), x.stride(1), gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
     a.out, a.ldo, a.ws = out.data_ptr(), out.stride(1), ws.data_ptr()
-    check(load().mi355x_groupnorm(C.byref(a), stream_ptr()), "mi355x_groupnorm")
+    _launch("mi355x_groupnorm", (C.byref(a),), "mi355x_groupnorm")
     return out
 
 
 def nchw_to_nhwc(x: Tensor, out: Tensor) -> Tensor:
     B, Cc, H, W = x.shape
     assert x.is_contiguous() and out.stride(-1) == 1
-    check(load().mi355x_nchw_to_nhwc(dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, Cc, H * W, out.stride(-2), stream_ptr()), "mi355x_nchw_to_nhwc")
+    _launch("mi355x_nchw_to_nhwc", (dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, Cc, H * W, out.stride(-2),), "mi355x_nchw_to_nhwc")
     return out
 
 
@@ -427,37 +480,34 @@ def nhwc_to_nchw(x: Tensor, out: Tensor, C_: int) -> Tensor:
     """x: [B, HW, ld] rows; out: [B, C, H, W] contiguous."""
     B, HW = x.shape[0], x.shape[1]
     assert out.is_contiguous() and x.stride(-1) == 1
-    check(load().mi355x_nhwc_to_nchw(dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, C_, HW, x.stride(1), stream_ptr()), "mi355x_nhwc_to_nchw")
+    _launch("mi355x_nhwc_to_nchw", (dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, C_, HW, x.stride(1),), "mi355x_nhwc_to_nchw")
     return out
 
 
 def im2col3x3_nchw(x: Tensor, out: Tensor) -> Tensor:
     B, Cc, H, W = x.shape
     assert x.is_contiguous() and out.dim() == 2 and out.is_contiguous()
-    check(load().mi355x_im2col3x3_nchw(dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, Cc, H, W, out.shape[1], stream_ptr()), "mi355x_im2col3x3_nchw")
+    _launch("mi355x_im2col3x3_nchw", (dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, Cc, H, W, out.shape[1],), "mi355x_im2col3x3_nchw")
     return out
 
 
 def concat2(a_: Tensor, b_: Tensor, out: Tensor) -> Tensor:
     """Channel concat of two row-major 2-D tensors [M, C1] ++ [M, C2] -> out [M, C1+C2]."""
     M = a_.shape[0]
-    check(
-        load().mi355x_concat2(dtype_code(a_.dtype), a_.data_ptr(), a_.stride(0), a_.shape[1], b_.data_ptr(), b_.stride(0), b_.shape[1],
-                              out.data_ptr(), out.stride(0), M, stream_ptr()),
-        "mi355x_concat2",
-    )
+    _launch("mi355x_concat2", (dtype_code(a_.dtype), a_.data_ptr(), a_.stride(0), a_.shape[1], b_.data_ptr(), b_.stride(0), b_.shape[1],
+                              out.data_ptr(), out.stride(0), M,), "mi355x_concat2")
     return out
 
 
 def axpby(a_: Tensor, alpha: float, b_: Tensor, beta: float, out: Tensor) -> Tensor:
     assert a_.is_contiguous() and b_.is_contiguous() and out.is_contiguous() and a_.numel() == b_.numel() == out.numel()
-    check(load().mi355x_axpby(dtype_code(a_.dtype), a_.data_ptr(), alpha, b_.data_ptr(), beta, out.data_ptr(), a_.numel(), stream_ptr()), "mi355x_axpby")
+    _launch("mi355x_axpby", (dtype_code(a_.dtype), a_.data_ptr(), alpha, b_.data_ptr(), beta, out.data_ptr(), a_.numel(),), "mi355x_axpby")
     return out
 
 
 def silu(x: Tensor, out: Tensor) -> Tensor:
     assert x.is_contiguous() and out.is_contiguous()
-    check(load().mi355x_silu(dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), x.numel(), stream_ptr()), "mi355x_silu")
+    _launch("mi355x_silu", (dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), x.numel(),), "mi355x_silu")
     return out
 
 
@@ -465,7 +515,7 @@ def cfg_ddim_step(x: Tensor, unet_out: Tensor, coef: Tensor) -> Tensor:
     """In-place: x <- ddim(x, cfg(unet_out)). unet_out = [uncond; cond] (2*x.numel() elements); coef: f32[5] on device."""
     assert x.is_contiguous() and unet_out.is_contiguous() and unet_out.numel() == 2 * x.numel()
     assert coef.dtype == torch.float32 and coef.numel() >= 5 and coef.is_cuda
-    check(load().mi355x_cfg_ddim_step(dtype_code(x.dtype), x.data_ptr(), unet_out.data_ptr(), coef.data_ptr(), x.numel(), stream_ptr()), "mi355x_cfg_ddim_step")
+    _launch("mi355x_cfg_ddim_step", (dtype_code(x.dtype), x.data_ptr(), unet_out.data_ptr(), coef.data_ptr(), x.numel(),), "mi355x_cfg_ddim_step")
     return x
 
 

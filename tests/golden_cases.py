@@ -1,0 +1,69 @@
+"""Recipes of the golden cases: everything needed to rebuild weights, adapters and inputs from seeds alone.
+
+Shared by oracle/make_golden.py (which runs the real reference on them) and by the tests that check the oracle, the
+host mirror and the HIP path against the stored reference outputs.  Latents are 32x32 (the size the reference's own
+UNet parity test uses, tests/foundationals/latent_diffusion/test_sdxl_unet.py:17-54) so that a case costs seconds.
+"""
+from __future__ import annotations
+
+from typing import Any, Mapping, Sequence
+
+from refiners_amd import synth
+
+CASES: dict[str, dict[str, Any]] = {
+    # BASELINE.json config 2 at reduced latent size: bare SDXL, one CFG pair, DDIM step 10 of 50
+    "sdxl_bare": dict(family="sdxl", weight_seed=0, input_seed=1, images=1, latent_hw=(32, 32), num_steps=50, step=10, condition_scale=5.0,
+                      adapters=[]),
+    # config 3: IP-Adapter + two rank-16 LoRAs (scales 1.0 / 0.8) on all 722 Linears under SDXLCrossAttention
+    "sdxl_lora_ip": dict(family="sdxl", weight_seed=0, input_seed=2, images=1, latent_hw=(32, 32), num_steps=50, step=25, condition_scale=5.0,
+                         adapters=["ip", "lora:l1:1.0", "lora:l2:0.8"]),
+    # config 4's adapter: ControlLora (with its own rank-8 LoRA on the copied encoder) at scale 0.9, non-square latent
+    "sdxl_control": dict(family="sdxl", weight_seed=0, input_seed=3, images=1, latent_hw=(32, 24), num_steps=30, step=29, condition_scale=7.5,
+                         adapters=["control:canny:0.9"]),
+    # Conv2d LoRAs on ResidualBlock / Downsample / Upsample convolutions (reference tests/e2e/test_diffusion.py:1655-1663)
+    "sdxl_conv_lora": dict(family="sdxl", weight_seed=0, input_seed=4, images=1, latent_hw=(16, 16), num_steps=50, step=0, condition_scale=5.0,
+                           adapters=["convlora:c1:0.7"]),
+    # config 1 at reduced latent size: SD1.5, single forward, no CFG
+    "sd1_bare": dict(family="sd1", weight_seed=0, input_seed=5, latent_hw=(32, 32), timestep=500),
+}
+
+
+def conv_lora_targets(shapes: Mapping[str, Sequence[int]]) -> list[str]:
+    out = []
+    for k, s in shapes.items():
+        if k.endswith(".weight") and len(s) == 4 and any(t in k for t in ("ResidualBlock", "Downsample", "Upsample")):
+            if "MiddleBlock" in k or "Chain_4" in k or "Chain_3.Upsample" in k or "UpBlocks.Chain_9" in k:
+                out.append(k[: -len(".weight")])
+    return out
+
+
+def control_lora_targets(shapes: Mapping[str, Sequence[int]]) -> list[str]:
+    """A handful of encoder-half Linears and convs (real control-lora files adapt all of them at rank 128)."""
+    picks = []
+    for k in shapes:
+        if not k.endswith(".weight") or not (k.startswith("DownBlocks") or k.startswith("MiddleBlock")):
+            continue
+        if "Chain_5.SDXLCrossAttention.Chain_2.CrossAttentionBlock_1" in k and "Linear" in k.split(".")[-2]:
+            picks.append(k[: -len(".weight")])
+        elif "Chain_2.ResidualBlock.Chain.Conv2d" in k or "MiddleBlock.ResidualBlock_1.Chain.RangeAdapter2d.Conv2d" in k:
+            picks.append(k[: -len(".weight")])
+    return picks
+
+
+def build_specs(cfg: Mapping[str, Any], shapes: Mapping[str, Sequence[int]]) -> dict[str, Any]:
+    """Adapter specs (refiners_amd.synth formats) of a case: kwargs for synth.apply_adapters and for the oracle."""
+    seed = cfg["weight_seed"] + 100
+    batch = cfg["images"] * 2
+    loras, ip, control = [], None, []
+    for item in cfg["adapters"]:
+        kind, *rest = item.split(":")
+        if kind == "lora":
+            loras.append(synth.lora_spec(shapes, rest[0], float(rest[1]), rank=16, seed=seed))
+        elif kind == "convlora":
+            loras.append(synth.lora_spec(shapes, rest[0], float(rest[1]), rank=8, seed=seed, targets=conv_lora_targets(shapes)))
+        elif kind == "ip":
+            ip = synth.ip_spec(shapes, scale=0.6, batch=batch, seed=seed)
+        elif kind == "control":
+            own = synth.lora_spec(shapes, f"ctl_{rest[0]}", 1.0, rank=8, seed=seed + 1, targets=control_lora_targets(shapes))
+            control.append(synth.control_spec(rest[0], float(rest[1]), batch, cfg["latent_hw"], seed=seed, loras=[own]))
+    return {"loras": loras, "ip": ip, "control": control}
