@@ -194,7 +194,10 @@ class Lowering:
         self.es = 4 if dtype == torch.float32 else 2
         self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
         self.cache = cache or PackCache()
-        self.pool = Pool(device, dtype)
+        # two arenas: prologue results must survive across steps, so they never share storage with step temporaries
+        self.step_pool = Pool(device, dtype)
+        self.prologue_pool = Pool(device, dtype)
+        self.pool = self.step_pool
         self.prologue: list = []
         self.step: list = []
         self._target = self.step
@@ -206,14 +209,15 @@ class Lowering:
             self.low, self.ops = low, ops
 
         def __enter__(self) -> None:
-            self.saved = self.low._target
+            self.saved = (self.low._target, self.low.pool)
             self.low._target = self.ops
+            self.low.pool = self.low.prologue_pool if self.ops is self.low.prologue else self.low.step_pool
             self.rec = native.recording(self.ops)
             self.rec.__enter__()
 
         def __exit__(self, *exc: object) -> None:
             self.rec.__exit__(*exc)
-            self.low._target = self.saved
+            self.low._target, self.low.pool = self.saved
 
     def in_prologue(self) -> "Lowering._Section":
         return Lowering._Section(self, self.prologue)
@@ -511,10 +515,11 @@ class Lowering:
             q = self.linear(h, qs)
             k = self.linear(h, ks)
         if native_path:
-            vt = self.pool.get(C, M)
+            vt_base = self.pool.get(C + 1, M)  # one spare row: the kernel reads V^T rows up to the next multiple of 64 keys
+            vt = vt_base[:C]
             self.linear_T(h, vs, vt)
             o = self.sdpa(q, B, heads, [(k, vt, M // B, 1.0)])
-            self.pool.put(vt)
+            self.pool.put(vt_base)
         else:
             v = self.linear(h, vs)
             o = self.sdpa(q, B, heads, [(k, v, M // B, 1.0)], v_plain=[v])
@@ -685,3 +690,282 @@ class UNetContext:
         self.low.pool.pin(out)
         self.low.linear(src, lin, out=out)
         return out
+
+
+# ------------------------------------------------------------------------------------------------ whole-UNet lowering
+def sinusoid_rows(x: Tensor, dim: int) -> Tensor:
+    """range_adapter.py:11-22 on a 1-D float tensor: [cos | sin] of x * 10000^(-i/half), float32."""
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32, device=x.device) / half
+    angle = x.float().unsqueeze(1) * torch.exp(exponent).unsqueeze(0)
+    return torch.cat([torch.cos(angle), torch.sin(angle)], dim=-1)
+
+
+@dataclass
+class UNetIO:
+    """Static input / output buffers of a lowered UNet (filled by CompiledUNet before a replay)."""
+
+    x: Tensor  # [B, Cin, H, W] compute dtype, NCHW (the reference's input layout)
+    timestep: Tensor  # [B] float32
+    out: Tensor  # [B, Cout, H, W]
+    pooled: Optional[Tensor] = None  # [B, 1280]
+    time_ids: Optional[Tensor] = None  # [B, 6] float32
+    tokens: dict[tuple[str, str], tuple[Tensor, int]] = field(default_factory=dict)  # (context, key) -> ([B*Lp, width], L)
+    conditions: dict[str, Tensor] = field(default_factory=dict)  # control context name -> [B, 3, 8H, 8W]
+
+
+class UNetLowering(Lowering):
+    """Lowers SDXLUNet / SD1UNet trees (reference xl/unet.py:258-351, sd1/unet.py:165-249), with ControlLoras at
+    index 0 (xl/control_lora.py:144-248), into `prologue` + `step`."""
+
+    def lower(self, unet: Any, io: UNetIO) -> None:
+        B, _, H, W = io.x.shape
+        self.io = io
+        ctx = UNetContext(self, B)
+        ctx.text = dict(io.tokens)
+        n_slots = len(unet.init_context()["unet"]["residuals"])
+        ctx.residuals = [None] * n_slots
+        cur: Any = None
+        with self.in_step():
+            for child in kids(unet):
+                if isa(child, "ControlLora"):
+                    self.control_lora(child, ctx, H, W)
+                elif isa(child, "TimestepEncoder"):
+                    self.timestep_encoder(child, ctx)
+                elif cname(child) in ("DownBlocks", "UpBlocks"):
+                    for stage in kids(child):
+                        _expect(isa(stage, "Chain"), "UNet stages must be Chains")
+                        for piece in kids(stage):
+                            cur = self.piece(piece, cur, ctx, H, W)
+                elif cname(child) == "MiddleBlock":
+                    for piece in kids(child):
+                        cur = self.piece(piece, cur, ctx, H, W)
+                elif isa(child, "Residual") and len(kids(child)) == 1 and self._reads_residuals(kids(child)[0]):
+                    cur = self.add_last_residual(cur, ctx)  # xl/unet.py:282
+                elif isa(child, "Sum") and len(kids(child)) == 2 and self._reads_residuals(kids(child)[0]) and cname(kids(child)[1]) == "MiddleBlock":
+                    for piece in kids(kids(child)[1]):  # sd1/unet.py:193-196: residuals[-1] + MiddleBlock(x)
+                        cur = self.piece(piece, cur, ctx, H, W)
+                    cur = self.add_last_residual(cur, ctx)
+                elif isa(child, "Chain") and [cname(k) for k in kids(child)] == ["GroupNorm", "SiLU", "Conv2d"]:
+                    cur = self.output_block(child, cur)
+                else:
+                    raise Unsupported(f"unexpected top-level UNet child {cname(child)}")
+            _expect(isinstance(cur, Tensor), "UNet did not end with an output block")
+
+    @staticmethod
+    def _reads_residuals(m: Any) -> bool:
+        return isa(m, "UseContext") and m.context == "unet" and m.key == "residuals"
+
+    # -- timestep ----------------------------------------------------------------------------------------------
+    def _range_encoder(self, enc: Any, res: Optional[Tensor]) -> Tensor:
+        ch = kids(enc)
+        _expect(len(ch) == 5 and isa(ch[0], "Lambda") and isa(ch[1], "Converter") and isa(ch[3], "SiLU"), "unexpected RangeEncoder layout")
+        l1, l2 = self.linear_spec(ch[2]), self.linear_spec(ch[4])
+        B = self.io.timestep.shape[0]
+        sin = torch.empty(B, enc.sinusoidal_embedding_dim, device=self.device, dtype=self.dtype)
+        ts = self.io.timestep
+        dim = enc.sinusoidal_embedding_dim
+        self.python(lambda: sin.copy_(sinusoid_rows(ts, dim)), "sinusoid(timestep)")
+        e1 = self.linear(sin, l1)
+        e1s = self.pool.get(B, l1.N)
+        native.silu(e1, e1s)
+        te = self.linear(e1s, l2, res=res)
+        self.pool.put(e1)
+        self.pool.put(e1s)
+        return te
+
+    def timestep_encoder(self, node: Any, ctx: UNetContext) -> None:
+        ch = kids(node)
+        B = ctx.B
+        if len(ch) == 2 and isa(ch[0], "Sum"):  # SDXL: Sum(Chain(UseContext timestep, RangeEncoder), TextTimeEmbedding)
+            sc = kids(ch[0])
+            _expect(len(sc) == 2 and isa(sc[1], "TextTimeEmbedding") and isa(kids(sc[0])[1], "RangeEncoder"), "unexpected SDXL TimestepEncoder layout")
+            tt = kids(sc[1])
+            _expect(len(tt) == 5 and isa(tt[0], "Concatenate") and isa(tt[1], "Converter") and isa(tt[3], "SiLU"), "unexpected TextTimeEmbedding layout")
+            l1, l2 = self.linear_spec(tt[2]), self.linear_spec(tt[4])
+            _expect(self.io.pooled is not None and self.io.time_ids is not None, "SDXL needs pooled_text_embedding and time_ids")
+            with self.in_prologue():  # constant over the sampling loop
+                cat = torch.empty(B, l1.K, device=self.device, dtype=self.dtype)
+                pooled, ids, dim = self.io.pooled, self.io.time_ids, sc[1].time_ids_embedding_dim
+                _expect(pooled.shape[1] + ids.shape[1] * dim == l1.K, "TextTimeEmbedding width mismatch")
+
+                def fill() -> None:
+                    cat[:, : pooled.shape[1]] = pooled
+                    cat[:, pooled.shape[1] :] = sinusoid_rows(ids.reshape(-1), dim).reshape(B, -1)
+
+                self.python(fill, "text_time_concat")
+                t1 = self.linear(cat, l1)
+                t1s = self.pool.get(B, l1.N)
+                native.silu(t1, t1s)
+                tte = self.pool.get(B, l2.N)
+                self.pool.pin(tte)
+                self.linear(t1s, l2, out=tte)
+                self.pool.put(t1)
+                self.pool.put(t1s)
+            temb = self._range_encoder(kids(sc[0])[1], res=tte)
+            writer = ch[1]
+        else:  # SD1.5: Passthrough(UseContext timestep, RangeEncoder, SetContext)
+            _expect(len(ch) == 3 and isa(ch[1], "RangeEncoder"), "unexpected TimestepEncoder layout")
+            temb = self._range_encoder(ch[1], res=None)
+            writer = ch[2]
+        _expect(isa(writer, "SetContext") and writer.context == "range_adapter", "TimestepEncoder must write context range_adapter")
+        ts = self.pool.get(B, temb.shape[1])
+        self.pool.pin(ts)
+        native.silu(temb, ts)
+        self.pool.put(temb)
+        ctx.temb_silu[writer.key] = ts
+
+    # -- stage pieces ------------------------------------------------------------------------------------------
+    def stem(self, conv: Any) -> Act:
+        """First convolution, straight from the NCHW latents (im2col of the tiny-channel image, then one GEMM)."""
+        _expect(isa(conv, "Conv2d") and conv.kernel_size == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1), "unsupported stem conv")
+        B, cin, H, W = self.io.x.shape
+        _expect(conv.in_channels == cin, "stem conv channel mismatch")
+        kp = (9 * cin + self.kblk - 1) // self.kblk * self.kblk
+
+        def pack() -> Tensor:
+            wp = torch.zeros(conv.out_channels, kp, device=self.device, dtype=self.dtype)
+            wp[:, : 9 * cin] = native.pack_conv_weight(self.cvt(conv.weight))
+            return wp
+
+        wp = self.cache.get(("stem", kp) + PackCache.ident(conv.weight), pack)
+        cols = self.pool.get(B * H * W, kp)
+        native.im2col3x3_nchw(self.io.x, cols)
+        out = self.pool.get(B * H * W, conv.out_channels)
+        native.gemm([(cols, wp)], out, bias=self._w(conv.bias))
+        self.pool.put(cols)
+        return Act(out, B, H, W)
+
+    def _release(self, a: Optional[Act]) -> None:
+        if a is not None:
+            self.pool.put(a.t)
+
+    def piece(self, m: Any, cur: Optional[Act], ctx: UNetContext, H: int, W: int) -> Optional[Act]:
+        if cur is None:
+            return self.stem(m)
+        if isa(m, "ResidualBlock"):
+            out = self.residual_block(m, cur, ctx)
+        elif isa(m, "CrossAttentionBlock2d"):
+            out = self.cross_attention_2d(m, cur, ctx)
+        elif isa(m, "Downsample"):
+            ch = kids(m)
+            conv = ch[-1]
+            _expect(all(isa(c, "SetContext") for c in ch[:-1]), "Downsample with explicit zero padding (padding=0) is not lowered")
+            if any(isa(c, "SetContext") for c in ch[:-1]):
+                ctx.shapes.append((cur.H, cur.W))
+            spec = self.conv_spec(conv)
+            _expect(spec.stride == 2 and spec.ksize == 3, "unexpected Downsample convolution")
+            out = self.conv(cur, spec)
+        elif isa(m, "Upsample"):
+            ch = kids(m)
+            _expect(len(ch) == 3 and isa(ch[0], "Parallel") and isa(ch[1], "Interpolate") and ch[1].mode == "nearest", "unexpected Upsample layout")
+            src = kids(ch[0])[1]
+            th, tw = ctx.shapes.pop() if isa(src, "UseContext") else (cur.H * m.upsample_factor, cur.W * m.upsample_factor)
+            _expect((th, tw) == (2 * cur.H, 2 * cur.W), "only exact 2x nearest upsampling is lowered")
+            out = self.conv(cur, self.conv_spec(ch[2]), ups=2)
+        elif isa(m, "ResidualAccumulator"):
+            self.accumulate(ctx, m.n, cur)
+            return cur
+        elif isa(m, "ResidualConcatenator"):
+            skip = self.slot(ctx, m.n)
+            _expect(skip is not None and (skip.B, skip.H, skip.W) == (cur.B, cur.H, cur.W), "skip tensor missing or of another size")
+            cat = self.pool.get(cur.M, cur.C + skip.C)
+            native.concat2(cur.t, skip.t, cat)
+            out = Act(cat, cur.B, cur.H, cur.W)
+        elif isa(m, "ZeroConvolution"):
+            self.zero_convolution(m, cur, ctx)
+            return cur
+        elif isa(m, "Residual") and len(kids(m)) == 2 and isa(kids(m)[0], "UseContext") and isa(kids(m)[1], "ConditionEncoder"):
+            out = self.add_condition(m, cur)
+        else:
+            out = self.torch_node(m, cur)
+        self._release(cur)
+        return out
+
+    def slot(self, ctx: UNetContext, n: int) -> Optional[Act]:
+        return ctx.residuals[n]
+
+    def accumulate(self, ctx: UNetContext, n: int, a: Act) -> None:
+        """residuals[n] <- a + residuals[n]   (unet.py:54-66); aliasing `a` when the slot still holds its initial 0.0."""
+        prev = ctx.residuals[n]
+        if prev is None:
+            self.pool.pin(a.t)
+            ctx.residuals[n] = a
+            return
+        _expect((prev.B, prev.H, prev.W, prev.C) == (a.B, a.H, a.W, a.C), "residual slot shape mismatch")
+        s = self.pool.get(a.M, a.C)
+        self.pool.pin(s)
+        native.axpby(a.t, 1.0, prev.t, 1.0, s)
+        ctx.residuals[n] = Act(s, a.B, a.H, a.W)
+
+    def add_last_residual(self, cur: Act, ctx: UNetContext) -> Act:
+        last = ctx.residuals[-1]
+        if last is None:  # 0.0 in the reference: x + 0.0
+            return cur
+        out = self.pool.get(cur.M, cur.C)
+        native.axpby(cur.t, 1.0, last.t, 1.0, out)
+        self._release(cur)
+        return Act(out, cur.B, cur.H, cur.W)
+
+    def output_block(self, node: Any, cur: Act) -> Tensor:
+        gn, _, conv = kids(node)
+        g = self.groupnorm(cur, gn, silu=True)
+        self._release(cur)
+        y = self.conv(g, self.conv_spec(conv))
+        self.pool.put(g.t)
+        native.nhwc_to_nchw(y.tokens(), self.io.out, y.C)
+        self.pool.put(y.t)
+        return self.io.out
+
+    # -- ControlLora -------------------------------------------------------------------------------------------
+    def zero_convolution(self, m: Any, cur: Act, ctx: UNetContext) -> None:
+        """residuals[n] += scale * conv1x1(x)   (control_lora.py:90-141): the scale is folded into the packed weights."""
+        ch = kids(m)
+        _expect(len(ch) == 3 and isa(ch[0], "Conv2d") and isa(ch[1], "Multiply") and isa(ch[2], "ResidualAccumulator") and ch[1].bias == 0.0, "unexpected ZeroConvolution layout")
+        conv, scale = ch[0], float(ch[1].scale)
+        _expect(conv.kernel_size == (1, 1), "ZeroConvolution must be 1x1")
+        w = self.cache.get(("zc_w", scale) + PackCache.ident(conv.weight), lambda: (conv.weight.detach().to(self.device, torch.float32).reshape(conv.out_channels, conv.in_channels) * scale).to(self.dtype).contiguous())
+        b = self.cache.get(("zc_b", scale) + PackCache.ident(conv.bias), lambda: (conv.bias.detach().to(self.device, torch.float32) * scale).to(self.dtype).contiguous())
+        prev = ctx.residuals[ch[2].n]
+        z = self.pool.get(cur.M, conv.out_channels)
+        self.pool.pin(z)
+        native.gemm([(cur.t, w)], z, bias=b, res=None if prev is None else prev.t)
+        ctx.residuals[ch[2].n] = Act(z, cur.B, cur.H, cur.W)
+
+    def add_condition(self, m: Any, cur: Act) -> Act:
+        """x + ConditionEncoder(condition)   (control_lora.py:190-202).  The encoder sees a constant image, so it runs in
+        the prologue; its 3/16/32/96-channel convolutions are below the 128-byte granularity of the implicit-GEMM kernel
+        and go through torch there."""
+        reader, enc = kids(m)
+        cond = self.io.conditions.get(reader.context)
+        _expect(cond is not None, f"no condition image registered for {reader.context}")
+        e_nchw = torch.empty(cur.B, cur.C, cur.H, cur.W, device=self.device, dtype=self.dtype)
+        with self.in_prologue():
+            e = self.pool.get(cur.M, cur.C)  # prologue arena: must survive across steps
+            self.pool.pin(e)
+
+            def run() -> None:
+                y = enc(cond)
+                assert tuple(y.shape) == tuple(e_nchw.shape), f"ConditionEncoder produced {tuple(y.shape)}"
+                e_nchw.copy_(y)
+
+            self.python(run, "torch:ConditionEncoder")
+            native.nchw_to_nhwc(e_nchw, Act(e, cur.B, cur.H, cur.W).tokens())
+        self.stats["fallback_nodes"].append("ConditionEncoder(prologue)")
+        out = self.pool.get(cur.M, cur.C)
+        native.axpby(cur.t, 1.0, e, 1.0, out)
+        return Act(out, cur.B, cur.H, cur.W)
+
+    def control_lora(self, node: Any, ctx: UNetContext, H: int, W: int) -> None:
+        """Passthrough(TimestepEncoder', DownBlocks', MiddleBlock'): fills ctx.residuals, returns nothing."""
+        ch = kids(node)
+        _expect(len(ch) == 3 and isa(ch[0], "TimestepEncoder") and cname(ch[1]) == "DownBlocks" and cname(ch[2]) == "MiddleBlock", "unexpected ControlLora layout")
+        sub = UNetContext(self, ctx.B, text=ctx.text, temb_silu=ctx.temb_silu, residuals=ctx.residuals, shapes=[])
+        self.timestep_encoder(ch[0], sub)
+        cur: Optional[Act] = None
+        for stage in kids(ch[1]):
+            for piece in kids(stage):
+                cur = self.piece(piece, cur, sub, H, W)
+        for piece in kids(ch[2]):
+            cur = self.piece(piece, cur, sub, H, W)
+        self._release(cur)

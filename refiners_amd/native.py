@@ -283,7 +283,7 @@ _zeros: dict[int, Tensor] = {}
 
 
 def zero_page(device: torch.device) -> Tensor:
-    idx = device.index if device.index is not None else torch.cuda.current_device()
+    idx = (device.index if device.index is not None else torch.cuda.current_device()) if device.type == "cuda" else -1
     z = _zeros.get(idx)
     if z is None:
         z = torch.zeros(256, dtype=torch.uint8, device=device)
@@ -455,8 +455,11 @@ def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: flo
     B, HW, Cc = x.shape
     assert x.stride(2) == 1 and out.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and out.stride(0) == HW * out.stride(1)
     need = load().mi355x_groupnorm_ws_floats(B, HW, Cc)
-    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-    key = (dev, torch.cuda.current_stream().cuda_stream)
+    if x.device.type == "cuda":
+        dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        key = (dev, torch.cuda.current_stream().cuda_stream)
+    else:  # dry-run lowering on the meta / cpu device (tests): nothing is launched
+        key = (-1, 0)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)
@@ -465,7 +468,7 @@ def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: flo
     a.B, a.HW, a.C, a.G = B, HW, Cc, groups
     a.x, a.ldx, a.gamma, a.beta, a.eps, a.silu = x.data_ptr(), x.stride(1), gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
     a.out, a.ldo, a.ws = out.data_ptr(), out.stride(1), ws.data_ptr()
-    _launch("mi355x_groupnorm", (C.byref(a),), "mi355x_groupnorm")
+    _launch("mi355x_groupnorm", (C.byref(a),), "mi355x_groupnorm", keep=(ws,))
     return out
 
 

@@ -1,0 +1,167 @@
+"""pytest -m gpu: the MI355X engine (lowered Chain tree -> HIP kernels through the C ABI) against
+ (a) the golden outputs of the real reference (tests/golden/, float32 CPU Chain forward of finegrain-ai/refiners) and
+ (b) the CPU oracle at sizes the goldens do not cover.
+Tolerances: float32 mode <= 1e-3 relative (BASELINE.json north_star); bfloat16 mode is compared with the same float32
+reference and must stay inside the reference's own cross-implementation bar of 1e-2 norm-wise
+(reference tests/foundationals/latent_diffusion/test_sdxl_unet.py:48)."""
+import pytest
+import torch
+
+import refiners_amd
+from refiners_amd import native
+from refiners_amd.engine.compiled import CompiledSDXL, CompiledUNet
+from refiners_amd.latent_diffusion.sampling import DDIM
+from refiners_amd.latent_diffusion.sdxl import SDXLUNet
+from tests import support as S
+
+pytestmark = pytest.mark.gpu
+F32_TOL = 1e-3
+BF16_TOL = 1e-2
+SDXL_CASES = [c for c, cfg in S.CASES.items() if cfg["family"] == "sdxl"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_native(gpu_device):
+    native.load()
+
+
+def build(case: str, dtype: torch.dtype, dev="cuda"):
+    cfg = S.CASES[case]
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", cfg["weight_seed"]), device=dev, dtype=dtype)
+    specs = S.build_specs(cfg, S.key_shapes("sdxl"))
+    handles = S.synth.apply_adapters(unet, refiners_amd.namespace(), device=dev, dtype=dtype, **specs)
+    inp = {k: v.to(dev) for k, v in S.synth.sdxl_inputs(cfg["images"], cfg["latent_hw"], cfg["input_seed"]).items()}
+    return cfg, unet, specs, handles, inp
+
+
+def set_context(unet, cfg, inp, dtype):
+    ts = DDIM(cfg["num_steps"]).timesteps[cfg["step"]].unsqueeze(0).to("cuda")
+    unet.set_timestep(ts)
+    unet.set_clip_text_embedding(inp["text"].to(dtype))
+    unet.set_pooled_text_embedding(inp["pooled"].to(dtype))
+    unet.set_time_ids(inp["time_ids"])
+
+
+@pytest.mark.parametrize("case", SDXL_CASES)
+def test_unet_float32_matches_reference(case):
+    cfg, unet, specs, handles, inp = build(case, torch.float32)
+    fast = CompiledUNet(unet)
+    set_context(unet, cfg, inp, torch.float32)
+    y = fast(torch.cat((inp["x"], inp["x"])))
+    gold = S.golden(case)["unet_out"]
+    l2, mx = S.rel_err(y, gold)
+    print(f"{case} f32: l2 {l2:.2e} max {mx:.2e} ops {fast.stats['step_ops']} fallbacks {fast.stats['fallback_nodes']}")
+    assert l2 < F32_TOL and mx < F32_TOL, (case, l2, mx)
+    # the unfused torch path of the same tree on the GPU agrees too (drop-in: same call, same context protocol)
+    set_context(unet, cfg, inp, torch.float32)
+    y_ref = unet(torch.cat((inp["x"], inp["x"])))
+    l2, mx = S.rel_err(y, y_ref)
+    assert l2 < F32_TOL and mx < F32_TOL, (case, "vs unfused", l2, mx)
+    # bit-reproducible, graph replay included (reference tests/foundationals/latent_diffusion/test_sd15_unet.py:21-37)
+    set_context(unet, cfg, inp, torch.float32)
+    y2 = fast(torch.cat((inp["x"], inp["x"])))
+    set_context(unet, cfg, inp, torch.float32)
+    y3 = fast(torch.cat((inp["x"], inp["x"])))
+    assert torch.equal(y, y2) and torch.equal(y, y3)
+
+
+@pytest.mark.parametrize("case", SDXL_CASES)
+def test_unet_bfloat16_close_to_float32_reference(case):
+    cfg, unet, specs, handles, inp = build(case, torch.bfloat16)
+    fast = CompiledUNet(unet)
+    set_context(unet, cfg, inp, torch.bfloat16)
+    y = fast(torch.cat((inp["x"], inp["x"])).to(torch.bfloat16))
+    gold = S.golden(case)["unet_out"]
+    l2, mx = S.rel_err(y.float(), gold)
+    set_context(unet, cfg, inp, torch.bfloat16)
+    y_t = unet(torch.cat((inp["x"], inp["x"])).to(torch.bfloat16))  # stock torch bf16 kernels on the same tree
+    l2_t, _ = S.rel_err(y_t.float(), gold)
+    print(f"{case} bf16: engine l2 {l2:.2e} max {mx:.2e}; torch-bf16 unfused l2 {l2_t:.2e}")
+    assert l2 < BF16_TOL, (case, l2, mx)
+    assert l2 < 1.5 * l2_t + 1e-3, "the fused path must not be less accurate than the unfused bf16 path"
+
+
+@pytest.mark.parametrize("case", ["sdxl_bare", "sdxl_lora_ip"])
+def test_cfg_ddim_step_matches_reference(case):
+    cfg, unet, specs, handles, inp = build(case, torch.float32)
+    sd = CompiledSDXL(unet, num_inference_steps=cfg["num_steps"], condition_scale=cfg["condition_scale"])
+    kw = {}
+    if specs["ip"] is not None:
+        kw["clip_image_embedding"] = specs["ip"]["tokens"].to("cuda")
+    sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], **kw)
+    x1 = sd.step(cfg["step"]).clone()
+    l2, mx = S.rel_err(x1, S.golden(case)["x_next"])
+    assert l2 < F32_TOL and mx < F32_TOL, (case, l2, mx)
+    # graph replay == direct replay, bit for bit
+    sd2 = CompiledSDXL(unet, num_inference_steps=cfg["num_steps"], condition_scale=cfg["condition_scale"], use_graph=False)
+    sd2.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], **kw)
+    assert torch.equal(x1, sd2.step(cfg["step"]))
+    sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], **kw)
+    assert torch.equal(x1, sd.step(cfg["step"]))  # second call goes through the captured graph
+
+
+def test_adapters_stay_live_after_compilation():
+    """Scales changed and adapters ejected AFTER the first fused call must take effect (SURVEY.md section 7 'hard parts')."""
+    from oracle import unet_oracle as O
+
+    cfg, unet, specs, handles, inp = build("sdxl_lora_ip", torch.float32)
+    fast = CompiledUNet(unet)
+    xx = torch.cat((inp["x"], inp["x"]))
+    set_context(unet, cfg, inp, torch.float32)
+    y0 = fast(xx)
+    for a in handles["loras"]:
+        a.loras["l2"].scale = 0.25
+    handles["ip"].scale = 0.1
+    set_context(unet, cfg, inp, torch.float32)
+    y1 = fast(xx)
+    assert not torch.equal(y0, y1)
+    specs["loras"][1]["scale"] = 0.25
+    specs["ip"]["scale"] = 0.1
+    ts, _ = O.ddim_tables(cfg["num_steps"])
+    cpu = {k: v.cpu() for k, v in inp.items()}
+    ref = O.sdxl_unet(S.weights("sdxl", 0), torch.cat((cpu["x"], cpu["x"])), ts[cfg["step"]].unsqueeze(0), cpu["text"], cpu["pooled"], cpu["time_ids"],
+                      **S.oracle_adapters(specs))
+    l2, mx = S.rel_err(y1, ref)
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    for a in handles["loras"]:
+        a.eject()
+    handles["ip"].eject()
+    set_context(unet, cfg, inp, torch.float32)
+    y2 = fast(xx)
+    ref = O.sdxl_unet(S.weights("sdxl", 0), torch.cat((cpu["x"], cpu["x"])), ts[cfg["step"]].unsqueeze(0), cpu["text"], cpu["pooled"], cpu["time_ids"])
+    l2, mx = S.rel_err(y2, ref)
+    assert l2 < F32_TOL and mx < F32_TOL, ("after eject", l2, mx)
+
+
+def test_sd1_float32_matches_reference():
+    from refiners_amd.latent_diffusion.sd1 import SD1UNet
+
+    cfg = S.CASES["sd1_bare"]
+    unet = SD1UNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sd1", cfg["weight_seed"]), device="cuda", dtype=torch.float32)
+    x = torch.randn((1, 4, *cfg["latent_hw"]), generator=S.synth._gen("in.x", cfg["input_seed"])).cuda()
+    text = torch.randn((1, 77, 768), generator=S.synth._gen("in.text", cfg["input_seed"])).cuda()
+    fast = CompiledUNet(unet)
+    unet.set_clip_text_embedding(text)
+    unet.set_timestep(torch.tensor([cfg["timestep"]], device="cuda"))
+    y = fast(x)
+    l2, mx = S.rel_err(y, S.golden("sd1_bare")["unet_out"])
+    print(f"sd1 f32: l2 {l2:.2e} max {mx:.2e} fallbacks {len(fast.stats['fallback_nodes'])}")
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+
+
+def test_full_size_step_matches_oracle():
+    """BASELINE.json config 2 geometry (1024x1024 -> 128x128 latents, CFG pair), float32, against the CPU oracle."""
+    from oracle import unet_oracle as O
+
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", 0), device="cuda", dtype=torch.float32)
+    inp = S.synth.sdxl_inputs(1, (128, 128), seed=7)
+    sd = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0)
+    sd.set_inputs(inp["x"].cuda(), clip_text_embedding=inp["text"].cuda(), pooled_text_embedding=inp["pooled"].cuda(), time_ids=inp["time_ids"].cuda())
+    x1 = sd.step(0).clone()
+    ref = O.sdxl_cfg_step(S.weights("sdxl", 0), inp["x"], 0, 50, inp["text"], inp["pooled"], inp["time_ids"], condition_scale=5.0)
+    l2, mx = S.rel_err(x1, ref)
+    print(f"full-size f32 step: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
