@@ -49,7 +49,11 @@ class CompiledUNet:
 
     # -- context plumbing ----------------------------------------------------------------------------------
     def _contexts(self) -> dict[str, dict[str, Any]]:
-        return self.unet.provider.contexts
+        # Chain.set_context REPLACES the top-level dict but MERGES into every descendant's (context.py:16-46,
+        # chain.py:131-156), so after set_timestep / set_time_ids / ... only a child Chain sees
+        # all of them -- read where the UseContext nodes read, not at unet.provider.
+        child = next((m for m in kids(self.unet) if isa(m, "Chain")), None)
+        return (child if child is not None else self.unet).provider.contexts
 
     def _gather(self) -> dict[str, Any]:
         c = self._contexts()

@@ -1,0 +1,115 @@
+"""Multi-GPU layer of the hot path: one process per GPU, independent prompts per rank, no per-step collective.
+
+The reference has no multi-device support at all; the sampling loop shards naturally because
+every image is an independent 50-step trajectory (batch invariance is one of the reference's own tests,
+tests/e2e/test_diffusion.py:1539-1597).  So the only collectives are
+  * ONE broadcast of UNet + adapter weights from rank 0 at start-up (RCCL over xGMI; flattened into a few large
+    buckets so that each launch moves hundreds of MB and RCCL can keep all links of the ring busy), and
+  * an optional gather of the final latents (128 KiB per image).
+Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU (tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Iterable, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's environment; initialises the default process group if needed."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int = 512 << 20) -> int:
+    """In-place broadcast of many tensors through few large flat buckets (same dtype and device per bucket).
+    Returns the number of collective launches."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    groups: dict[tuple[torch.dtype, torch.device], list[Tensor]] = {}
+    for t in tensors:
+        groups.setdefault((t.dtype, t.device), []).append(t)
+    launches = 0
+    for (dtype, device), items in groups.items():
+        bucket: list[Tensor] = []
+        size = 0
+
+        def flush() -> None:
+            nonlocal bucket, size, launches
+            if not bucket:
+                return
+            flat = torch.cat([b.detach().reshape(-1) for b in bucket])
+            dist.broadcast(flat, src=src)
+            launches += 1
+            off = 0
+            for b in bucket:
+                n = b.numel()
+                b.detach().copy_(flat[off : off + n].view_as(b))
+                off += n
+            bucket, size = [], 0
+
+        for t in items:
+            nbytes = t.numel() * t.element_size()
+            if size and size + nbytes > bucket_bytes:
+                flush()
+            bucket.append(t)
+            size += nbytes
+        flush()
+    return launches
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 512 << 20) -> int:
+    """Broadcast every parameter and buffer of a (possibly adapted) Chain tree from `src`."""
+    seen: dict[int, Tensor] = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        seen.setdefault(id(t), t)
+    return broadcast_tensors(seen.values(), src=src, bucket_bytes=bucket_bytes)
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous slice of `n_items` prompts for `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def shard(items: Sequence[Any], rank: int, world: int) -> list[Any]:
+    return [items[i] for i in shard_range(len(items), rank, world)]
+
+
+def gather_latents(x: Tensor, dst: int = 0) -> Tensor | None:
+    """Concatenate every rank's (n_i, 4, H, W) latents on `dst` (ranks may hold different n_i)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    world = dist.get_world_size()
+    counts = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+    most = int(max(int(c) for c in counts))
+    padded = torch.zeros((most,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    padded[: x.shape[0]] = x
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    if dist.get_rank() != dst:
+        return None
+    return torch.cat([p[: int(c)] for p, c in zip(parts, counts)])
+
+
+def max_over_ranks(value: float, device: torch.device | str = "cpu") -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)

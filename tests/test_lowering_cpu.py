@@ -1,0 +1,111 @@
+"""CPU checks of the host side of the engine: the C-ABI library loads and exports what the header declares, the
+lowering matches every golden-case tree (dry run on the meta device: argument structs are built, nothing is launched),
+and the drop-in reads its inputs where refiners' context store really keeps them."""
+import re
+from collections import Counter
+from pathlib import Path
+
+import pytest
+import torch
+
+import refiners_amd
+from refiners_amd import native, synth
+from refiners_amd.engine.compiled import CompiledUNet
+from refiners_amd.engine.lowering import UNetIO, UNetLowering
+from refiners_amd.fluxion.tree import tree_epoch
+from refiners_amd.latent_diffusion.sd1 import SD1UNet
+from refiners_amd.latent_diffusion.sdxl import SDXLUNet
+from tests import support as S
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    from refiners_amd.build_native import build_native
+
+    build_native()
+
+
+def test_library_exports_every_symbol_of_the_header():
+    header = (ROOT / "include" / "mi355x_refiners.h").read_text()
+    declared = set(re.findall(r"\b(mi355x_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
+    lib = native.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mi355x_abi_version() == 1
+
+
+def _dry(unet, B, H, W, dtype, tokens, pooled=True, conditions=()):
+    dev = torch.device("meta")
+    io = UNetIO(x=torch.empty(B, 4, H, W, device=dev, dtype=dtype), timestep=torch.empty(B, device=dev), out=torch.empty(B, 4, H, W, device=dev, dtype=dtype))
+    if pooled:
+        io.pooled = torch.empty(B, 1280, device=dev, dtype=dtype)
+        io.time_ids = torch.empty(B, 6, device=dev)
+    for ck, (L, width) in tokens.items():
+        io.tokens[ck] = (torch.zeros(B * ((L + 63) // 64 * 64), width, device=dev, dtype=dtype), L)
+    for name in conditions:
+        io.conditions[name] = torch.empty(B, 3, 8 * H, 8 * W, device=dev, dtype=dtype)
+    low = UNetLowering(dev, dtype)
+    low.lower(unet, io)
+    return low
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [c for c, cfg in S.CASES.items() if cfg["family"] == "sdxl"])
+def test_every_golden_tree_lowers_without_fallback(case, dtype):
+    cfg = S.CASES[case]
+    unet = SDXLUNet(4, device="meta", dtype=dtype)
+    specs = S.build_specs(cfg, S.key_shapes("sdxl"))
+    synth.apply_adapters(unet, refiners_amd.namespace(), device="meta", dtype=dtype, **specs)
+    tokens = {("cross_attention_block", "clip_text_embedding"): (77, 2048)}
+    if specs["ip"] is not None:
+        tokens[("ip_adapter", "clip_image_embedding")] = (4, 2048)
+    low = _dry(unet, 2, *cfg["latent_hw"], dtype, tokens, conditions=[f"control_lora_{c['name']}" for c in specs["control"]])
+    kinds = Counter(e[2] for e in low.step)
+    assert kinds["mi355x_attention"] == (140 if not specs["control"] else 140 + 68)
+    assert kinds["mi355x_layernorm"] == (210 if not specs["control"] else 210 + 102)
+    assert kinds["mi355x_groupnorm"] >= 46 and kinds["mi355x_concat2"] == 9
+    # the text / image K and V^T projections are hoisted out of the per-step program
+    assert sum(1 for e in low.prologue if e[2] == "mi355x_gemm") >= 140
+    assert [f for f in low.stats["fallback_nodes"] if "ConditionEncoder" not in f] == []
+    if case == "sdxl_lora_ip":
+        assert low.stats["lora_sites"] == 722 and low.stats["ip_sites"] == 70
+    if case == "sdxl_bare":
+        assert len(low.step) < 1000  # the reference issues ~2 700 module calls for the same work
+
+
+def test_sd1_tree_lowers_with_torch_sdpa_for_its_head_dims():
+    low = _dry(SD1UNet(4, device="meta"), 1, 32, 32, torch.float32, {("cross_attention_block", "clip_text_embedding"): (77, 768)}, pooled=False)
+    assert Counter(low.stats["fallback_nodes"]) == Counter({"SDPA(head_dim=40)": 10, "SDPA(head_dim=80)": 10, "SDPA(head_dim=160)": 12})
+
+
+def test_inputs_are_read_where_the_context_store_keeps_them():
+    """set_context replaces the top-level dict and merges below (reference context.py:16-46): after the four set_* calls
+    `unet.provider` only shows the last one; the drop-in must still see all of them."""
+    unet = SDXLUNet(4, device="meta")
+    unet.set_timestep(torch.tensor([981]))
+    unet.set_clip_text_embedding(torch.zeros(2, 77, 2048))
+    unet.set_pooled_text_embedding(torch.zeros(2, 1280))
+    unet.set_time_ids(torch.zeros(2, 6))
+    assert set(unet.provider.contexts["diffusion"]) == {"time_ids"}
+    got = CompiledUNet(unet)._gather()
+    assert got["timestep"] is not None and got["pooled"] is not None and got["time_ids"] is not None
+    assert list(got["tokens"]) == [("cross_attention_block", "clip_text_embedding")]
+
+
+def test_scale_and_structure_changes_move_the_tree_epoch():
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd.fluxion.adapters import LinearLora, LoraAdapter
+
+    chain = fl.Chain(fl.Linear(8, 8))
+    e0 = tree_epoch()
+    lora = LinearLora("a", in_features=8, out_features=8, rank=2)
+    adapter = LoraAdapter(chain[0], lora).inject(chain)
+    e1 = tree_epoch()
+    lora.scale = 0.5
+    e2 = tree_epoch()
+    adapter.eject()
+    e3 = tree_epoch()
+    assert e0 < e1 < e2 < e3

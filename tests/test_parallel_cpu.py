@@ -1,0 +1,68 @@
+"""world_size-2 gloo tests of the multi-GPU layer (weights broadcast, prompt sharding, latent gather): the same code
+path the 8-GPU bench takes with backend nccl (= RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, q) -> None:
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd import parallel
+    from refiners_amd.fluxion.adapters import LinearLora, LoraAdapter
+    from refiners_amd.latent_diffusion.sampling import DDIM, SDXLDenoiser  # noqa: F401
+
+    parallel.init_from_env("gloo")
+    torch.manual_seed(100 + rank)  # ranks start with DIFFERENT weights; after the broadcast they must equal rank 0's
+    model = fl.Chain(fl.Linear(16, 32), fl.SiLU(), fl.Linear(32, 8), fl.LayerNorm(8))
+    lora = LinearLora("l", in_features=16, out_features=32, rank=4)
+    torch.nn.init.normal_(lora.up.weight)
+    LoraAdapter(model[0], lora).inject(model)
+    n = parallel.broadcast_module(model, src=0, bucket_bytes=1024)  # tiny buckets: several launches
+    digest = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().sum().item()
+    prompts = [f"p{i}" for i in range(5)]
+    mine = parallel.shard(prompts, rank, world)
+    x = torch.full((len(mine), 4, 2, 2), float(rank))
+    allx = parallel.gather_latents(x, dst=0)
+    slow = parallel.max_over_ranks(1.0 + rank)
+    q.put((rank, n, digest, mine, None if allx is None else allx[:, 0, 0, 0].tolist(), slow))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_shard_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, n0, d0, m0, all0, s0), (r1, n1, d1, m1, all1, s1) = got
+    assert n0 == n1 and n0 > 1
+    assert d0 == d1  # identical weights everywhere after the broadcast
+    assert m0 == ["p0", "p1", "p2"] and m1 == ["p3", "p4"]
+    assert all0 == [0.0, 0.0, 0.0, 1.0, 1.0] and all1 is None
+    assert s0 == s1 == 2.0
+
+
+def test_shard_range_covers_everything():
+    from refiners_amd.parallel import shard_range
+
+    for n in (0, 1, 7, 32):
+        for world in (1, 2, 3, 8):
+            idx = [i for r in range(world) for i in shard_range(n, r, world)]
+            assert idx == list(range(n))
