@@ -305,16 +305,38 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
 }
 
 int g_use_glds = 1;
+int g_tile = 0;  // 0 = heuristic, 1..4 = force a tile configuration (probing / A-B runs)
+
+// Tile configurations (all 4 waves, 2 x 2):  1: 128x128   2: 128x64   3: 64x128   4: 64x64
+// The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
+// how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.
+inline int pick_tile(const GemmP& p) {
+    if (g_tile >= 1 && g_tile <= 4) return g_tile;
+    auto blocks = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    if (blocks(128, 128) >= 448) return 1;
+    if (p.geglu) return blocks(64, 128) >= 256 ? 3 : 3;
+    if (blocks(128, 64) >= 448 || blocks(64, 128) >= 448) return (p.N % 128 == 0 || p.N > 256) ? 3 : 2;
+    return 4;
+}
+
+template <typename T, bool CONV, bool GLDS>
+int launch_tile(const GemmP& p, hipStream_t stream) {
+    switch (pick_tile(p)) {
+        case 1: return launch_cfg<T, 128, 128, 2, 2, CONV, GLDS>(p, stream);
+        case 2: return launch_cfg<T, 128, 64, 2, 2, CONV, GLDS>(p, stream);
+        case 3: return launch_cfg<T, 64, 128, 2, 2, CONV, GLDS>(p, stream);
+        default: return p.geglu ? launch_cfg<T, 64, 128, 2, 2, CONV, GLDS>(p, stream) : launch_cfg<T, 64, 64, 2, 2, CONV, GLDS>(p, stream);
+    }
+}
 
 template <typename T>
 int launch_t(const GemmP& p, bool conv, hipStream_t stream) {
-    // one tile configuration for now: 128x128 block, 2x2 waves of 64x64
     if (g_use_glds) {
-        if (conv) return launch_cfg<T, 128, 128, 2, 2, true, true>(p, stream);
-        return launch_cfg<T, 128, 128, 2, 2, false, true>(p, stream);
+        if (conv) return launch_tile<T, true, true>(p, stream);
+        return launch_tile<T, false, true>(p, stream);
     } else {
-        if (conv) return launch_cfg<T, 128, 128, 2, 2, true, false>(p, stream);
-        return launch_cfg<T, 128, 128, 2, 2, false, false>(p, stream);
+        if (conv) return launch_tile<T, true, false>(p, stream);
+        return launch_tile<T, false, false>(p, stream);
     }
 }
 
@@ -327,6 +349,10 @@ extern "C" int mi355x_set_option(const char* name, int value) {
     // debugging / A-B switches; not part of the stable contract
     if (name && name[0] == 'g') {  // "glds"
         g_use_glds = value;
+        return MI355X_OK;
+    }
+    if (name && name[0] == 't') {  // "tile"
+        g_tile = value;
         return MI355X_OK;
     }
     return MI355X_EARG;

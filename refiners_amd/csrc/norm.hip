@@ -142,44 +142,62 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
+// One workgroup per (group, sample): the cg channels of the group x nchunk partials are reduced by 256 threads in a
+// fixed order (L = 256 / cg lanes per channel, then a serial sum of the L lane totals), so the result is deterministic.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ x, int64_t ldx, int HW, int C, int G,
                                                            int nchunk, const float* __restrict__ part,
                                                            const T* __restrict__ gamma, float eps, float* __restrict__ tab) {
-    extern __shared__ float sm[];  // mean_c[C], m2_c[C]
-    float* mean_c = sm;
-    float* m2_c = sm + C;
-    const int b = blockIdx.x;
+    __shared__ float red[256 * 2];
+    __shared__ float mean_c[256], m2_c[256];
+    __shared__ float stat[2];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cg = C / G;
+    const int L = 256 / cg;  // lanes per channel (cg <= 256 is checked by the host)
+    const int t = threadIdx.x;
+    const int cl = t / L, j = t - cl * L;
+    const bool on = cl < cg;
+    const int c = g * cg + cl;
     const float n = (float)HW;
-    const T* xb = x + (int64_t)b * HW * ldx;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (on) {
         const float* pp = part + ((int64_t)b * nchunk * C + c) * 2;
-        for (int k = 0; k < nchunk; ++k) {
+        for (int k = j; k < nchunk; k += L) {
             s1 += pp[(int64_t)k * C * 2 + 0];
             s2 += pp[(int64_t)k * C * 2 + 1];
         }
-        const float piv = to_f32(xb[c]);
-        mean_c[c] = piv + s1 / n;
-        m2_c[c] = fmaxf(s2 - s1 * s1 / n, 0.f);
+    }
+    red[t * 2 + 0] = s1;
+    red[t * 2 + 1] = s2;
+    __syncthreads();
+    if (on && j == 0) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int q = 0; q < L; ++q) {
+            a1 += red[(t + q) * 2 + 0];
+            a2 += red[(t + q) * 2 + 1];
+        }
+        const float piv = to_f32(x[(int64_t)b * HW * ldx + c]);
+        mean_c[cl] = piv + a1 / n;
+        m2_c[cl] = fmaxf(a2 - a1 * a1 / n, 0.f);
     }
     __syncthreads();
-    const int cg = C / G;
-    float* tb = tab + (int64_t)b * C * 2;
-    for (int gi = threadIdx.x; gi < G; gi += 256) {
+    if (t == 0) {
         float mg = 0.f;
-        for (int c = gi * cg; c < (gi + 1) * cg; ++c) mg += mean_c[c];
+        for (int q = 0; q < cg; ++q) mg += mean_c[q];
         mg /= (float)cg;
         float m2 = 0.f;
-        for (int c = gi * cg; c < (gi + 1) * cg; ++c) {
-            const float d = mean_c[c] - mg;
-            m2 += m2_c[c] + n * d * d;
+        for (int q = 0; q < cg; ++q) {
+            const float d = mean_c[q] - mg;
+            m2 += m2_c[q] + n * d * d;
         }
-        const float rstd = rsqrtf(m2 / (n * (float)cg) + eps);
-        for (int c = gi * cg; c < (gi + 1) * cg; ++c) {
-            tb[c * 2 + 0] = mg;
-            tb[c * 2 + 1] = rstd * to_f32(gamma[c]);
-        }
+        stat[0] = mg;
+        stat[1] = rsqrtf(m2 / (n * (float)cg) + eps);
+    }
+    __syncthreads();
+    if (t < cg) {
+        float* tb = tab + ((int64_t)b * C + g * cg + t) * 2;
+        tb[0] = stat[0];
+        tb[1] = stat[1] * to_f32(gamma[g * cg + t]);
     }
 }
 
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 inline int gn_ppc(int B, int HW, int C, int es) {
     const int nv = C * es / 16;
     const int pl = nv >= 256 ? 1 : 256 / nv;
-    int64_t target = ((int64_t)B * HW + 1023) / 1024;  // ~1024 workgroups
+    int64_t target = ((int64_t)B * HW + 511) / 512;  // ~512 workgroups in total
     int ppc = (int)(target < pl ? pl : target);
     ppc = ((ppc + pl - 1) / pl) * pl;
     if (ppc < 4 * pl) ppc = 4 * pl;
@@ -245,7 +263,7 @@ int run_groupnorm(const mi355x_groupnorm_args* a, hipStream_t st) {
     float* tab = a->ws + (int64_t)a->B * nchunk * a->C * 2;
     const T* x = static_cast<const T*>(a->x);
     hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, ppc, nchunk, part);
-    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->B), dim3(256), a->C * 2 * sizeof(float), st, x, a->ldx, a->HW, a->C, a->G,
+    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, a->G,
                        nchunk, part, static_cast<const T*>(a->gamma), a->eps, tab);
     const int64_t nvec_total = (int64_t)a->B * a->HW * (a->C / EPC);
     int64_t blocks = (nvec_total + 255) / 256;
@@ -285,7 +303,7 @@ extern "C" int mi355x_groupnorm(const mi355x_groupnorm_args* a, void* stream) {
     const int es = a->dtype == MI355X_F32 ? 4 : 2;
     if (a->B <= 0 || a->HW <= 0 || a->C <= 0 || a->G <= 0 || a->C % a->G) return MI355X_ESHAPE;
     if ((a->C * es) % 16 || (a->ldx * es) % 16 || (a->ldo * es) % 16) return MI355X_ESHAPE;
-    if ((a->C * es) / 16 > 256 * GN_MAXVPT) return MI355X_ESHAPE;
+    if ((a->C * es) / 16 > 256 * GN_MAXVPT || a->C / a->G > 256) return MI355X_ESHAPE;
     if (!al16(a->x) || !al16(a->out) || !al16(a->beta)) return MI355X_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return a->dtype == MI355X_F32 ? run_groupnorm<float>(a, st) : run_groupnorm<bf16_t>(a, st);
