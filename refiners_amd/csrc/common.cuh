@@ -85,6 +85,7 @@ MI_DEV void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 MI_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N> MI_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 MI_DEV int lane_id() { return threadIdx.x & 63; }
 MI_DEV int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }

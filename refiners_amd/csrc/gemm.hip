@@ -46,12 +46,13 @@ struct GemmP {
     int vec_ok;
 };
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, bool GLDS>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
     constexpr int XI = BM * 8 / NTHR, WI = BN * 8 / NTHR;
     constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
     constexpr int WNE = 16 * NT;  // columns per wave
     static_assert(BM * 8 % NTHR == 0 && BN * 8 % NTHR == 0, "tile/thread mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,8 +105,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     int total_kb = 0;
     for (int s = 0; s < p.nseg; ++s) total_kb += p.seg[s].nkb;
 
-    frag_t xr[XI], wr[WI];  // register staging (GLDS == false)
-
     auto issue = [&](int buf) {
         const SegP& sp = p.seg[seg];
         char* xs = smem + buf * STAGE;
@@ -133,29 +132,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
             } else {
                 src = sp.x + (int64_t)xm[it] * sp.ldxb + (int64_t)kb * 128 + xcoff[it];
             }
-            if constexpr (GLDS) glds16(src, xs + (it * NTHR + wid * 64) * 16);
-            else xr[it] = *reinterpret_cast<const frag_t*>(src);
+            glds16(src, xs + (it * NTHR + wid * 64) * 16);
         }
 #pragma unroll
         for (int it = 0; it < WI; ++it) {
             const char* src = sp.w + (int64_t)wnrow[it] * sp.ldwb + (int64_t)kb * 128 + wcoff[it];
-            if constexpr (GLDS) glds16(src, ws + (it * NTHR + wid * 64) * 16);
-            else wr[it] = *reinterpret_cast<const frag_t*>(src);
+            glds16(src, ws + (it * NTHR + wid * 64) * 16);
         }
         // advance
         if (++kb == sp.nkb) {
             kb = 0;
             ++seg;
-        }
-    };
-    auto commit = [&](int buf) {  // register-staged variant: write the staged chunks into LDS
-        if constexpr (!GLDS) {
-            char* xs = smem + buf * STAGE;
-            char* ws = xs + XBYTES;
-#pragma unroll
-            for (int it = 0; it < XI; ++it) *reinterpret_cast<frag_t*>(xs + (it * NTHR + tid) * 16) = xr[it];
-#pragma unroll
-            for (int it = 0; it < WI; ++it) *reinterpret_cast<frag_t*>(ws + (it * NTHR + tid) * 16) = wr[it];
         }
     };
     auto compute = [&](int buf) {
@@ -175,18 +162,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         }
     };
 
-    issue(0);
-    commit(0);
-    wait_vm0();
-    __syncthreads();
+    // ---- software pipeline: NSTAGE LDS buffers, D = NSTAGE - 1 K blocks in flight -------------------------------------
+    // per iteration: counted vmcnt (block t has landed, the D-1 younger ones stay in flight) -> raw barrier (no vmcnt(0)
+    // drain, guide section 5 "pipelining across barriers") -> issue block t+D into the buffer block t-1 was computed from
+    // -> MFMA on block t.  One barrier per K block.
+    constexpr int D = NSTAGE - 1;
+    constexpr int LPS = XI + WI;  // global_load_lds instructions per thread per stage
+#pragma unroll
+    for (int s0 = 0; s0 < D; ++s0)
+        if (s0 < total_kb) issue(s0);
     for (int t = 0; t < total_kb; ++t) {
-        const int cur = t & 1;
-        const bool more = (t + 1) < total_kb;
-        if (more) issue(cur ^ 1);
-        compute(cur);
-        if (more) commit(cur ^ 1);
-        wait_vm0();
-        __syncthreads();
+        if (t + D <= total_kb) wait_vm<(D - 1) * LPS>();
+        else wait_vm0();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + D < total_kb) issue((t + D) % NSTAGE);
+        compute(t % NSTAGE);
     }
 
     // ---- epilogue: every lane owns RUN = 4*NT consecutive columns of MT rows ----
@@ -287,10 +278,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, bool GLDS>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
-    constexpr int LDS = 2 * (BM + BN) * 128;
-    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, GLDS>;
+    constexpr int LDS = NSTAGE * (BM + BN) * 128;
+    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -304,40 +295,55 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
 
-int g_use_glds = 1;
-int g_tile = 0;  // 0 = heuristic, 1..4 = force a tile configuration (probing / A-B runs)
+int g_tile = 0;    // 0 = heuristic, 1..4 = force a tile configuration (probing / A-B runs)
+int g_stages = 0;  // 0 = heuristic, 2..4 = force the LDS pipeline depth
 
 // Tile configurations (all 4 waves, 2 x 2):  1: 128x128   2: 128x64   3: 64x128   4: 64x64
 // The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
 // how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.
-inline int pick_tile(const GemmP& p) {
+inline int pick_tile(const GemmP& p, bool conv) {
+    // measured on MI355X over the UNet's shapes (tools/probe_gemm.py, profiles/r01_b_probe_gemm_tiles.log)
     if (g_tile >= 1 && g_tile <= 4) return g_tile;
-    auto blocks = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-    if (blocks(128, 128) >= 448) return 1;
-    if (p.geglu) return blocks(64, 128) >= 256 ? 3 : 3;
-    if (blocks(128, 64) >= 448 || blocks(64, 128) >= 448) return (p.N % 128 == 0 || p.N > 256) ? 3 : 2;
-    return 4;
+    const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (conv) return p.M <= 8192 ? 3 : 1;
+    if (p.geglu) return 1;
+    if (b128 <= 256) return 4;
+    if (b128 < 1000) return 2;
+    return 1;
+}
+inline int pick_stages(const GemmP&, int) {
+    // two LDS stages everywhere: deeper pipelines cost a resident workgroup per CU (LDS), and on these short-K GEMMs
+    // co-resident workgroups hide latency better than prefetch depth does (same probe).
+    if (g_stages >= 2 && g_stages <= 4) return g_stages;
+    return 2;
 }
 
-template <typename T, bool CONV, bool GLDS>
+template <typename T, int BM, int BN, bool CONV>
+int launch_stages(const GemmP& p, int stages, hipStream_t stream) {
+    switch (stages) {
+        case 2: return launch_cfg<T, BM, BN, 2, 2, CONV, 2>(p, stream);
+        case 4: return launch_cfg<T, BM, BN, 2, 2, CONV, 4>(p, stream);
+        default: return launch_cfg<T, BM, BN, 2, 2, CONV, 3>(p, stream);
+    }
+}
+
+template <typename T, bool CONV>
 int launch_tile(const GemmP& p, hipStream_t stream) {
-    switch (pick_tile(p)) {
-        case 1: return launch_cfg<T, 128, 128, 2, 2, CONV, GLDS>(p, stream);
-        case 2: return launch_cfg<T, 128, 64, 2, 2, CONV, GLDS>(p, stream);
-        case 3: return launch_cfg<T, 64, 128, 2, 2, CONV, GLDS>(p, stream);
-        default: return p.geglu ? launch_cfg<T, 64, 128, 2, 2, CONV, GLDS>(p, stream) : launch_cfg<T, 64, 64, 2, 2, CONV, GLDS>(p, stream);
+    int tile = pick_tile(p, CONV);
+    if (p.geglu && (tile == 2 || tile == 4)) tile = 3;  // the GEGLU epilogue needs 64 packed columns per wave
+    const int st = pick_stages(p, tile);
+    switch (tile) {
+        case 1: return launch_stages<T, 128, 128, CONV>(p, st, stream);
+        case 2: return launch_stages<T, 128, 64, CONV>(p, st, stream);
+        case 3: return launch_stages<T, 64, 128, CONV>(p, st, stream);
+        default: return launch_stages<T, 64, 64, CONV>(p, st, stream);
     }
 }
 
 template <typename T>
 int launch_t(const GemmP& p, bool conv, hipStream_t stream) {
-    if (g_use_glds) {
-        if (conv) return launch_tile<T, true, true>(p, stream);
-        return launch_tile<T, false, true>(p, stream);
-    } else {
-        if (conv) return launch_tile<T, true, false>(p, stream);
-        return launch_tile<T, false, false>(p, stream);
-    }
+    if (conv) return launch_tile<T, true>(p, stream);
+    return launch_tile<T, false>(p, stream);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -347,8 +353,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 extern "C" int mi355x_set_option(const char* name, int value);
 extern "C" int mi355x_set_option(const char* name, int value) {
     // debugging / A-B switches; not part of the stable contract
-    if (name && name[0] == 'g') {  // "glds"
-        g_use_glds = value;
+    if (name && name[0] == 'g') return MI355X_OK;  // "glds": the GEMM has a single (global_load_lds) loader now
+    if (name && name[0] == 's') {  // "stages"
+        g_stages = value;
         return MI355X_OK;
     }
     if (name && name[0] == 't') {  // "tile"

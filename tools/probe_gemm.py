@@ -25,8 +25,9 @@ def timeit(fn, iters=30):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def set_tile(v):
+def set_tile(v, st=0):
     native.load().mi355x_set_option(b"tile", v)
+    native.load().mi355x_set_option(b"stages", st)
 
 
 rows = []
@@ -43,11 +44,14 @@ for (M, K, N, geglu, cnt) in GEMMS:
     for tile in (1, 2, 3, 4):
         if geglu and tile in (2, 4):
             continue
-        set_tile(tile)
-        t = min(timeit(lambda: native.gemm([(x, w)], o, geglu=geglu)) for _ in range(3))
-        tf = 2 * M * K * N / t / 1e12
-        rows.append(dict(kind="gemm", M=M, K=K, N=N, geglu=geglu, tile=tile, us=t * 1e6, tflops=tf))
-        print(f"gemm M={M:5d} K={K:5d} N={N:5d} geglu={int(geglu)} tile={tile}: {t*1e6:8.1f} us {tf:7.1f} TF", flush=True)
+        line = f"gemm M={M:5d} K={K:5d} N={N:5d} geglu={int(geglu)} tile={tile}:"
+        for st in (2, 3, 4):
+            set_tile(tile, st)
+            t = min(timeit(lambda: native.gemm([(x, w)], o, geglu=geglu)) for _ in range(3))
+            tf = 2 * M * K * N / t / 1e12
+            rows.append(dict(kind="gemm", M=M, K=K, N=N, geglu=geglu, tile=tile, stages=st, us=t * 1e6, tflops=tf))
+            line += f"  s{st}: {t*1e6:7.1f} us {tf:6.1f} TF"
+        print(line, flush=True)
     set_tile(0)
     t = min(timeit(lambda: native.gemm([(x, w)], o, geglu=geglu)) for _ in range(3))
     print(f"   auto: {t*1e6:8.1f} us {2*M*K*N/t/1e12:7.1f} TF", flush=True)
@@ -60,11 +64,14 @@ for (B, C, Co, H) in CONVS:
     w = (torch.randn(Co, 9 * C, device=dev) * (9 * C) ** -0.5).to(dt)
     o = torch.empty(B * H * H, Co, device=dev, dtype=dt)
     for tile in (1, 2, 3, 4, 0):
-        set_tile(tile)
-        t = min(timeit(lambda: native.conv_gemm([(x, w, 3, 1, 1)], o, B, H, H), iters=10) for _ in range(3))
-        tf = 2 * B * H * H * 9 * C * Co / t / 1e12
-        rows.append(dict(kind="conv", B=B, C=C, Co=Co, H=H, tile=tile, us=t * 1e6, tflops=tf))
-        print(f"conv B={B} C={C:5d} Co={Co:5d} H={H:4d} tile={tile}: {t*1e6:8.1f} us {tf:7.1f} TF", flush=True)
+        line = f"conv B={B} C={C:5d} Co={Co:5d} H={H:4d} tile={tile}:"
+        for st in ((2, 3, 4) if tile else (0,)):
+            set_tile(tile, st)
+            t = min(timeit(lambda: native.conv_gemm([(x, w, 3, 1, 1)], o, B, H, H), iters=10) for _ in range(3))
+            tf = 2 * B * H * H * 9 * C * Co / t / 1e12
+            rows.append(dict(kind="conv", B=B, C=C, Co=Co, H=H, tile=tile, stages=st, us=t * 1e6, tflops=tf))
+            line += f"  s{st}: {t*1e6:7.1f} us {tf:6.1f} TF"
+        print(line, flush=True)
     set_tile(0)
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 (ROOT / "gpurun_out" / "probe_gemm.json").write_text(json.dumps(rows, indent=1))
