@@ -46,7 +46,8 @@ struct GemmP {
     int vec_ok;
 };
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE>
+// ABL (ablation, probing only): 0 = the real kernel; 1 = no MFMA; 2 = no LDS fragment reads; 3 = no global->LDS loads
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
@@ -132,12 +133,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
             } else {
                 src = sp.x + (int64_t)xm[it] * sp.ldxb + (int64_t)kb * 128 + xcoff[it];
             }
-            glds16(src, xs + (it * NTHR + wid * 64) * 16);
+            if constexpr (ABL != 3) glds16(src, xs + (it * NTHR + wid * 64) * 16);
+            else asm volatile("" ::"v"(src));
         }
 #pragma unroll
         for (int it = 0; it < WI; ++it) {
             const char* src = sp.w + (int64_t)wnrow[it] * sp.ldwb + (int64_t)kb * 128 + wcoff[it];
-            glds16(src, ws + (it * NTHR + wid * 64) * 16);
+            if constexpr (ABL != 3) glds16(src, ws + (it * NTHR + wid * 64) * 16);
+            else asm volatile("" ::"v"(src));
         }
         // advance
         if (++kb == sp.nkb) {
@@ -152,13 +155,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         for (int kk = 0; kk < 2; ++kk) {
             frag_t xf[MT], wf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) xf[i] = lds_read_frag(xs, tile_off<128>(wm * 16 * MT + 16 * i + c16, 4 * kk + g));
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (ABL != 2) xf[i] = lds_read_frag(xs, tile_off<128>(wm * 16 * MT + 16 * i + c16, 4 * kk + g));
+                else xf[i] = frag_t{i + buf, kk, lane, 1};
+            }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wf[j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (ABL != 2) wf[j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
+                else wf[j] = frag_t{j, kk + buf, lane, 2};
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) mma_step<T>(acc[i][j], wf[j], xf[i]);
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (ABL != 1) mma_step<T>(acc[i][j], wf[j], xf[i]);
+                    else asm volatile("" ::"v"(wf[j]), "v"(xf[i]));
+                }
         }
     };
 
@@ -278,10 +290,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int ABL = 0>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
     constexpr int LDS = NSTAGE * (BM + BN) * 128;
-    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE>;
+    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -340,8 +352,20 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
     }
 }
 
+int g_ablate = 0;
+
 template <typename T>
 int launch_t(const GemmP& p, bool conv, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2) {
+        if (g_ablate && !conv) {  // probing only: bf16, plain GEMM, 2 stages; tile 1 (128x128) or 4 (64x64)
+            const bool small = g_tile == 4;
+            switch (g_ablate) {
+                case 1: return small ? launch_cfg<T, 64, 64, 2, 2, false, 2, 1>(p, stream) : launch_cfg<T, 128, 128, 2, 2, false, 2, 1>(p, stream);
+                case 2: return small ? launch_cfg<T, 64, 64, 2, 2, false, 2, 2>(p, stream) : launch_cfg<T, 128, 128, 2, 2, false, 2, 2>(p, stream);
+                default: return small ? launch_cfg<T, 64, 64, 2, 2, false, 2, 3>(p, stream) : launch_cfg<T, 128, 128, 2, 2, false, 2, 3>(p, stream);
+            }
+        }
+    }
     if (conv) return launch_tile<T, true>(p, stream);
     return launch_tile<T, false>(p, stream);
 }
@@ -354,6 +378,10 @@ extern "C" int mi355x_set_option(const char* name, int value);
 extern "C" int mi355x_set_option(const char* name, int value) {
     // debugging / A-B switches; not part of the stable contract
     if (name && name[0] == 'g') return MI355X_OK;  // "glds": the GEMM has a single (global_load_lds) loader now
+    if (name && name[0] == 'a') {  // "ablate"
+        g_ablate = value;
+        return MI355X_OK;
+    }
     if (name && name[0] == 's') {  // "stages"
         g_stages = value;
         return MI355X_OK;
