@@ -42,7 +42,10 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     procs = []
     for src in SOURCES:
         obj = CSRC / (src.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(CSRC / src), "-o", str(obj)]
+        # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified), which removes the
+        # v_accvgpr_read/write traffic between the softmax / epilogue VALU code and the matrix cores (attention inner
+        # loop: 1062 -> 876 instructions) and lowers the total register count of every kernel.
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -51,7 +51,10 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     constexpr int NTHR = NW * 64;
     constexpr int TILEB = 64 * ROWB;
     constexpr int STAGE = 2 * TILEB;
+    constexpr int NST = GLDS ? 3 : 2;  // LDS ring depth: the glds loader keeps two K/V tiles in flight (counted vmcnt)
+    constexpr int PD = NST - 1;
     constexpr int LI = 64 * CPR / NTHR;  // loader iterations per tile
+    constexpr int LPS = 2 * LI;          // global_load_lds instructions per thread per K/V tile pair
     constexpr int NS = D / DT<T>::KSTEP;  // MMA steps over head dim
     constexpr bool IS_BF16 = (ES == 2);
     static_assert(64 * CPR % NTHR == 0, "loader mismatch");
@@ -146,15 +149,32 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
 
         // all waves must be done reading LDS of the previous stream before it is overwritten
         __syncthreads();
-        issue(0, 0);
-        commit(0);
-        wait_vm0();
-        __syncthreads();
+        if constexpr (GLDS) {
+#pragma unroll
+            for (int s0 = 0; s0 < PD; ++s0)
+                if (s0 < ntile) issue(s0, s0);
+        } else {
+            issue(0, 0);
+            commit(0);
+            wait_vm0();
+            __syncthreads();
+        }
 
         for (int tile = 0; tile < ntile; ++tile) {
-            const int cur = tile & 1;
+            int cur;
             const bool more = tile + 1 < ntile;
-            if (more) issue(tile + 1, cur ^ 1);
+            if constexpr (GLDS) {
+                // tile `tile` has landed (the younger PD-1 stay in flight) -> raw barrier -> refill the buffer read last iteration
+                if (tile + PD <= ntile) wait_vm<(PD - 1) * LPS>();
+                else wait_vm0();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (tile + PD < ntile) issue(tile + PD, (tile + PD) % NST);
+                cur = tile % NST;
+            } else {
+                cur = tile & 1;
+                if (more) issue(tile + 1, cur ^ 1);
+            }
             const char* ks = smem + cur * STAGE;
             const char* vs = ks + TILEB;
 
@@ -195,14 +215,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float mnew = fmaxf(mrun[jq], mx);
-                const float alpha = exp2f((mrun[jq] - mnew) * p.c);
+                const float alpha = fast_exp2((mrun[jq] - mnew) * p.c);
                 const float mc = mnew * p.c;
                 float ps = 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = exp2f(st[t][jq][r] * p.c - mc);
+                        const float e = fast_exp2(st[t][jq][r] * p.c - mc);
                         st[t][jq][r] = e;
                         ps += e;
                     }
@@ -251,9 +271,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                     }
                 }
             }
-            if (more) commit(cur ^ 1);
-            wait_vm0();
-            __syncthreads();
+            if constexpr (!GLDS) {
+                if (more) commit(cur ^ 1);
+                wait_vm0();
+                __syncthreads();
+            }
         }
 
         // ---- finish this stream ----
@@ -293,11 +315,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     }
 }
 
-int g_attn_glds = 1;
+int g_attn_glds = 0;  // register-staged K/V loader by default: measured faster than glds for attention (probe_attn3)
 
 template <typename T, int NW, int NSTREAM, bool GLDS>
 int launch_attn(const AttnP& p0, hipStream_t stream) {
-    constexpr int LDS = 2 * 2 * 64 * 64 * sizeof(T);
+    constexpr int LDS = (GLDS ? 3 : 2) * 2 * 64 * 64 * sizeof(T);
     auto kfn = attn_kernel<T, NW, NSTREAM, GLDS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -311,19 +333,34 @@ int launch_attn(const AttnP& p0, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
 
+int g_attn_nw = 0;  // 0 = heuristic, 2 / 4 = force the number of waves (32 queries each) per workgroup
+
+template <typename T, int NW>
+int launch_attn_nw(const AttnP& p, hipStream_t stream) {
+    if (g_attn_glds) {
+        if (p.nstream == 2) return launch_attn<T, NW, 2, true>(p, stream);
+        return launch_attn<T, NW, 1, true>(p, stream);
+    }
+    if (p.nstream == 2) return launch_attn<T, NW, 2, false>(p, stream);
+    return launch_attn<T, NW, 1, false>(p, stream);
+}
+
 template <typename T>
 int launch_attn_t(const AttnP& p, hipStream_t stream) {
-    if (g_attn_glds) {
-        if (p.nstream == 2) return launch_attn<T, 4, 2, true>(p, stream);
-        return launch_attn<T, 4, 1, true>(p, stream);
-    }
-    if (p.nstream == 2) return launch_attn<T, 4, 2, false>(p, stream);
-    return launch_attn<T, 4, 1, false>(p, stream);
+    // 128-query workgroups unless that leaves the 256 CUs with fewer than two workgroups each
+    int nw = g_attn_nw;
+    if (nw != 2 && nw != 4) nw = 4;  // 2-wave workgroups never won on MI355X (profiles/r01_c_probe_attention.log)
+    return nw == 2 ? launch_attn_nw<T, 2>(p, stream) : launch_attn_nw<T, 4>(p, stream);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int mi355x_attention_set_nw(int v) {
+    g_attn_nw = v;
+    return MI355X_OK;
+}
 
 extern "C" int mi355x_attention_set_glds(int v) {
     g_attn_glds = v;

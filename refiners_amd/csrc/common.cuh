@@ -99,6 +99,9 @@ MI_DEV int xcd_remap(int bid, int nblk) {
     return base + idx;
 }
 
+// v_exp_f32 without the denormal-range fix-up sequence exp2f() expands to: softmax arguments are <= 0 and results that
+// would be denormal are flushed to 0, which is what an online softmax wants.
+MI_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 MI_DEV float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 MI_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -42,7 +42,8 @@ struct GemmP {
     const char* res;
     int64_t ldres;  // elements
     const char* zeros;
-    int tiles_n;
+    int tiles_m, tiles_n;
+    int pn, hm, hn;  // XCD rasterisation: the 8 XCDs own a pm x pn grid of hm x hn-tile regions
     int vec_ok;
 };
 
@@ -61,8 +62,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
     const int g = lane >> 4, c16 = lane & 15;
     const int wm = wid / WN, wn = wid % WN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+    // XCD-aware rasterisation: workgroup b runs on XCD b % 8 (observed dispatch rule, a speed assumption only); each XCD
+    // owns one rectangular region of the tile grid so that its private L2 sees as few distinct operand rows as possible.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int rm = xcd / p.pn, rn = xcd - rm * p.pn;
+    const int lm = idx / p.hn, ln = idx - lm * p.hn;
+    const int tm = rm * p.hm + lm, tn = rn * p.hn + ln;
+    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-thread loader coordinates (fixed for the whole K loop) ----
@@ -301,8 +307,28 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     }
     GemmP q = p;
     q.tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int grid = tiles_m * q.tiles_n;
+    q.tiles_m = (p.M + BM - 1) / BM;
+    // split the 8 XCDs pm x pn so that the operand bytes pulled into the L2s, pn * |X| + pm * |W| ~ pn * M + pm * N, is
+    // smallest among the splits that leave no XCD idle
+    int best_pm = 8, best_pn = 1;
+    double best = 1e300;
+    for (int pm = 1; pm <= 8; pm *= 2) {
+        const int pn = 8 / pm;
+        if (pm > q.tiles_m && pm > 1) continue;
+        if (pn > q.tiles_n && pn > 1) continue;
+        const int hm = (q.tiles_m + pm - 1) / pm, hn = (q.tiles_n + pn - 1) / pn;
+        const double waste = (double)(hm * pm) * (hn * pn) / ((double)q.tiles_m * q.tiles_n);  // padding blocks exit at once
+        const double cost = ((double)pn * p.M + (double)pm * p.N) * (0.75 + 0.25 * waste);
+        if (cost < best) {
+            best = cost;
+            best_pm = pm;
+            best_pn = pn;
+        }
+    }
+    q.pn = best_pn;
+    q.hm = (q.tiles_m + best_pm - 1) / best_pm;
+    q.hn = (q.tiles_n + best_pn - 1) / best_pn;
+    const int grid = 8 * q.hm * q.hn;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64), LDS, stream, q);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
@@ -315,9 +341,9 @@ int g_stages = 0;  // 0 = heuristic, 2..4 = force the LDS pipeline depth
 // how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.
 inline int pick_tile(const GemmP& p, bool conv) {
     // measured on MI355X over the UNet's shapes (tools/probe_gemm.py, profiles/r01_b_probe_gemm_tiles.log)
-    if (g_tile >= 1 && g_tile <= 4) return g_tile;
+    if (g_tile >= 1 && g_tile <= 5) return g_tile;
     const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (conv) return p.M <= 8192 ? 3 : 1;
+    if (conv) return 3;  // 64 x 128 wins for every conv shape of the UNet (r01_b probe: 339 / 540 / 570 TF at 32^2 / 64^2 / 128^2)
     if (p.geglu) return 1;
     if (b128 <= 256) return 4;
     if (b128 < 1000) return 2;
@@ -338,6 +364,12 @@ int launch_stages(const GemmP& p, int stages, hipStream_t stream) {
         default: return launch_cfg<T, BM, BN, 2, 2, CONV, 3>(p, stream);
     }
 }
+// tile 5: 256 x 128, 8 waves (4 x 2) of 64 x 64: 25 % fewer operand bytes per FLOP through the L1 -> LDS path than 128 x 128
+template <typename T, bool CONV>
+int launch_big(const GemmP& p, int stages, hipStream_t stream) {
+    if (stages == 3) return launch_cfg<T, 256, 128, 4, 2, CONV, 3>(p, stream);
+    return launch_cfg<T, 256, 128, 4, 2, CONV, 2>(p, stream);
+}
 
 template <typename T, bool CONV>
 int launch_tile(const GemmP& p, hipStream_t stream) {
@@ -348,6 +380,7 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
         case 1: return launch_stages<T, 128, 128, CONV>(p, st, stream);
         case 2: return launch_stages<T, 128, 64, CONV>(p, st, stream);
         case 3: return launch_stages<T, 64, 128, CONV>(p, st, stream);
+        case 5: return launch_big<T, CONV>(p, st, stream);
         default: return launch_stages<T, 64, 64, CONV>(p, st, stream);
     }
 }
