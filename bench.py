@@ -92,6 +92,8 @@ def main() -> None:
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lora-mode", choices=["fused", "merged"], default="merged",
+                    help="merged: W' = W + sum s B A formed at lowering time (one launch per adapted layer); fused: run-time LoRA K segments")
     args = ap.parse_args()
 
     import refiners_amd
@@ -127,7 +129,7 @@ def main() -> None:
     # ---- inputs: independent prompts per rank, resident in HBM -------------------------------------------------------
     n_img = args.images_per_gpu
     inp = synth.sdxl_inputs(n_img, LATENT, seed=100 + rank)
-    pipe = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=not args.no_graph)
+    pipe = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=not args.no_graph, lora_mode=args.lora_mode)
     kw = {}
     if specs["ip"] is not None:
         kw["clip_image_embedding"] = specs["ip"]["tokens"].to(dev)
@@ -211,7 +213,8 @@ def main() -> None:
         "config": {"workload": "SDXL-base UNet CFG step, 1024x1024 (latent 2x4x128x128, 77 text tokens), DDIM-50" +
                    ("" if args.workload == "bare" else " + 2 LoRA r16 (722 Linears) + IP-Adapter"),
                    "baseline_config": "configs[1]" if args.workload == "bare" else "configs[2]", "images_per_gpu": n_img,
-                   "parallelism": f"replica x{world} (independent prompts, weights broadcast once)", "hip_graph": not args.no_graph},
+                   "parallelism": f"replica x{world} (independent prompts, weights broadcast once)", "hip_graph": not args.no_graph,
+                   "lora_mode": args.lora_mode if args.workload != "bare" else None},
         "step_latency_ms": round(ms_per_step, 3),
         "roofline": roofline, "cpu_baseline": cpu,
         "extra": {"params": n_params, "launches_per_step": pipe.engine.stats["step_ops"], "prologue_launches": pipe.engine.stats["prologue_ops"],

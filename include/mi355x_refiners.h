@@ -204,6 +204,14 @@ int mi355x_axpby(int32_t dtype, const void* a, float alpha, const void* b, float
 /* out = silu(x) over n elements. */
 int mi355x_silu(int32_t dtype, const void* x, void* out, int64_t n, void* stream);
 
+/* Sinusoidal embedding (src/refiners/foundationals/latent_diffusion/range_adapter.py:11-22, used for the timestep,
+ * stable_diffusion_xl/unet.py:56-78, and for time_ids, :20-53): for each of the n float32 values x[i],
+ *   out[(i / group) * ldo + col0 + (i % group) * dim + j]           = cos(x[i] * 10000^(-j / (dim/2)))
+ *   out[(i / group) * ldo + col0 + (i % group) * dim + dim/2 + j]   = sin(x[i] * 10000^(-j / (dim/2))),  j < dim/2
+ * computed in float32 and stored as `dtype`.  group = values per output row (1 for the timestep, 6 for SDXL's time_ids). */
+int mi355x_sinusoidal(int32_t dtype, const float* x, int64_t n, int32_t dim, int32_t group, void* out, int64_t ldo, int32_t col0,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * mi355x_cfg_ddim_step -- classifier-free-guidance combine + DDIM update in one launch, no host sync.
  * Replaces LatentDiffusionModel.forward's chunk/combine (src/refiners/foundationals/latent_diffusion/model.py:142-145)

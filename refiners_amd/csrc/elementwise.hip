@@ -120,6 +120,25 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(T* __restrict__ x, const 
     }
 }
 
+// out[(i / group) * ldo + col0 + (i % group) * dim + j]       = cos(x[i] * 10000^(-j / half)),  j < half
+// out[(i / group) * ldo + col0 + (i % group) * dim + half + j] = sin(...)                         (float32 arithmetic)
+template <typename T>
+__global__ __launch_bounds__(256) void sinusoidal_kernel(const float* __restrict__ x, int64_t n, int dim, int group, T* __restrict__ out,
+                                                          int64_t ldo, int col0) {
+    const int half = dim / 2;
+    const int64_t total = n * half;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t i = q / half;
+        const int j = (int)(q - i * half);
+        float e = -9.210340371976184f * (float)j;  // -ln(10000) * j, then / half: the reference's operation order
+        e /= (float)half;
+        const float a = x[i] * expf(e);
+        T* o = out + (i / group) * ldo + col0 + (i % group) * dim;
+        o[j] = from_f32<T>(cosf(a));
+        o[half + j] = from_f32<T>(sinf(a));
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL)                          \
@@ -212,5 +231,14 @@ extern "C" int mi355x_cfg_ddim_step(int32_t dtype, void* x, const void* unet_out
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = grid_for(n);
     DISPATCH_T(dtype, hipLaunchKernelGGL((cfg_ddim_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<T*>(x), static_cast<const T*>(unet_out), coef, n));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_sinusoidal(int32_t dtype, const float* x, int64_t n, int32_t dim, int32_t group, void* out, int64_t ldo, int32_t col0,
+                                 void* stream) {
+    if (!x || !out || n <= 0 || dim <= 0 || dim % 2 || group <= 0) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n * (dim / 2));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((sinusoidal_kernel<T>), dim3(grid), dim3(256), 0, st, x, n, (int)dim, (int)group, static_cast<T*>(out), ldo, (int)col0));
     return LAUNCH_OK();
 }

@@ -35,10 +35,11 @@ def _ident(t: Optional[Tensor]) -> Any:
 
 
 class CompiledUNet:
-    def __init__(self, unet: Any, use_graph: bool = True) -> None:
+    def __init__(self, unet: Any, use_graph: bool = True, lora_mode: str = "fused") -> None:
         native.load()  # fail loudly: there is no fallback for a missing HIP library
         self.unet = unet
         self.use_graph = use_graph
+        self.lora_mode = lora_mode  # see Lowering.__init__
         self.cache = PackCache()
         self.low: Optional[UNetLowering] = None
         self.io: Optional[UNetIO] = None
@@ -89,7 +90,7 @@ class CompiledUNet:
             io.tokens[ck] = (torch.zeros(B * lp, width, device=dev, dtype=dtype), L)
         for name, v in got["conditions"].items():
             io.conditions[name] = torch.empty(tuple(v.shape), device=dev, dtype=dtype)
-        low = UNetLowering(dev, dtype, self.cache)
+        low = UNetLowering(dev, dtype, self.cache, self.lora_mode)
         low.lower(self.unet, io)
         self.cache.sweep()
         self.low, self.io, self.graph, self.prologue_key = low, io, None, None
@@ -176,11 +177,11 @@ class CompiledSDXL:
     The per-step host work is: two tiny device copies (timestep, DDIM coefficients) and one hipGraphLaunch.  The Chain
     tree's context store is not touched per step (the reference spends ~19 000 Python calls per step on it)."""
 
-    def __init__(self, unet: Any, num_inference_steps: int = 50, condition_scale: float = 5.0, use_graph: bool = True) -> None:
+    def __init__(self, unet: Any, num_inference_steps: int = 50, condition_scale: float = 5.0, use_graph: bool = True, lora_mode: str = "fused") -> None:
         from ..latent_diffusion.sampling import DDIM
 
         self.unet = unet
-        self.engine = CompiledUNet(unet, use_graph=False)
+        self.engine = CompiledUNet(unet, use_graph=False, lora_mode=lora_mode)
         self.use_graph = use_graph
         self.solver = DDIM(num_inference_steps)
         self.condition_scale = condition_scale

@@ -189,7 +189,14 @@ class PackCache:
 
 # ------------------------------------------------------------------------------------------------ the lowering
 class Lowering:
-    def __init__(self, device: torch.device, dtype: torch.dtype, cache: Optional[PackCache] = None) -> None:
+    def __init__(self, device: torch.device, dtype: torch.dtype, cache: Optional[PackCache] = None, lora_mode: str = "fused") -> None:
+        # lora_mode: "fused"  = LoraAdapter semantics kept at run time: one skinny down-projection launch per adapted
+        #                       site, up-projections as an extra K segment of the parent GEMM (exactly the reference's sum);
+        #            "merged" = W' = W + sum_i s_i B_i A_i is formed once per (weights, scales) in float32 and rounded to
+        #                       the compute dtype: an adapted Linear / Conv2d costs exactly ONE launch and zero extra
+        #                       FLOPs.  Scales stay live: changing them re-lowers and re-merges the touched sites only.
+        assert lora_mode in ("fused", "merged")
+        self.lora_mode = lora_mode
         self.device, self.dtype = device, dtype
         self.es = 4 if dtype == torch.float32 else 2
         self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
@@ -293,6 +300,24 @@ class Lowering:
         if geglu:
             _expect(n_out % 64 == 0, "GEGLU width must be a multiple of 64")
             perm = self.cache.get(("geglu_idx", n_out), lambda: native.geglu_pack_index(n_out // 2, device=self.device))
+        if loras and self.lora_mode == "merged":
+            downs = [kids(lr)[0].weight for lr in loras]
+            ups = [kids(lr)[1].weight for lr in loras]
+            scales = tuple(float(kids(lr)[2].scale) for lr in loras)
+
+            def merge() -> Tensor:
+                acc = w.detach().to(device=self.device, dtype=torch.float32).clone()
+                for d, u, sc in zip(downs, ups, scales):
+                    _expect(tuple(d.shape)[1] == k_in and tuple(u.shape)[0] == n_out, "LoRA shape does not match its target")
+                    acc.addmm_(u.detach().to(self.device, torch.float32), d.detach().to(self.device, torch.float32), alpha=sc)
+                acc = acc.to(self.dtype)
+                return acc[perm].contiguous() if perm is not None else acc.contiguous()
+
+            wm = self.cache.get(("merged", geglu) + PackCache.ident(w, *downs, *ups) + scales, merge)
+            self.stats["lora_sites"] += 1
+            bp = None if b is None else (self.cache.get(("geglu_b",) + PackCache.ident(b), lambda: self.cvt(b)[perm].contiguous()) if geglu else self._w(b))
+            return LinSpec(wm, bp, None, geglu=geglu)
+        if geglu:
             wp = self.cache.get(("geglu_w",) + PackCache.ident(w), lambda: self.cvt(w)[perm].contiguous())
             bp = None if b is None else self.cache.get(("geglu_b",) + PackCache.ident(b), lambda: self.cvt(b)[perm].contiguous())
             return LinSpec(wp, bp, self._lora_pack_linear(loras, n_out, k_in, perm), geglu=True)
@@ -319,6 +344,20 @@ class Lowering:
         _expect((i * self.es) % 128 == 0, f"conv in_channels {i} not 128-byte aligned")
         wp = self.cache.get(("convw",) + PackCache.ident(w), lambda: native.pack_conv_weight(self.cvt(w)))
         lora = None
+        if loras and self.lora_mode == "merged" and all(kids(lr)[1].kernel_size == (1, 1) and kids(lr)[0].kernel_size == (kh, kh) for lr in loras):
+            dws = [kids(lr)[0].weight for lr in loras]
+            uws = [kids(lr)[1].weight for lr in loras]
+            scs = tuple(float(kids(lr)[2].scale) for lr in loras)
+
+            def merge_conv() -> Tensor:
+                acc = w.detach().to(device=self.device, dtype=torch.float32).clone()
+                for d, u, sc in zip(dws, uws, scs):  # (B A)[o, i, ky, kx] = sum_r B[o, r] A[r, i, ky, kx]
+                    acc += sc * torch.einsum("or,rikl->oikl", u.detach().to(self.device, torch.float32)[:, :, 0, 0], d.detach().to(self.device, torch.float32))
+                return native.pack_conv_weight(acc.to(self.dtype))
+
+            wp = self.cache.get(("merged_conv",) + PackCache.ident(w, *dws, *uws) + scs, merge_conv)
+            self.stats["lora_sites"] += 1
+            loras = []
         if loras:
             downs = [kids(lr)[0] for lr in loras]
             ups = [kids(lr)[1] for lr in loras]
@@ -762,11 +801,10 @@ class UNetLowering(Lowering):
         _expect(len(ch) == 5 and isa(ch[0], "Lambda") and isa(ch[1], "Converter") and isa(ch[3], "SiLU"), "unexpected RangeEncoder layout")
         l1, l2 = self.linear_spec(ch[2]), self.linear_spec(ch[4])
         B = self.io.timestep.shape[0]
-        sin = torch.empty(B, enc.sinusoidal_embedding_dim, device=self.device, dtype=self.dtype)
-        ts = self.io.timestep
-        dim = enc.sinusoidal_embedding_dim
-        self.python(lambda: sin.copy_(sinusoid_rows(ts, dim)), "sinusoid(timestep)")
+        sin = self.pool.get(B, enc.sinusoidal_embedding_dim)
+        native.sinusoidal(self.io.timestep, enc.sinusoidal_embedding_dim, sin)
         e1 = self.linear(sin, l1)
+        self.pool.put(sin)
         e1s = self.pool.get(B, l1.N)
         native.silu(e1, e1s)
         te = self.linear(e1s, l2, res=res)
@@ -785,16 +823,15 @@ class UNetLowering(Lowering):
             l1, l2 = self.linear_spec(tt[2]), self.linear_spec(tt[4])
             _expect(self.io.pooled is not None and self.io.time_ids is not None, "SDXL needs pooled_text_embedding and time_ids")
             with self.in_prologue():  # constant over the sampling loop
-                cat = torch.empty(B, l1.K, device=self.device, dtype=self.dtype)
                 pooled, ids, dim = self.io.pooled, self.io.time_ids, sc[1].time_ids_embedding_dim
                 _expect(pooled.shape[1] + ids.shape[1] * dim == l1.K, "TextTimeEmbedding width mismatch")
-
-                def fill() -> None:
-                    cat[:, : pooled.shape[1]] = pooled
-                    cat[:, pooled.shape[1] :] = sinusoid_rows(ids.reshape(-1), dim).reshape(B, -1)
-
-                self.python(fill, "text_time_concat")
+                emb = self.pool.get(B, ids.shape[1] * dim)
+                native.sinusoidal(ids, dim, emb, group=ids.shape[1])
+                cat = self.pool.get(B, l1.K)
+                native.concat2(pooled, emb, cat)
                 t1 = self.linear(cat, l1)
+                self.pool.put(emb)
+                self.pool.put(cat)
                 t1s = self.pool.get(B, l1.N)
                 native.silu(t1, t1s)
                 tte = self.pool.get(B, l2.N)
@@ -932,28 +969,57 @@ class UNetLowering(Lowering):
         native.gemm([(cur.t, w)], z, bias=b, res=None if prev is None else prev.t)
         ctx.residuals[ch[2].n] = Act(z, cur.B, cur.H, cur.W)
 
+    def _padded_conv_spec(self, conv: Any, cin_pad: int, cout_pad: int) -> ConvSpec:
+        """Conv2d whose channel counts are below the kernel's 128-byte granularity: zero-pad input channels (weight
+        columns) and output channels (weight rows, bias) so that padded activations stay exactly zero."""
+        _expect(isa(conv, "Conv2d") and conv.kernel_size == (3, 3) and tuple(conv.padding) == (1, 1) and conv.stride[0] == conv.stride[1], "unexpected ConditionEncoder conv")
+        o, i = conv.out_channels, conv.in_channels
+
+        def pack() -> tuple[Tensor, Tensor]:
+            w = torch.zeros(cout_pad, cin_pad, 3, 3, device=self.device, dtype=self.dtype)
+            w[:o, :i] = conv.weight.detach().to(device=self.device, dtype=self.dtype)
+            b = torch.zeros(cout_pad, device=self.device, dtype=self.dtype)
+            b[:o] = conv.bias.detach().to(device=self.device, dtype=self.dtype)
+            return native.pack_conv_weight(w), b
+
+        wp, bp = self.cache.get(("padconv", cin_pad, cout_pad) + PackCache.ident(conv.weight, conv.bias), pack)
+        return ConvSpec(wp, bp, cin_pad, cout_pad, 3, conv.stride[0])
+
+    def condition_encoder(self, enc: Any, cond: Tensor) -> Act:
+        """ConditionEncoder (control_lora.py:14-87): (B, 3, 8H, 8W) -> (B, 320, H, W), eight 3x3 convs with SiLU.  Runs in
+        the prologue (the control image is constant over the sampling loop) on channel-padded NHWC activations."""
+        convs = [m for m in enc.modules() if isa(m, "Conv2d")]
+        order = [m for m in enc.modules() if isa(m, "Conv2d", "SiLU")]
+        _expect(len(convs) == 8 and isa(order[-1], "Conv2d"), "unexpected ConditionEncoder layout")
+        pad = lambda c: (c + self.kblk - 1) // self.kblk * self.kblk
+        B, C, H, W = cond.shape
+        x = torch.zeros(B * H * W, pad(C), device=self.device, dtype=self.dtype)  # padding channels stay zero for ever
+        self.prologue_keep = getattr(self, "prologue_keep", []) + [x]
+        a = Act(x, B, H, W)
+        native.nchw_to_nhwc(cond, a.tokens())
+        for k, m in enumerate(order):
+            if isa(m, "SiLU"):
+                native.silu(a.t, a.t)
+                continue
+            last = m is order[-1]
+            spec = self._padded_conv_spec(m, a.C, m.out_channels if last else pad(m.out_channels))
+            nxt = self.conv(a, spec)
+            if a.t is not x:
+                self.pool.put(a.t)
+            a = nxt
+        return a
+
     def add_condition(self, m: Any, cur: Act) -> Act:
-        """x + ConditionEncoder(condition)   (control_lora.py:190-202).  The encoder sees a constant image, so it runs in
-        the prologue; its 3/16/32/96-channel convolutions are below the 128-byte granularity of the implicit-GEMM kernel
-        and go through torch there."""
+        """x + ConditionEncoder(condition)   (control_lora.py:190-202), encoder output produced in the prologue."""
         reader, enc = kids(m)
         cond = self.io.conditions.get(reader.context)
         _expect(cond is not None, f"no condition image registered for {reader.context}")
-        e_nchw = torch.empty(cur.B, cur.C, cur.H, cur.W, device=self.device, dtype=self.dtype)
         with self.in_prologue():
-            e = self.pool.get(cur.M, cur.C)  # prologue arena: must survive across steps
-            self.pool.pin(e)
-
-            def run() -> None:
-                y = enc(cond)
-                assert tuple(y.shape) == tuple(e_nchw.shape), f"ConditionEncoder produced {tuple(y.shape)}"
-                e_nchw.copy_(y)
-
-            self.python(run, "torch:ConditionEncoder")
-            native.nchw_to_nhwc(e_nchw, Act(e, cur.B, cur.H, cur.W).tokens())
-        self.stats["fallback_nodes"].append("ConditionEncoder(prologue)")
+            e = self.condition_encoder(enc, cond)
+            self.pool.pin(e.t)
+        _expect((e.B, e.H, e.W, e.C) == (cur.B, cur.H, cur.W, cur.C), "ConditionEncoder output does not match the UNet stem")
         out = self.pool.get(cur.M, cur.C)
-        native.axpby(cur.t, 1.0, e, 1.0, out)
+        native.axpby(cur.t, 1.0, e.t, 1.0, out)
         return Act(out, cur.B, cur.H, cur.W)
 
     def control_lora(self, node: Any, ctx: UNetContext, H: int, W: int) -> None:

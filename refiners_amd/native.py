@@ -148,6 +148,7 @@ EXPORTS = [
     "mi355x_axpby",
     "mi355x_silu",
     "mi355x_cfg_ddim_step",
+    "mi355x_sinusoidal",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -183,6 +184,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_axpby.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_silu.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_cfg_ddim_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mi355x_sinusoidal.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     if lib.mi355x_abi_version() != 1:
@@ -520,6 +522,14 @@ def cfg_ddim_step(x: Tensor, unet_out: Tensor, coef: Tensor) -> Tensor:
     assert coef.dtype == torch.float32 and coef.numel() >= 5 and coef.is_cuda
     _launch("mi355x_cfg_ddim_step", (dtype_code(x.dtype), x.data_ptr(), unet_out.data_ptr(), coef.data_ptr(), x.numel(),), "mi355x_cfg_ddim_step")
     return x
+
+
+def sinusoidal(x: Tensor, dim: int, out: Tensor, group: int = 1, col0: int = 0) -> Tensor:
+    """x: float32 values (any shape, contiguous); out: 2-D [x.numel() / group, >= col0 + group * dim] rows of the compute dtype."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.dim() == 2 and out.stride(1) == 1
+    assert x.numel() % group == 0 and out.shape[0] >= x.numel() // group and out.shape[1] >= col0 + group * dim
+    _launch("mi355x_sinusoidal", (dtype_code(out.dtype), x.data_ptr(), x.numel(), dim, group, out.data_ptr(), out.stride(0), col0), "mi355x_sinusoidal")
+    return out
 
 
 def set_glds(enabled: bool) -> None:

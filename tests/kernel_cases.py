@@ -257,6 +257,20 @@ def cfg_ddim_case(n, dtype, seed=120):
     return _cmp(x, ref, dtype)
 
 
+def sinusoidal_case(n, dim, group, dtype, seed=130):
+    x = (torch.rand(n, generator=torch.Generator().manual_seed(seed)) * 1000).to(DEV)
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32, device=DEV) / half
+    ang = x.unsqueeze(1) * torch.exp(exponent).unsqueeze(0)
+    ref = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).reshape(n // group, group * dim)
+    col0 = 16
+    out = torch.zeros(n // group, col0 + group * dim + 8, dtype=dtype, device=DEV)
+    native.sinusoidal(x, dim, out, group=group, col0=col0)
+    assert float(out[:, :col0].abs().max()) == 0 and float(out[:, col0 + group * dim :].abs().max()) == 0
+    # cos / sin of arguments up to 1000 rad: float32 argument rounding alone is ~6e-5 absolute
+    return (out[:, col0 : col0 + group * dim].float() - ref).abs().max().item(), 1.0, (2e-4 if dtype == torch.float32 else 8e-3)
+
+
 def all_cases():
     """(name, thunk) list; sizes chosen so the whole list runs in well under a minute on one MI355X."""
     cases = []
@@ -295,5 +309,7 @@ def all_cases():
             (f"layout_{tag}_320", lambda dt=dt: layout_case(1, 320, 16, 24, dt)),
             (f"concat_axpby_{tag}", lambda dt=dt: concat_axpby_case(1000, 640, 320, dt)),
             (f"cfg_ddim_{tag}", lambda dt=dt: cfg_ddim_case(4 * 128 * 128, dt)),
+            (f"sinusoidal_{tag}_timestep", lambda dt=dt: sinusoidal_case(2, 320, 1, dt)),
+            (f"sinusoidal_{tag}_time_ids", lambda dt=dt: sinusoidal_case(12, 256, 6, dt)),
         ]
     return cases

@@ -76,6 +76,21 @@ def test_every_golden_tree_lowers_without_fallback(case, dtype):
         assert len(low.step) < 1000  # the reference issues ~2 700 module calls for the same work
 
 
+def test_merged_lora_mode_adds_no_step_launch():
+    cfg = S.CASES["sdxl_lora_ip"]
+    unet = SDXLUNet(4, device="meta", dtype=torch.bfloat16)
+    specs = S.build_specs(cfg, S.key_shapes("sdxl"))
+    synth.apply_adapters(unet, refiners_amd.namespace(), device="meta", dtype=torch.bfloat16, **specs)
+    dev = torch.device("meta")
+    io = UNetIO(x=torch.empty(2, 4, 32, 32, device=dev, dtype=torch.bfloat16), timestep=torch.empty(2, device=dev), out=torch.empty(2, 4, 32, 32, device=dev, dtype=torch.bfloat16))
+    io.pooled, io.time_ids = torch.empty(2, 1280, device=dev, dtype=torch.bfloat16), torch.empty(2, 6, device=dev)
+    io.tokens[("cross_attention_block", "clip_text_embedding")] = (torch.zeros(256, 2048, device=dev, dtype=torch.bfloat16), 77)
+    io.tokens[("ip_adapter", "clip_image_embedding")] = (torch.zeros(128, 2048, device=dev, dtype=torch.bfloat16), 4)
+    low = UNetLowering(dev, torch.bfloat16, None, "merged")
+    low.lower(unet, io)
+    assert len(low.step) == 981 and low.stats["lora_sites"] == 722 and low.stats["ip_sites"] == 70
+
+
 def test_sd1_tree_lowers_with_torch_sdpa_for_its_head_dims():
     low = _dry(SD1UNet(4, device="meta"), 1, 32, 32, torch.float32, {("cross_attention_block", "clip_text_embedding"): (77, 768)}, pooled=False)
     assert Counter(low.stats["fallback_nodes"]) == Counter({"SDPA(head_dim=40)": 10, "SDPA(head_dim=80)": 10, "SDPA(head_dim=160)": 12})
