@@ -198,3 +198,47 @@ def test_merged_lora_mode_matches_reference(case):
         ref = O.sdxl_unet(S.weights("sdxl", 0), torch.cat((cpu["x"], cpu["x"])), ts[cfg["step"]].unsqueeze(0), cpu["text"], cpu["pooled"], cpu["time_ids"])
         l2, mx = S.rel_err(y0, ref)  # ... but all scales at zero == the bare model on these inputs
         assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+
+
+def test_sampling_loop_and_batch_invariance():
+    """Ten consecutive DDIM steps (graph replay, latents resident on the GPU) against the unfused mirror looping on the
+    same GPU in float32, and batch invariance: image 0 of a 2-image batch equals the same image sampled alone
+    (reference tests/e2e/test_diffusion.py:1539-1597 holds itself to atol 5e-3; float32 here gives ~1e-6)."""
+    from refiners_amd.latent_diffusion.sampling import SDXLDenoiser
+
+    cfg, unet, specs, handles, inp1 = build("sdxl_bare", torch.float32)
+    inp2 = {k: v.cuda() for k, v in S.synth.sdxl_inputs(2, (32, 32), seed=11).items()}
+    steps = 10
+    sd = CompiledSDXL(unet, num_inference_steps=steps, condition_scale=5.0)
+    sd.set_inputs(inp2["x"], clip_text_embedding=inp2["text"], pooled_text_embedding=inp2["pooled"], time_ids=inp2["time_ids"])
+    fast2 = sd.sample().clone()
+    ref = SDXLDenoiser(unet, DDIM(steps, device="cuda"))
+    x = inp2["x"].clone()
+    with torch.no_grad():
+        for s in range(steps):
+            x = ref(x, s, clip_text_embedding=inp2["text"], pooled_text_embedding=inp2["pooled"], time_ids=inp2["time_ids"], condition_scale=5.0)
+    l2, mx = S.rel_err(fast2, x)
+    print(f"10-step trajectory f32: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    # the same first image alone: [neg_0, neg_1, cond_0, cond_1] -> [neg_0, cond_0]
+    pick = torch.tensor([0, 2], device="cuda")
+    sd1 = CompiledSDXL(unet, num_inference_steps=steps, condition_scale=5.0)
+    sd1.set_inputs(inp2["x"][:1], clip_text_embedding=inp2["text"][pick], pooled_text_embedding=inp2["pooled"][pick], time_ids=inp2["time_ids"][pick])
+    alone = sd1.sample()
+    l2, mx = S.rel_err(alone, fast2[:1])
+    print(f"batch invariance f32: l2 {l2:.2e} max {mx:.2e}")
+    assert mx < 5e-3, (l2, mx)
+
+
+def test_control_lora_through_the_step_api():
+    """ControlLora condition image passed through CompiledSDXL.set_inputs (config 4's adapter), float32 vs the golden step."""
+    case = "sdxl_control"
+    cfg, unet, specs, handles, inp = build(case, torch.float32)
+    sd = CompiledSDXL(unet, num_inference_steps=cfg["num_steps"], condition_scale=cfg["condition_scale"])
+    ctl = specs["control"][0]
+    sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"],
+                  conditions={ctl["name"]: ctl["condition"].cuda()})
+    x1 = sd.step(cfg["step"])
+    l2, mx = S.rel_err(x1, S.golden(case)["x_next"])
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    assert sd.engine.stats["fallback_nodes"] == []  # the ConditionEncoder runs on the native kernels too
