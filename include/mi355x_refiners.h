@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 1
+#define MI355X_ABI_VERSION 2
 
 enum { MI355X_F32 = 0, MI355X_BF16 = 1 };
 
@@ -66,6 +66,7 @@ int mi355x_device_info(char* buf, int32_t buflen);
  *               nearest-upsampled by `ups`; K_s = ksize*ksize*k ordered (ky, kx, channel); W_s rows are [N][K_s].
  * Weight rows W_s[n] must be "N-packed" by the caller exactly as refiners_amd.native.pack does (identity order
  * unless geglu, where value/gate rows are interleaved in groups of 32 so that one lane holds both).
+ * Long-K / small-MN problems (the 32x32-resolution convolutions: 320 tiles, K = 11520) can be split along K (`ksplit`).
  * Epilogue order: + bias[n] ; + rowbias[(m / rows_per_group)*ld_rowbias + n] ; geglu: v = a * gelu_erf(g) ;
  * + res[m*ldres + n] ; convert to dtype ; store out[m*ldo + n].
  */
@@ -100,6 +101,12 @@ typedef struct {
     const void* res;        /* [M][ldres] or NULL */
     int64_t ldres;
     const void* zeros;      /* >= 256 zero bytes in device memory; required when conv == 1 */
+    int32_t tile;           /* 0 = let the library choose; 1: 128x128  2: 128x64  3: 64x128  4: 64x64  5: 256x128 (M x N) */
+    int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
+                               partial sums into `ws`, a second launch adds them in a fixed order (deterministic) and
+                               applies the epilogue.  Not combinable with geglu. */
+    void* ws;               /* split-K scratch, >= ksplit * M * N * 4 bytes, 16-byte aligned (ignored unless ksplit > 1) */
+    int64_t ws_bytes;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

@@ -43,6 +43,9 @@ struct GemmP {
     int64_t ldres;  // elements
     const char* zeros;
     int tiles_m, tiles_n;
+    int ksplit, kb_per_split, grid0;  // split-K: ksplit workgroups per tile, each accumulating kb_per_split K blocks
+    float* partial;                   // [ksplit][M][N] float32 partial sums (split-K only)
+    int tile_hint;                    // 0 = heuristic, 1..5 = caller's choice
     int pn, hm, hn;  // XCD rasterisation: the 8 XCDs own a pm x pn grid of hm x hn-tile regions
     int vec_ok;
 };
@@ -64,10 +67,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int wm = wid / WN, wn = wid % WN;
     // XCD-aware rasterisation: workgroup b runs on XCD b % 8 (observed dispatch rule, a speed assumption only); each XCD
     // owns one rectangular region of the tile grid so that its private L2 sees as few distinct operand rows as possible.
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int rm = xcd / p.pn, rn = xcd - rm * p.pn;
-    const int lm = idx / p.hn, ln = idx - lm * p.hn;
-    const int tm = rm * p.hm + lm, tn = rn * p.hn + ln;
+    const int split = p.ksplit > 1 ? blockIdx.x / p.grid0 : 0;
+    const int bx = blockIdx.x - split * p.grid0;
+    int tm, tn;
+    if (p.pn > 0) {  // rectangular regions (exact split of the tile grid, grid0 = 8 * hm * hn)
+        const int xcd = bx & 7, idx = bx >> 3;
+        const int rm = xcd / p.pn, rn = xcd - rm * p.pn;
+        const int lm = idx / p.hn, ln = idx - lm * p.hn;
+        tm = rm * p.hm + lm;
+        tn = rn * p.hn + ln;
+    } else {  // contiguous chunk of the row-major (pn == 0) or column-major (pn == -1) tile order per XCD, balanced to +-1 tile
+        const int id = xcd_remap(bx, p.grid0);
+        if (p.pn == 0) {
+            tm = id / p.tiles_n;
+            tn = id - tm * p.tiles_n;
+        } else {
+            tn = id / p.tiles_m;
+            tm = id - tn * p.tiles_m;
+        }
+    }
     if (tm >= p.tiles_m || tn >= p.tiles_n) return;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -111,6 +129,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     int seg = 0, kb = 0;  // kb = block index inside the current segment
     int total_kb = 0;
     for (int s = 0; s < p.nseg; ++s) total_kb += p.seg[s].nkb;
+    if (p.ksplit > 1) {  // this workgroup's share of the K blocks: [first, first + total_kb)
+        const int first = split * p.kb_per_split;
+        total_kb = min(p.kb_per_split, total_kb - first);
+        kb = first;
+        while (seg < p.nseg - 1 && kb >= p.seg[seg].nkb) {
+            kb -= p.seg[seg].nkb;
+            ++seg;
+        }
+    }
 
     auto issue = [&](int buf) {
         const SegP& sp = p.seg[seg];
@@ -208,6 +235,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int nl = wn * WNE + RUN * g;
     const int n = n0 + nl;
     const bool full = p.vec_ok && (n + RUN <= p.N);
+    if (p.ksplit > 1) {  // split-K: raw float32 partial sums; bias / residual / conversion happen in splitk_reduce_kernel
+        float* part = p.partial + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * 16 * MT + 16 * i + c16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int nn = n + 4 * j;
+                if (nn + 4 <= p.N) *reinterpret_cast<f32x4*>(part + (int64_t)m * p.N + nn) = acc[i][j];
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nn + r < p.N) part[(int64_t)m * p.N + nn + r] = acc[i][j][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + wm * 16 * MT + 16 * i + c16;
@@ -296,6 +341,42 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     }
 }
 
+// out[m][n] = dtype( sum_s partial[s][m][n] (fixed order) + bias[n] + rowbias[m / rpg][n] + res[m][n] ): 4 columns per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
+    const int nq = (p.N + 3) / 4;
+    const int64_t total = (int64_t)p.M * nq;
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const T* rowbias = reinterpret_cast<const T*>(p.rowbias);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int m = (int)(q / nq);
+        const int n = (int)(q - (int64_t)m * nq) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full4 = n + 4 <= p.N;
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float* pp = p.partial + ((int64_t)s * p.M + m) * p.N + n;
+            if (full4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(pp);
+                v[0] += t[0], v[1] += t[1], v[2] += t[2], v[3] += t[3];
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) v[r] += pp[r];
+            }
+        }
+        for (int r = 0; r < 4; ++r) {
+            const int nn = n + r;
+            if (nn >= p.N) break;
+            float val = v[r];
+            if (bias) val += to_f32(bias[nn]);
+            if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
+            if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
+            out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int ABL = 0>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
     constexpr int LDS = NSTAGE * (BM + BN) * 128;
@@ -308,28 +389,44 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     GemmP q = p;
     q.tiles_n = (p.N + BN - 1) / BN;
     q.tiles_m = (p.M + BM - 1) / BM;
-    // split the 8 XCDs pm x pn so that the operand bytes pulled into the L2s, pn * |X| + pm * |W| ~ pn * M + pm * N, is
-    // smallest among the splits that leave no XCD idle
-    int best_pm = 8, best_pn = 1;
-    double best = 1e300;
-    for (int pm = 1; pm <= 8; pm *= 2) {
+    // How the 8 XCDs (private L2 each) share the tile grid.  Bytes pulled into the L2s ~ nx * |X| + nw * |W| where nx / nw =
+    // number of XCDs that touch each activation row / weight row; |X|, |W| in K-elements per row (a 3x3 conv reads every
+    // activation row through 9 taps but it is ONE row in L2).  Candidates: exact pm x pn rectangles, or balanced contiguous
+    // chunks of the row-major (nx = 1, nw = 8) / column-major (nx = 8, nw = 1) order.
+    double kx = 0, kw = 0;
+    for (int sgi = 0; sgi < p.nseg; ++sgi) {
+        const SegP& sg = p.seg[sgi];
+        kw += sg.nkb;
+        kx += CONV ? (double)sg.nkb / (sg.ksize * sg.ksize) : (double)sg.nkb;
+    }
+    const double bx_ = (double)p.M * kx, bw_ = (double)p.N * kw;
+    double best = bx_ + 8.0 * bw_;  // row-major chunks
+    q.pn = 0;
+    q.hm = q.hn = 0;
+    if (8.0 * bx_ + bw_ < best) {
+        best = 8.0 * bx_ + bw_;
+        q.pn = -1;
+    }
+    for (int pm = 2; pm <= 4; pm *= 2) {
         const int pn = 8 / pm;
-        if (pm > q.tiles_m && pm > 1) continue;
-        if (pn > q.tiles_n && pn > 1) continue;
-        const int hm = (q.tiles_m + pm - 1) / pm, hn = (q.tiles_n + pn - 1) / pn;
-        const double waste = (double)(hm * pm) * (hn * pn) / ((double)q.tiles_m * q.tiles_n);  // padding blocks exit at once
-        const double cost = ((double)pn * p.M + (double)pm * p.N) * (0.75 + 0.25 * waste);
+        if (q.tiles_m % pm || q.tiles_n % pn) continue;
+        const double cost = pn * bx_ + pm * bw_;
         if (cost < best) {
             best = cost;
-            best_pm = pm;
-            best_pn = pn;
+            q.pn = pn;
+            q.hm = q.tiles_m / pm;
+            q.hn = q.tiles_n / pn;
         }
     }
-    q.pn = best_pn;
-    q.hm = (q.tiles_m + best_pm - 1) / best_pm;
-    q.hn = (q.tiles_n + best_pn - 1) / best_pn;
-    const int grid = 8 * q.hm * q.hn;
+    q.grid0 = q.tiles_m * q.tiles_n;
+    const int grid = q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64), LDS, stream, q);
+    if (q.ksplit > 1) {
+        const int64_t work = (int64_t)q.M * ((q.N + 3) / 4);
+        int64_t rb = (work + 255) / 256;
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((int)rb), dim3(256), 0, stream, q);
+    }
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
 
@@ -342,6 +439,7 @@ int g_stages = 0;  // 0 = heuristic, 2..4 = force the LDS pipeline depth
 inline int pick_tile(const GemmP& p, bool conv) {
     // measured on MI355X over the UNet's shapes (tools/probe_gemm.py, profiles/r01_b_probe_gemm_tiles.log)
     if (g_tile >= 1 && g_tile <= 5) return g_tile;
+    if (p.tile_hint >= 1 && p.tile_hint <= 5) return p.tile_hint;
     const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (conv) return 3;  // 64 x 128 wins for every conv shape of the UNet (r01_b probe: 339 / 540 / 570 TF at 32^2 / 64^2 / 128^2)
     if (p.geglu) return 1;
@@ -484,6 +582,22 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     if (a->res) vec = vec && aligned16(a->res) && (a->ldres * es) % 16 == 0;
     p.vec_ok = vec ? 1 : 0;
     if (p.geglu && (!vec || a->N % 64)) return MI355X_ESHAPE;
+    p.tile_hint = a->tile;
+    p.ksplit = 1;
+    p.partial = nullptr;
+    if (a->ksplit > 1) {
+        int total_kb = 0;
+        for (int s = 0; s < a->nseg; ++s) total_kb += p.seg[s].nkb;
+        if (p.geglu || !a->ws || (reinterpret_cast<uintptr_t>(a->ws) & 15)) return MI355X_EARG;
+        const int kbps = (total_kb + a->ksplit - 1) / a->ksplit;
+        const int ks = (total_kb + kbps - 1) / kbps;  // no empty split
+        if ((int64_t)ks * a->M * a->N * 4 > a->ws_bytes) return MI355X_EARG;
+        if (ks > 1) {
+            p.ksplit = ks;
+            p.kb_per_split = kbps;
+            p.partial = static_cast<float*>(a->ws);
+        }
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (a->dtype == MI355X_F32) return launch_t<float>(p, a->conv != 0, st);
     return launch_t<bf16_t>(p, a->conv != 0, st);

@@ -442,9 +442,26 @@ class Lowering:
             _expect(sspec.lora is None and sspec.ksize == 1 and sspec.stride == 1, "unsupported shortcut convolution")
             segs.append((sa.image(), sspec.w, 1, 1, 1))
         _expect(len(segs) <= native.MAX_SEG, "too many K segments for one conv launch")
-        native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res)
+        # few output tiles but a very long K (the 32 x 32-resolution convolutions of a CFG pair: 160 tiles, K = 11 520):
+        # split K three ways over 128 x 128 tiles (measured 169 -> 108 us, profiles/r01_h_probe_splitk.log); the float32
+        # partials are summed in a fixed order by a second launch, so the result stays bit-reproducible.
+        M_out = a.B * OH * OW
+        tiles128 = ((M_out + 127) // 128) * ((spec.cout + 127) // 128)
+        total_kb = sum(w.shape[1] for _, w, _, _, _ in segs) * self.es // 128
+        tile, ksplit, ws = 0, 1, None
+        if tiles128 <= 192 and total_kb >= 96:
+            tile, ksplit = 1, 3
+            ws = self.splitk_workspace(ksplit * M_out * spec.cout)
+        native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res, tile=tile, ksplit=ksplit, ws=ws)
         self.pool.put(t)
         return Act(out, a.B, OH, OW)
+
+    def splitk_workspace(self, floats: int) -> Tensor:
+        """One float32 scratch per size class, shared by every split-K launch of the (sequential) program."""
+        store = self.__dict__.setdefault("_splitk_ws", {})
+        if floats not in store:
+            store[floats] = torch.empty(floats, device=self.device, dtype=torch.float32)
+        return store[floats]
 
     # -- emitters: norms / glue ------------------------------------------------------------------------------
     def groupnorm(self, a: Act, gn: Any, silu: bool) -> Act:

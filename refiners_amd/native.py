@@ -63,6 +63,10 @@ class GemmArgs(C.Structure):
         ("res", C.c_void_p),
         ("ldres", C.c_int64),
         ("zeros", C.c_void_p),
+        ("tile", C.c_int32),
+        ("ksplit", C.c_int32),
+        ("ws", C.c_void_p),
+        ("ws_bytes", C.c_int64),
     ]
 
 
@@ -187,7 +191,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_sinusoidal.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
-    if lib.mi355x_abi_version() != 1:
+    if lib.mi355x_abi_version() != 2:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
     return lib
@@ -333,6 +337,9 @@ def gemm(
     geglu: bool = False,
     M: Optional[int] = None,
     N: Optional[int] = None,
+    tile: int = 0,
+    ksplit: int = 1,
+    ws: Optional[Tensor] = None,
 ) -> Tensor:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s])."""
     a = GemmArgs()
@@ -350,6 +357,7 @@ def gemm(
         sg.ksize, sg.stride, sg.ups, sg.H, sg.W = 1, 1, 1, 0, 0
         keep.append((x, w))
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, geglu)
+    _fill_split(a, tile, ksplit, ws)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm")
     return out
 
@@ -365,6 +373,9 @@ def conv_gemm(
     rowbias: Optional[Tensor] = None,
     rows_per_group: int = 1,
     res: Optional[Tensor] = None,
+    tile: int = 0,
+    ksplit: int = 1,
+    ws: Optional[Tensor] = None,
 ) -> Tensor:
     """Implicit-GEMM convolution over NHWC images.
 
@@ -389,8 +400,18 @@ def conv_gemm(
         sg.ksize, sg.stride, sg.ups, sg.H, sg.W = ksize, stride, ups, h, wd
     a.zeros = zero_page(img0.device).data_ptr()
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, False)
+    _fill_split(a, tile, ksplit, ws)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm(conv)")
     return out
+
+
+def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor]) -> None:
+    a.tile, a.ksplit = tile, ksplit
+    if ksplit > 1:
+        assert ws is not None and ws.is_contiguous(), "split-K needs a scratch tensor of ksplit * M * N float32"
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    else:
+        a.ws, a.ws_bytes = None, 0
 
 
 def _fill_epilogue(a: GemmArgs, out: Tensor, bias, rowbias, rows_per_group, res, geglu) -> None:

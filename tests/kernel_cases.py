@@ -53,6 +53,36 @@ def gemm_case(M, K, N, dtype, *, bias=False, res=False, rowbias=0, seed=0):
     return _cmp(out, ref, dtype)
 
 
+def gemm_splitk_case(M, K, N, dtype, ksplit, tile=0, seed=5):
+    """Split-K: ksplit workgroups per tile + deterministic float32 reduction with the full epilogue (bias, residual)."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2)
+    r = _rand(M, N, dtype=dtype, seed=seed + 3)
+    ws = torch.empty(ksplit * M * N, dtype=torch.float32, device=DEV)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, w)], out, bias=b, res=r, tile=tile, ksplit=ksplit, ws=ws)
+    out2 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, w)], out2, bias=b, res=r, tile=tile, ksplit=ksplit, ws=ws)
+    assert torch.equal(out, out2), "split-K must be bit-reproducible"
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    return _cmp(out, ref, dtype)
+
+
+def conv_splitk_case(B, Cin, Cout, H, W, dtype, ksplit, seed=55):
+    x = _rand(B, Cin, H, W, dtype=dtype, seed=seed)
+    w = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=(Cin * 9) ** -0.5)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2)
+    rb = _rand(B, Cout, dtype=dtype, seed=seed + 3)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + rb.float()[:, :, None, None]
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    out = torch.empty(B * H * W, Cout, dtype=dtype, device=DEV)
+    ws = torch.empty(ksplit * B * H * W * Cout, dtype=torch.float32, device=DEV)
+    native.conv_gemm([(x_nhwc, native.pack_conv_weight(w), 3, 1, 1)], out, B, H, W, bias=b, rowbias=rb, rows_per_group=H * W, ksplit=ksplit, ws=ws)
+    got = out.float().reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+    return _cmp(got, ref, dtype)
+
+
 def gemm_lora_case(M, K, N, dtype, ranks=(16, 16), seed=10):
     """y = x W^T + b + sum_i s_i (x A_i^T) B_i^T as ONE fused launch after the skinny down-projection launch."""
     x = _rand(M, K, dtype=dtype, seed=seed)
@@ -283,6 +313,11 @@ def all_cases():
             (f"gemm_{tag}_300x640x200_Nedge", lambda dt=dt: gemm_case(300, 640, 200, dt, bias=True, res=True)),
             (f"gemm_{tag}_2x1280x320_rowbiasless", lambda dt=dt: gemm_case(2, 1280, 320, dt, bias=True)),
             (f"gemm_{tag}_512x640x640_rowbias", lambda dt=dt: gemm_case(512, 640, 640, dt, bias=True, rowbias=256)),
+            (f"gemm_{tag}_splitk2_512x1280x384", lambda dt=dt: gemm_splitk_case(512, 1280, 384, dt, 2)),
+            (f"gemm_{tag}_splitk3_300x1920x200_edges", lambda dt=dt: gemm_splitk_case(300, 1920, 200, dt, 3, tile=1)),
+            (f"gemm_{tag}_splitk4_tile2", lambda dt=dt: gemm_splitk_case(1024, 2560, 640, dt, 4, tile=2)),
+            (f"conv_{tag}_3x3_splitk2", lambda dt=dt: conv_splitk_case(2, 640, 384, 16, 16, dt, 2)),
+            (f"conv_{tag}_3x3_splitk3", lambda dt=dt: conv_splitk_case(1, 320, 320, 32, 32, dt, 3)),
             (f"gemm_{tag}_lora_2048x640x640", lambda dt=dt: gemm_lora_case(2048, 640, 640, dt)),
             (f"gemm_{tag}_lora_154x2048x1280", lambda dt=dt: gemm_lora_case(154, 2048, 1280, dt)),
             (f"gemm_{tag}_geglu_1024x640x2560", lambda dt=dt: gemm_geglu_case(1024, 640, 2560, dt)),

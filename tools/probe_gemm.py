@@ -59,6 +59,31 @@ def main():
         tt = min(timeit(lambda: torch.matmul(x, w.t())) for _ in range(3))
         print(f"   torch(hipBLASLt): {tt*1e6:8.1f} us {2*M*K*N/tt/1e12:7.1f} TF", flush=True)
         rows.append(dict(kind="torch", M=M, K=K, N=N, us=tt * 1e6, tflops=2 * M * K * N / tt / 1e12))
+    # split-K candidates: long K, few tiles
+    for (M, K, N) in ((2048, 5120, 1280), (2048, 1280, 1280), (8192, 2560, 640)):
+        x = torch.randn(M, K, device=dev).to(dt)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
+        o = torch.empty(M, N, device=dev, dtype=dt)
+        ws = torch.empty(4 * M * N, device=dev, dtype=torch.float32)
+        for tile in (1, 2, 4):
+            line = f"splitk gemm M={M} K={K} N={N} tile={tile}:"
+            for ks in (1, 2, 3, 4):
+                set_tile(0, 2)
+                t = min(timeit(lambda: native.gemm([(x, w)], o, tile=tile, ksplit=ks, ws=ws)) for _ in range(3))
+                line += f"  k{ks}: {t*1e6:7.1f} us {2*M*K*N/t/1e12:6.1f} TF"
+            print(line, flush=True)
+    for (B, C, Co, H) in ((2, 1280, 1280, 32), (2, 2560, 1280, 32), (2, 640, 640, 64)):
+        x = torch.randn(B, H, H, C, device=dev).to(dt)
+        w = (torch.randn(Co, 9 * C, device=dev) * (9 * C) ** -0.5).to(dt)
+        o = torch.empty(B * H * H, Co, device=dev, dtype=dt)
+        ws = torch.empty(4 * B * H * H * Co, device=dev, dtype=torch.float32)
+        for tile in (1, 3):
+            line = f"splitk conv C={C} Co={Co} H={H} tile={tile}:"
+            for ks in (1, 2, 3, 4):
+                set_tile(0, 2)
+                t = min(timeit(lambda: native.conv_gemm([(x, w, 3, 1, 1)], o, B, H, H, tile=tile, ksplit=ks, ws=ws), iters=10) for _ in range(3))
+                line += f"  k{ks}: {t*1e6:7.1f} us {2*B*H*H*9*C*Co/t/1e12:6.1f} TF"
+            print(line, flush=True)
     CONVS = [(2, 1280, 1280, 32), (2, 2560, 1280, 32), (2, 320, 320, 128), (2, 640, 640, 64), (2, 1920, 640, 64), (2, 960, 320, 128), (2, 640, 320, 128)]
     for (B, C, Co, H) in CONVS:
         x = torch.randn(B, H, H, C, device=dev).to(dt)
