@@ -67,3 +67,15 @@ def build_specs(cfg: Mapping[str, Any], shapes: Mapping[str, Sequence[int]]) -> 
             own = synth.lora_spec(shapes, f"ctl_{rest[0]}", 1.0, rank=8, seed=seed + 1, targets=control_lora_targets(shapes))
             control.append(synth.control_spec(rest[0], float(rest[1]), batch, cfg["latent_hw"], seed=seed, loras=[own]))
     return {"loras": loras, "ip": ip, "control": control}
+
+
+# ------------------------------------------------------------------------------------------------ config 5: SAM ViT-H
+SAM_CASE = dict(weight_seed=0, input_seed=9)
+
+
+def sam_sample(neck_out, early):
+    """Strided samples + statistics of the image encoder's two outputs (what tests/golden/sam_vit_h.safetensors stores)."""
+    import torch
+
+    stats = torch.tensor([neck_out.mean(), neck_out.abs().mean(), neck_out.std(), early.mean(), early.abs().mean(), early.std()], dtype=torch.float64)
+    return {"neck": neck_out[:, :, ::4, ::4].float().clone(), "early": early[:, ::8, ::8, ::8].float().clone(), "stats": stats.float()}
