@@ -68,6 +68,7 @@ int mi355x_device_info(char* buf, int32_t buflen);
  * unless geglu, where value/gate rows are interleaved in groups of 32 so that one lane holds both).
  * Long-K / small-MN problems (the 32x32-resolution convolutions: 320 tiles, K = 11520) can be split along K (`ksplit`).
  * Epilogue order: + bias[n] ; + rowbias[(m / rows_per_group)*ld_rowbias + n] ; geglu: v = a * gelu_erf(g) ;
+ * (or v = gelu_erf(v) when geglu == 2: fl.GeLU, src/refiners/fluxion/layers/activations.py:83-125) ;
  * + res[m*ldres + n] ; convert to dtype ; store out[m*ldo + n].
  */
 #define MI355X_MAX_SEG 3
@@ -97,7 +98,7 @@ typedef struct {
     const void* rowbias;    /* [M / rows_per_group][ld_rowbias] or NULL (RangeAdapter2d time-embedding bias) */
     int64_t ld_rowbias;
     int32_t rows_per_group;
-    int32_t geglu;          /* 0 / 1 */
+    int32_t geglu;          /* epilogue activation: 0 none, 1 GEGLU (value * gelu_erf(gate), packed rows), 2 gelu_erf on every column */
     const void* res;        /* [M][ldres] or NULL */
     int64_t ldres;
     const void* zeros;      /* >= 256 zero bytes in device memory; required when conv == 1 */
@@ -203,6 +204,12 @@ int mi355x_nhwc_to_nchw(int32_t dtype, const void* x, void* out, int32_t B, int3
 /* im2col of a small-channel NCHW image for the UNet's first 3x3 conv (src/refiners/foundationals/latent_diffusion/
  * stable_diffusion_xl/unet.py:118-121): out[M = B*H*W][ldo], column (ky*3+kx)*C + c, zero elsewhere up to ldo. */
 int mi355x_im2col3x3_nchw(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, int64_t ldo, void* stream);
+/* Non-overlapping P x P patches of an NCHW image as GEMM rows (SAM's PatchEncoder convolution, src/refiners/foundationals/
+ * segment_anything/image_encoder.py:8-44): out[(b, py, px)][c*P*P + ky*P + kx] = x[b][c][py*P + ky][px*P + kx]. */
+int mi355x_patchify_nchw(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t P, int64_t ldo, void* stream);
+/* out[i][0:C] = idx[i] >= 0 ? x[idx[i]][0:C] : 0   (row gather with zero fill: WindowPartition / WindowMerge of
+ * segment_anything/image_encoder.py:202-236 as static index tables).  C * sizeof(dtype) must be a multiple of 16. */
+int mi355x_gather_rows(int32_t dtype, const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int64_t n_rows, int32_t C, void* stream);
 /* out[m][0:C1] = a[m][0:C1]; out[m][C1:C1+C2] = b[m][0:C2]   (ResidualConcatenator, unet.py:69-79, NHWC). */
 int mi355x_concat2(int32_t dtype, const void* a, int64_t lda, int32_t C1, const void* b, int64_t ldb, int32_t C2,
                    void* out, int64_t ldo, int64_t M, void* stream);

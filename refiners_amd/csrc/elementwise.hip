@@ -139,6 +139,37 @@ __global__ __launch_bounds__(256) void sinusoidal_kernel(const float* __restrict
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int C, int H, int W, int P, int64_t ldo) {
+    const int GH = H / P, GW = W / P, K = C * P * P;
+    const int64_t total = (int64_t)B * GH * GW * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % K);
+        const int64_t m = i / K;
+        const int kx = col % P, ky = (col / P) % P, c = col / (P * P);
+        const int px = (int)(m % GW), py = (int)((m / GW) % GH), b = (int)(m / ((int64_t)GW * GH));
+        out[m * ldo + col] = x[(((int64_t)b * C + c) * H + py * P + ky) * W + px * P + kx];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ x, int64_t ldx, const int* __restrict__ idx, T* __restrict__ out,
+                                                           int64_t ldo, int64_t n_rows, int NV) {
+    constexpr int EPC = DT<T>::EPC;
+    const int64_t total = n_rows * NV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / NV;
+        const int v = (int)(i - r * NV);
+        const int src = idx[r];
+        Vec16<T> t;
+        if (src >= 0) t = load16<T>(x + (int64_t)src * ldx + v * EPC);
+        else
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) t.set(e, 0.f);
+        store16<T>(out + r * ldo + v * EPC, t);
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL)                          \
@@ -240,5 +271,26 @@ extern "C" int mi355x_sinusoidal(int32_t dtype, const float* x, int64_t n, int32
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = grid_for(n * (dim / 2));
     DISPATCH_T(dtype, hipLaunchKernelGGL((sinusoidal_kernel<T>), dim3(grid), dim3(256), 0, st, x, n, (int)dim, (int)group, static_cast<T*>(out), ldo, (int)col0));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_patchify_nchw(int32_t dtype, const void* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t P, int64_t ldo,
+                                    void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || P <= 0 || H % P || W % P) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((int64_t)B * (H / P) * (W / P) * C * P * P);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((patchify_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), static_cast<T*>(out), B, C, H, W, P, ldo));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_gather_rows(int32_t dtype, const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int64_t n_rows, int32_t C,
+                                  void* stream) {
+    if (!x || !idx || !out || n_rows <= 0 || C <= 0) return MI355X_EARG;
+    const int es = dtype == MI355X_F32 ? 4 : 2;
+    if ((C * es) % 16 || (ldx * es) % 16 || (ldo * es) % 16 || !al16(x) || !al16(out)) return MI355X_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nv = C * es / 16;
+    const int grid = grid_for(n_rows * nv);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), ldx, idx, static_cast<T*>(out), ldo, n_rows, nv));
     return LAUNCH_OK();
 }

@@ -392,7 +392,7 @@ class Lowering:
         return t
 
     def linear(self, x: Tensor, spec: LinSpec, *, res: Optional[Tensor] = None, out: Optional[Tensor] = None,
-               rows: Optional[int] = None, lora_t: Optional[Tensor] = None) -> Tensor:
+               rows: Optional[int] = None, lora_t: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
         """out[M, N(/2 if geglu)] = epi(x W^T + b (+ LoRA) (+ res)).  `lora_t` lets callers share one down-projection
         launch between Linears that read the same x."""
         M = x.shape[0]
@@ -404,7 +404,7 @@ class Lowering:
         if spec.lora is not None:
             t = lora_t if lora_t is not None else self.lora_down(x, spec.lora)
             segs.append((t, spec.lora.bs_cat))
-        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu)
+        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu)
         if t is not None and lora_t is None:
             self.pool.put(t)
         return out

@@ -153,6 +153,8 @@ EXPORTS = [
     "mi355x_silu",
     "mi355x_cfg_ddim_step",
     "mi355x_sinusoidal",
+    "mi355x_patchify_nchw",
+    "mi355x_gather_rows",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -189,6 +191,8 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_silu.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_cfg_ddim_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_sinusoidal.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    lib.mi355x_patchify_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    lib.mi355x_gather_rows.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     if lib.mi355x_abi_version() != 2:
@@ -335,6 +339,7 @@ def gemm(
     rows_per_group: int = 1,
     res: Optional[Tensor] = None,
     geglu: bool = False,
+    gelu: bool = False,
     M: Optional[int] = None,
     N: Optional[int] = None,
     tile: int = 0,
@@ -356,7 +361,8 @@ def gemm(
         sg.x, sg.ldx, sg.w, sg.ldw, sg.k = t[0].data_ptr(), t[1], t[2].data_ptr(), t[3], t[4]
         sg.ksize, sg.stride, sg.ups, sg.H, sg.W = 1, 1, 1, 0, 0
         keep.append((x, w))
-    _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, geglu)
+    assert not (geglu and gelu)
+    _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, 2 if gelu else geglu)
     _fill_split(a, tile, ksplit, ws)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm")
     return out
@@ -428,7 +434,7 @@ def _fill_epilogue(a: GemmArgs, out: Tensor, bias, rowbias, rows_per_group, res,
         a.res, a.ldres = res.data_ptr(), res.stride(0)
     else:
         a.res, a.ldres = None, 0
-    a.geglu = 1 if geglu else 0
+    a.geglu = int(geglu)  # 0 none, 1 GEGLU, 2 GELU
 
 
 def attention(
@@ -550,6 +556,23 @@ def sinusoidal(x: Tensor, dim: int, out: Tensor, group: int = 1, col0: int = 0) 
     assert x.dtype == torch.float32 and x.is_contiguous() and out.dim() == 2 and out.stride(1) == 1
     assert x.numel() % group == 0 and out.shape[0] >= x.numel() // group and out.shape[1] >= col0 + group * dim
     _launch("mi355x_sinusoidal", (dtype_code(out.dtype), x.data_ptr(), x.numel(), dim, group, out.data_ptr(), out.stride(0), col0), "mi355x_sinusoidal")
+    return out
+
+
+def patchify_nchw(x: Tensor, patch: int, out: Tensor) -> Tensor:
+    """x: [B, C, H, W] contiguous; out: [B * (H/P) * (W/P), >= C*P*P] rows."""
+    B, Cc, H, W = x.shape
+    assert x.is_contiguous() and out.dim() == 2 and out.stride(1) == 1 and out.shape[1] >= Cc * patch * patch
+    _launch("mi355x_patchify_nchw", (dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), B, Cc, H, W, patch, out.stride(0)), "mi355x_patchify_nchw")
+    return out
+
+
+def gather_rows(x: Tensor, idx: Tensor, out: Tensor) -> Tensor:
+    """out[i] = x[idx[i]] (zero row where idx[i] < 0); x, out: 2-D with unit column stride; idx: int32 on the device."""
+    assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1 and x.shape[1] == out.shape[1]
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == out.shape[0]
+    _launch("mi355x_gather_rows", (dtype_code(x.dtype), x.data_ptr(), x.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), out.shape[0], x.shape[1]),
+            "mi355x_gather_rows", keep=(idx,))
     return out
 
 

@@ -287,6 +287,33 @@ def cfg_ddim_case(n, dtype, seed=120):
     return _cmp(x, ref, dtype)
 
 
+def gemm_gelu_case(M, K, N, dtype, seed=35):
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2)
+    r = _rand(M, N, dtype=dtype, seed=seed + 3)
+    out = torch.empty(M, N, dtype=dtype, device=DEV)
+    native.gemm([(x, w)], out, bias=b, res=r, gelu=True)
+    ref = F.gelu(x.float() @ w.float().t() + b.float(), approximate="none") + r.float()
+    return _cmp(out, ref, dtype)
+
+
+def patchify_gather_case(dtype, seed=140):
+    x = _rand(2, 3, 64, 48, dtype=dtype, seed=seed)
+    P = 16
+    cols = torch.empty(2 * 4 * 3, 3 * P * P, dtype=dtype, device=DEV)
+    native.patchify_nchw(x, P, cols)
+    ref = F.unfold(x.float(), kernel_size=P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)
+    e1 = (cols.float() - ref).abs().max().item()
+    src = _rand(50, 64, dtype=dtype, seed=seed + 1)
+    idx = torch.tensor([3, -1, 49, 0, 7, -1, 7], dtype=torch.int32, device=DEV)
+    out = torch.full((7, 64), float("nan"), dtype=dtype, device=DEV)
+    native.gather_rows(src, idx, out)
+    want = torch.where(idx[:, None] >= 0, src[idx.clamp(min=0).long()], torch.zeros_like(src[:7]))
+    e2 = (out.float() - want.float()).abs().max().item()
+    return max(e1, e2), 1.0, 0.0
+
+
 def sinusoidal_case(n, dim, group, dtype, seed=130):
     x = (torch.rand(n, generator=torch.Generator().manual_seed(seed)) * 1000).to(DEV)
     half = dim // 2
@@ -344,6 +371,9 @@ def all_cases():
             (f"layout_{tag}_320", lambda dt=dt: layout_case(1, 320, 16, 24, dt)),
             (f"concat_axpby_{tag}", lambda dt=dt: concat_axpby_case(1000, 640, 320, dt)),
             (f"cfg_ddim_{tag}", lambda dt=dt: cfg_ddim_case(4 * 128 * 128, dt)),
+            (f"gemm_{tag}_gelu_res_1000x640x384", lambda dt=dt: gemm_gelu_case(1000, 640, 384, dt)),
+            (f"gemm_{tag}_gelu_Nedge", lambda dt=dt: gemm_gelu_case(300, 640, 200, dt)),
+            (f"patchify_gather_{tag}", lambda dt=dt: patchify_gather_case(dt)),
             (f"sinusoidal_{tag}_timestep", lambda dt=dt: sinusoidal_case(2, 320, 1, dt)),
             (f"sinusoidal_{tag}_time_ids", lambda dt=dt: sinusoidal_case(12, 256, 6, dt)),
         ]

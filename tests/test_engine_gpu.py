@@ -242,3 +242,28 @@ def test_control_lora_through_the_step_api():
     l2, mx = S.rel_err(x1, S.golden(case)["x_next"])
     assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
     assert sd.engine.stats["fallback_nodes"] == []  # the ConditionEncoder runs on the native kernels too
+
+
+def test_sam_vit_h_float32_matches_reference():
+    """BASELINE.json config 5: SAM ViT-H image encoder with HQ-SAM's encoder hook, float32, vs the real reference's output."""
+    import json
+
+    from refiners_amd.engine.sam import CompiledSAMViT
+    from refiners_amd.segment_anything import SAMViTAdapter, SAMViTH
+    from tests.golden_cases import SAM_CASE, sam_sample
+
+    shapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "sam_vit_h_keys.json").read_text()).items()}
+    vit = SAMViTH(device="meta")
+    vit.load_state_dict({k: v.cuda() for k, v in S.synth.synth_state_dict(shapes, SAM_CASE["weight_seed"]).items()}, assign=True)
+    adapter = SAMViTAdapter(vit).inject()
+    adapter.set_context("hq_sam", {"early_vit_embedding": None})
+    image = torch.rand((1, 3, 1024, 1024), generator=S.synth._gen("sam.image", SAM_CASE["input_seed"])).cuda()
+    fast = CompiledSAMViT(vit)
+    neck = fast(image)
+    early = vit.layer(("Transformer", 7), torch.nn.Module).use_context("hq_sam")["early_vit_embedding"]
+    got, gold = sam_sample(neck.cpu(), early.cpu()), S.golden("sam_vit_h")
+    for k in ("neck", "early", "stats"):
+        l2, mx = S.rel_err(got[k], gold[k])
+        print(f"sam {k}: l2 {l2:.2e} max {mx:.2e}")
+        assert l2 < F32_TOL and mx < F32_TOL, (k, l2, mx)
+    print("sam launches", fast.stats["step_ops"], "fallbacks", len(fast.stats["fallback_nodes"]))
