@@ -96,7 +96,9 @@ class SAMLowering(Lowering):
         att = self.pool.get(qkv.shape[0], C)
         node = fsa[1]
 
-        def attend() -> None:  # the node's own torch forward (head_dim 80 + relative position bias: not covered by the flash kernel)
+        def attend(att: Tensor = att, qkv: Tensor = qkv, shape: tuple = shape, node: Any = node) -> None:
+            # the node's own torch forward (head_dim 80 + relative position bias: not covered by the flash kernel);
+            # arguments are bound NOW: `att` is rebound to the merged buffer a few lines below
             att.view(*shape, C).copy_(node(qkv.view(*shape, 3 * C)))
 
         self.python(attend, "torch:RelativePositionAttention")
@@ -120,7 +122,7 @@ class SAMLowering(Lowering):
         for extra in ch[2:]:
             _expect(isa(extra, "SetContext") and early is not None, f"unexpected {cname(extra)} at the end of a TransformerLayer")
             flat = early.view(M, C)
-            self.python(lambda: flat.copy_(tok), "copy:early_vit_embedding")
+            self.python(lambda flat=flat, tok=tok: flat.copy_(tok), "copy:early_vit_embedding")
         return tok
 
     def neck(self, neck: Any, tok: Tensor, B: int, gh: int, gw: int, out: Tensor) -> None:
