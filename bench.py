@@ -25,7 +25,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
-STEP_TFLOP = {"bare": 13.522, "lora_ip": 13.895}  # algorithmic FLOPs of one CFG-pair UNet forward
+STEP_TFLOP = {"bare": 13.522, "lora_ip": 13.895, "control": 19.563}  # algorithmic FLOPs of one CFG-pair UNet forward
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 LATENT = (128, 128)
 
@@ -100,7 +100,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["bare", "lora_ip"], default="bare")
+    ap.add_argument("--workload", choices=["bare", "lora_ip", "control"], default="bare",
+                    help="bare = BASELINE configs[1]; lora_ip = configs[2]; control = configs[3] (ControlLora canny; use --images-per-gpu 4 for its 32-prompt / 8-GPU shape)")
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -131,6 +132,9 @@ def main() -> None:
         specs = {"loras": [synth.lora_spec(shapes, "l1", 1.0, seed=5), synth.lora_spec(shapes, "l2", 0.8, seed=5)],
                  "ip": synth.ip_spec(shapes, 0.6, batch=2 * args.images_per_gpu, seed=5), "control": []}
         synth.apply_adapters(unet, refiners_amd.namespace(), device=dev, dtype=dtype, **specs)
+    if args.workload == "control":
+        specs = {"loras": [], "ip": None, "control": [synth.control_spec("canny", 1.0, 2 * args.images_per_gpu, LATENT, seed=5)]}
+        synth.apply_adapters(unet, refiners_amd.namespace(), device=dev, dtype=dtype, **specs)
     torch.cuda.synchronize()
     tb = time.time()
     n_bcast = parallel.broadcast_module(unet, src=0)
@@ -145,6 +149,8 @@ def main() -> None:
     kw = {}
     if specs["ip"] is not None:
         kw["clip_image_embedding"] = specs["ip"]["tokens"].to(dev)
+    if specs["control"]:
+        kw["conditions"] = {c["name"]: c["condition"].to(dev) for c in specs["control"]}
     pipe.set_inputs(inp["x"].to(dev), clip_text_embedding=inp["text"].to(dev), pooled_text_embedding=inp["pooled"].to(dev),
                     time_ids=inp["time_ids"].to(dev), **kw)
     for i in range(args.warmup):
@@ -223,8 +229,8 @@ def main() -> None:
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "SDXL-base UNet CFG step, 1024x1024 (latent 2x4x128x128, 77 text tokens), DDIM-50" +
-                   ("" if args.workload == "bare" else " + 2 LoRA r16 (722 Linears) + IP-Adapter"),
-                   "baseline_config": "configs[1]" if args.workload == "bare" else "configs[2]", "images_per_gpu": n_img,
+                   {"bare": "", "lora_ip": " + 2 LoRA r16 (722 Linears) + IP-Adapter", "control": " + ControlLora (canny)"}[args.workload],
+                   "baseline_config": {"bare": "configs[1]", "lora_ip": "configs[2]", "control": "configs[3]"}[args.workload], "images_per_gpu": n_img,
                    "parallelism": f"replica x{world} (independent prompts, weights broadcast once)", "hip_graph": not args.no_graph,
                    "lora_mode": args.lora_mode if args.workload != "bare" else None},
         "step_latency_ms": round(ms_per_step, 3),
