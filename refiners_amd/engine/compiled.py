@@ -130,10 +130,25 @@ class CompiledUNet:
         self.io.x.copy_(x)  # type: ignore[union-attr]
         return changed
 
+    def _tree_state(self) -> Any:
+        """What invalidates a lowered program.  Trees built from refiners_amd.fluxion bump a global epoch on every
+        structural change and scale assignment; trees built from refiners' own classes have no such counter, so their
+        state is a signature of the module identities and the live scales (a ~1 ms walk per call)."""
+        from ..fluxion.tree import Chain as MirrorChain
+
+        if isinstance(self.unet, MirrorChain):
+            return tree_epoch()
+        sig = []
+        for m in self.unet.modules():
+            sig.append(id(m))
+            if isa(m, "Multiply"):
+                sig.append(float(m.scale))
+        return hash(tuple(sig))
+
     def prepare_explicit(self, x_shape: tuple, device: torch.device, got: dict[str, Any]) -> bool:
         """Same, with the side inputs given explicitly: {"timestep", "pooled", "time_ids", "tokens": {(ctx, key): t},
         "conditions": {ctx_name: t}}.  Does not stage x (the caller fills io.x).  Returns True when the prologue must run."""
-        key = (tree_epoch(), tuple(x_shape), self.unet.dtype, tuple((k, tuple(v.shape)) for k, v in got["tokens"].items()),
+        key = (self._tree_state(), tuple(x_shape), self.unet.dtype, tuple((k, tuple(v.shape)) for k, v in got["tokens"].items()),
                tuple((k, tuple(v.shape)) for k, v in got["conditions"].items()), got["pooled"] is not None)
         if key != self.key:
             self._build(x_shape, device, got)
