@@ -224,6 +224,26 @@ def main() -> None:
                    "sample": "1 of the 50 DDIM steps of one 1024x1024 image (CFG pair), float32, oracle/unet_oracle.py; images/s extrapolated x50"}
             del sd_cpu
 
+    # ---- next-1 (outside the metric): VAE decode of the finished latents, for an end-to-end images/s figure ---------
+    vae_ms = None
+    try:
+        from refiners_amd.engine.vae import CompiledVAEDecoder
+        from refiners_amd.latent_diffusion.vae import SDXLAutoencoder
+
+        vae = SDXLAutoencoder(device="meta")
+        gpu_weights(vae, seed=7, dtype=dtype, device=dev)
+        dec = CompiledVAEDecoder(vae)
+        z = pipe.x[:1] * 0.13
+        dec(z)
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for _ in range(3):
+            dec(z)
+        torch.cuda.synchronize()
+        vae_ms = (time.perf_counter() - tv) / 3 * 1e3
+    except Exception as exc:  # noqa: BLE001 -- the VAE is outside the benchmarked path; report, do not fail the bench
+        vae_ms = f"failed: {type(exc).__name__}: {exc}"
+
     line = {
         "metric": "sdxl_base_1024px_images_per_sec_50_ddim_steps", "value": round(images_per_s, 4), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -238,7 +258,9 @@ def main() -> None:
         "extra": {"params": n_params, "launches_per_step": pipe.engine.stats["step_ops"], "prologue_launches": pipe.engine.stats["prologue_ops"],
                   "fallback_nodes": pipe.engine.stats["fallback_nodes"], "arena_bytes": pipe.engine.stats["pool_bytes"],
                   "weights_broadcast_s": round(bcast_s, 3), "broadcast_launches": n_bcast, "setup_s": round(setup_s, 1),
-                  "output_finite": finite, "device": native.device_info()},
+                  "output_finite": finite, "device": native.device_info(),
+                  "vae_decode_ms_per_image": round(vae_ms, 2) if isinstance(vae_ms, float) else vae_ms,
+                  "end_to_end_images_per_s_incl_vae": round(world * n_img / (ms_per_step * 1e-3 * 50 + n_img * vae_ms * 1e-3), 4) if isinstance(vae_ms, float) else None},
     }
     print(json.dumps(line), flush=True)
     if world > 1:

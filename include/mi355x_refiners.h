@@ -210,6 +210,10 @@ int mi355x_patchify_nchw(int32_t dtype, const void* x, void* out, int32_t B, int
 /* out[i][0:C] = idx[i] >= 0 ? x[idx[i]][0:C] : 0   (row gather with zero fill: WindowPartition / WindowMerge of
  * segment_anything/image_encoder.py:202-236 as static index tables).  C * sizeof(dtype) must be a multiple of 16. */
 int mi355x_gather_rows(int32_t dtype, const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int64_t n_rows, int32_t C, void* stream);
+/* 1x1 convolution of an NCHW image with at most 8 input and 8 output channels (the VAE decoder's 4 -> 4 conv on the latents,
+ * src/refiners/foundationals/latent_diffusion/auto_encoder.py:185-187): out[b][o][p] = bias[o] + sum_c w[o][c] x[b][c][p]. */
+int mi355x_pointwise_nchw(int32_t dtype, const void* x, const void* w, const void* bias, void* out, int32_t B, int32_t Ci, int32_t Co,
+                          int64_t HW, void* stream);
 /* out[m][0:C1] = a[m][0:C1]; out[m][C1:C1+C2] = b[m][0:C2]   (ResidualConcatenator, unet.py:69-79, NHWC). */
 int mi355x_concat2(int32_t dtype, const void* a, int64_t lda, int32_t C1, const void* b, int64_t ldb, int32_t C2,
                    void* out, int64_t ldo, int64_t M, void* stream);

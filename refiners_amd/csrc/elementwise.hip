@@ -170,6 +170,24 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
     }
 }
 
+// 1x1 convolution of an NCHW image with very few channels (the VAE decoder's 4 -> 4 post-quantisation conv): one thread per
+// pixel, weights [Co][Ci] and bias read through the scalar cache.  Ci, Co <= 8.
+template <typename T>
+__global__ __launch_bounds__(256) void pointwise_nchw_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b, T* __restrict__ out,
+                                                              int B, int Ci, int Co, int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bi = i / HW, px = i - bi * HW;
+        float xin[8];
+        for (int c = 0; c < Ci; ++c) xin[c] = to_f32(x[(bi * Ci + c) * HW + px]);
+        for (int o = 0; o < Co; ++o) {
+            float acc = b ? to_f32(b[o]) : 0.f;
+            for (int c = 0; c < Ci; ++c) acc += to_f32(w[o * Ci + c]) * xin[c];
+            out[(bi * Co + o) * HW + px] = from_f32<T>(acc);
+        }
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL)                          \
@@ -292,5 +310,15 @@ extern "C" int mi355x_gather_rows(int32_t dtype, const void* x, int64_t ldx, con
     const int nv = C * es / 16;
     const int grid = grid_for(n_rows * nv);
     DISPATCH_T(dtype, hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), ldx, idx, static_cast<T*>(out), ldo, n_rows, nv));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_pointwise_nchw(int32_t dtype, const void* x, const void* w, const void* bias, void* out, int32_t B, int32_t Ci, int32_t Co,
+                                     int64_t HW, void* stream) {
+    if (!x || !w || !out || B <= 0 || HW <= 0 || Ci <= 0 || Co <= 0 || Ci > 8 || Co > 8) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((int64_t)B * HW);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pointwise_nchw_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), static_cast<const T*>(w),
+                                         static_cast<const T*>(bias), static_cast<T*>(out), B, Ci, Co, HW));
     return LAUNCH_OK();
 }

@@ -155,6 +155,7 @@ EXPORTS = [
     "mi355x_sinusoidal",
     "mi355x_patchify_nchw",
     "mi355x_gather_rows",
+    "mi355x_pointwise_nchw",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -193,6 +194,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_sinusoidal.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.mi355x_patchify_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     lib.mi355x_gather_rows.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+    lib.mi355x_pointwise_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     if lib.mi355x_abi_version() != 2:
@@ -573,6 +575,15 @@ def gather_rows(x: Tensor, idx: Tensor, out: Tensor) -> Tensor:
     assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == out.shape[0]
     _launch("mi355x_gather_rows", (dtype_code(x.dtype), x.data_ptr(), x.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), out.shape[0], x.shape[1]),
             "mi355x_gather_rows", keep=(idx,))
+    return out
+
+
+def pointwise_nchw(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor) -> Tensor:
+    """1x1 conv of a few-channel NCHW image: x [B, Ci, H, W], w [Co, Ci], out [B, Co, H, W] (all contiguous)."""
+    B, Ci, H, W = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (out.shape[1], Ci)
+    _launch("mi355x_pointwise_nchw", (dtype_code(x.dtype), x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                      B, Ci, out.shape[1], H * W), "mi355x_pointwise_nchw")
     return out
 
 

@@ -79,3 +79,7 @@ def sam_sample(neck_out, early):
 
     stats = torch.tensor([neck_out.mean(), neck_out.abs().mean(), neck_out.std(), early.mean(), early.abs().mean(), early.std()], dtype=torch.float64)
     return {"neck": neck_out[:, :, ::4, ::4].float().clone(), "early": early[:, ::8, ::8, ::8].float().clone(), "stats": stats.float()}
+
+
+# ------------------------------------------------------------------------------------------------ next-1: VAE decode
+VAE_CASE = dict(weight_seed=0, input_seed=13, latent_hw=(16, 24), latent_std=0.13)

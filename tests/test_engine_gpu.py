@@ -267,3 +267,28 @@ def test_sam_vit_h_float32_matches_reference():
         print(f"sam {k}: l2 {l2:.2e} max {mx:.2e}")
         assert l2 < F32_TOL and mx < F32_TOL, (k, l2, mx)
     print("sam launches", fast.stats["step_ops"], "fallbacks", len(fast.stats["fallback_nodes"]))
+
+
+def test_vae_decoder_matches_reference():
+    """SDXL VAE decode on the engine, float32 vs the real reference's output; bf16 vs float32."""
+    import json
+
+    from refiners_amd.engine.vae import CompiledVAEDecoder
+    from refiners_amd.latent_diffusion.vae import SDXLAutoencoder
+    from tests.golden_cases import VAE_CASE
+
+    shapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "vae_keys.json").read_text()).items()}
+    sd = S.synth.synth_state_dict(shapes, VAE_CASE["weight_seed"])
+    z = (torch.randn((1, 4, *VAE_CASE["latent_hw"]), generator=S.synth._gen("vae.latents", VAE_CASE["input_seed"])) * VAE_CASE["latent_std"]).cuda()
+    gold = S.golden("vae_decode")["image"]
+    for dtype, tol in ((torch.float32, F32_TOL), (torch.bfloat16, 3e-2)):
+        vae = SDXLAutoencoder(device="meta")
+        vae.load_state_dict({k: v.to("cuda", dtype) for k, v in sd.items()}, assign=True)
+        fast = CompiledVAEDecoder(vae)
+        img = fast(z.to(dtype))
+        l2, mx = S.rel_err(img.float(), gold)
+        print(f"vae decode {dtype}: l2 {l2:.2e} max {mx:.2e} launches {fast.stats['step_ops']} fallbacks {fast.stats['fallback_nodes']}")
+        assert l2 < tol, (dtype, l2, mx)
+        if dtype == torch.float32:
+            assert mx < tol
+            assert torch.equal(img, fast(z))
