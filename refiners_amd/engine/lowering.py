@@ -504,11 +504,12 @@ class Lowering:
         out = self.pool.get(M, C)
         d = C // heads
         if d == 64:
-            q3 = q.view(B, Lq, C)
+            q3 = q.as_strided((B, Lq, C), (Lq * q.stride(0), q.stride(0), 1))
             st = []
             for k, vt, Lk, osc in streams:
                 lkp = k.shape[0] // B
-                st.append((k.view(B, lkp, C), vt.view(C, B, vt.shape[1] // B), Lk, osc))
+                kv = k.as_strided((B, lkp, C), (lkp * k.stride(0), k.stride(0), 1))  # k may be a column slice of a packed [Q|K] buffer
+                st.append((kv, vt.view(C, B, vt.shape[1] // B), Lk, osc))
             native.attention(q3, out.view(B, Lq, C), heads, st)
             return out
         # head dims the flash kernel does not cover (SD1.5: 40 / 80 / 160): torch SDPA on the same token-major tensors
@@ -571,11 +572,23 @@ class Lowering:
             q = self.linear(h, qs)
             k = self.linear(h, ks)
         if native_path:
-            vt_base = self.pool.get(C + 1, M)  # one spare row: the kernel reads V^T rows up to the next multiple of 64 keys
-            vt = vt_base[:C]
-            self.linear_T(h, vs, vt)
-            o = self.sdpa(q, B, heads, [(k, vt, M // B, 1.0)])
-            self.pool.put(vt_base)
+            L = M // B
+            if L % 64 == 0:
+                vt = self.pool.get(C, M)
+                self.linear_T(h, vs, vt)
+            else:
+                # token counts that are not a multiple of 64 (e.g. 1216x832 px -> 38x26 = 988 tokens at the deepest level): each
+                # sample's V^T columns start on a 64-key boundary (16-byte aligned rows, readable up to the padded length),
+                # one projection launch per sample; the padding is zeroed ONCE here (the kernel masks those keys' scores
+                # but still multiplies their V by an exact 0, so it must be finite)
+                lp = (L + 63) // 64 * 64
+                vt = torch.zeros(C, B * lp, device=self.device, dtype=self.dtype)
+                self.__dict__.setdefault("_keep", []).append(vt)
+                for b in range(B):
+                    self.linear_T(h[b * L : (b + 1) * L], vs, vt[:, b * lp : b * lp + L])
+            o = self.sdpa(q, B, heads, [(k, vt, L, 1.0)])
+            if L % 64 == 0:
+                self.pool.put(vt)
         else:
             v = self.linear(h, vs)
             o = self.sdpa(q, B, heads, [(k, v, M // B, 1.0)], v_plain=[v])

@@ -292,3 +292,21 @@ def test_vae_decoder_matches_reference():
         if dtype == torch.float32:
             assert mx < tol
             assert torch.equal(img, fast(z))
+
+
+def test_token_counts_that_are_not_multiples_of_64():
+    """Latent 24x40 -> 960 / 240 / 60 tokens per level (a real SDXL bucket such as 1216x832 px ends at 38x26 = 988 tokens):
+    the deepest levels take the per-sample padded V^T path.  float32 vs the CPU oracle."""
+    from oracle import unet_oracle as O
+
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", 0), device="cuda", dtype=torch.float32)
+    inp = S.synth.sdxl_inputs(1, (24, 40), seed=21)
+    sd = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0)
+    sd.set_inputs(inp["x"].cuda(), clip_text_embedding=inp["text"].cuda(), pooled_text_embedding=inp["pooled"].cuda(), time_ids=inp["time_ids"].cuda())
+    x1 = sd.step(3).clone()
+    ref = O.sdxl_cfg_step(S.weights("sdxl", 0), inp["x"], 3, 50, inp["text"], inp["pooled"], inp["time_ids"], condition_scale=5.0)
+    l2, mx = S.rel_err(x1, ref)
+    print(f"24x40 latents f32: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    assert torch.equal(x1, (sd.set_inputs(inp["x"].cuda(), clip_text_embedding=inp["text"].cuda(), pooled_text_embedding=inp["pooled"].cuda(), time_ids=inp["time_ids"].cuda()), sd.step(3))[1])
