@@ -391,16 +391,31 @@ class Chain(ContextModule):
         kept = [f for f in frames if not any(re.search(p, f.filename) for p in noise) and not f.name.startswith("_")]
         where = "".join(traceback.format_list(kept))
         text = re.sub(r"\n\s*\n", "\n", str(exc))
-        lines = render_tree(self, depth=3).split("\n")
-        key_line = next((i for i, ln in enumerate(lines) if name.split("_")[0] in ln), 0)
-        lo, hi = max(0, key_line - 10), min(len(lines), key_line + 11)
-        top = (self.get_parents() or [self])[-1]
-        path = next((f"{k}.{name}" if k else name for k, m in top.named_modules() if m is self), name)
+        excerpt = self._show_error_in_tree(name)
         shown = "\n".join(f"{i}: {_summarize(a)}" for i, a in enumerate(_flatten_args(args)))
-        msg = f"{where}\n{text}\n---------------\n>>> {path}\n" + "\n".join(lines[lo:hi]) + f"\n{shown}"
+        msg = f"{where}\n{text}\n---------------\n{excerpt}\n{shown}"
         if "Error" not in text:
             msg = f"{type(exc).__name__}:\n {msg}"
         return msg
+
+    def _show_error_in_tree(self, name: str, /, max_lines: int = 20) -> str:
+        """Depth-3 rendering of this Chain with the child registered under `name` flagged `>>> ... | <state-dict path>`,
+        cut to `max_lines` lines around the flag (reference chain.py:158-188)."""
+        root = _node(self)
+        _fold(root)
+        top = (self.get_parents() or [self])[-1]
+        prefix = next((k for k, m in top.named_modules() if m is self), "")
+        cls, _, ordinal = name.rpartition("_") if "_" in name else (name, "", "1")
+        seen = 0
+        for child in root["children"]:
+            if child["class_name"] == cls:
+                seen += 1
+                if ordinal.isdigit() and seen == int(ordinal):
+                    child["value"] = f">>> {child['value']} | {'.'.join(p for p in (prefix, name) if p)}"
+                    break
+        lines = _render(root, "", True, True, 3).split("\n")
+        at = next((i for i, ln in enumerate(lines) if ">>> " in ln), 0)
+        return "\n".join(lines[max(0, at - max_lines // 2) : min(len(lines), at + max_lines // 2 + 1)])
 
     def forward(self, *args: Any) -> Any:
         result: Any = None
