@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
     const int cg = C / G;
     const int L = 256 / cg;  // lanes per channel (cg <= 256 is checked by the host)
     const int t = threadIdx.x;
-    const int cl = t / L, j = t - cl * L;
-    const bool on = cl < cg;
+    const int j = t / cg, cl = t - j * cg;  // consecutive threads -> consecutive channels: each k reads one contiguous run
+    const bool on = j < L;
     const int c = g * cg + cl;
     const float n = (float)HW;
     float s1 = 0.f, s2 = 0.f;
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
     if (on && j == 0) {
         float a1 = 0.f, a2 = 0.f;
         for (int q = 0; q < L; ++q) {
-            a1 += red[(t + q) * 2 + 0];
-            a2 += red[(t + q) * 2 + 1];
+            a1 += red[(cl + cg * q) * 2 + 0];
+            a2 += red[(cl + cg * q) * 2 + 1];
         }
         const float piv = to_f32(x[(int64_t)b * HW * ldx + c]);
         mean_c[cl] = piv + a1 / n;
