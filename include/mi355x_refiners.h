@@ -83,6 +83,8 @@ typedef struct {
     int32_t stride;  /* conv == 1: 1 or 2 */
     int32_t ups;     /* conv == 1: 1 or 2 */
     int32_t H, W;    /* conv == 1: stored input height / width (before `ups`) */
+    int32_t asym;    /* conv == 1: 0 = zero padding ksize/2 on every side; 1 = padding only after the last row / column, i.e.
+                        F.pad(x, (0, 1, 0, 1)) followed by an unpadded conv (fl.Downsample(padding=0), layers/sampling.py:41-109) */
 } mi355x_gemm_seg;
 
 typedef struct {

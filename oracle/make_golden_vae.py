@@ -31,6 +31,11 @@ def main() -> None:
         img = vae.decode(z)
     save_file({"image": img.contiguous()}, str(GOLD / "vae_decode.safetensors"))
     print(tuple(img.shape), float(img.abs().mean()), float(img.std()))
+    pic = torch.rand((1, 3, 8 * VAE_CASE["latent_hw"][0], 8 * VAE_CASE["latent_hw"][1]), generator=synth._gen("vae.image", VAE_CASE["input_seed"])) * 2 - 1
+    with torch.no_grad():
+        lat = vae.encode(pic)
+    save_file({"latents": lat.contiguous()}, str(GOLD / "vae_encode.safetensors"))
+    print(tuple(lat.shape), float(lat.abs().mean()), float(lat.std()))
 
 
 if __name__ == "__main__":

@@ -57,3 +57,23 @@ def vae_decode(sd: SD, latents: Tensor, encoder_scale: float = 0.13025) -> Tenso
             x = F.conv2d(x, sd[f"{s}.Upsample.Conv2d.weight"], sd[f"{s}.Upsample.Conv2d.bias"], padding=1)
     x = F.silu(F.group_norm(x, 32, sd[f"{p}.Chain_2.GroupNorm.weight"], sd[f"{p}.Chain_2.GroupNorm.bias"], 1e-6))
     return F.conv2d(x, sd[f"{p}.Chain_2.Conv2d.weight"], sd[f"{p}.Chain_2.Conv2d.bias"], padding=1)
+
+
+@torch.no_grad()
+def vae_encode(sd: SD, image: Tensor, encoder_scale: float = 0.13025) -> Tensor:
+    """LatentDiffusionAutoencoder.encode (auto_encoder.py:317-320) = encoder_scale * Encoder(image) (83-141): image in [-1, 1],
+    (B, 3, 8h, 8w) -> latents (B, 4, h, w).  Downsample(padding=0) = F.pad(x, (0, 1, 0, 1)) + stride-2 conv (sampling.py:41-109)."""
+    p = "Encoder"
+    x = F.conv2d(image, sd[f"{p}.Conv2d.weight"], sd[f"{p}.Conv2d.bias"], padding=1)
+    for i in range(1, 6):
+        s = f"{p}.Chain_1.Chain_{i}"
+        x = resnet(sd, f"{s}.Resnet_1", x)
+        if i == 5:
+            x = attention(sd, f"{s}.Residual", x)
+        x = resnet(sd, f"{s}.Resnet_2", x)
+        if f"{s}.Downsample.Conv2d.weight" in sd:
+            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[f"{s}.Downsample.Conv2d.weight"], sd[f"{s}.Downsample.Conv2d.bias"], stride=2)
+    x = F.silu(F.group_norm(x, 32, sd[f"{p}.Chain_2.GroupNorm.weight"], sd[f"{p}.Chain_2.GroupNorm.bias"], 1e-6))
+    x = F.conv2d(x, sd[f"{p}.Chain_2.Conv2d.weight"], sd[f"{p}.Chain_2.Conv2d.bias"], padding=1)
+    x = F.conv2d(x, sd[f"{p}.Chain_3.Conv2d.weight"], sd[f"{p}.Chain_3.Conv2d.bias"])
+    return encoder_scale * x[:, :4]

@@ -26,6 +26,7 @@ struct SegP {
     int nkb;       // number of 128-byte K blocks in this segment
     int cpb;       // conv: K blocks per tap (= channels*sizeof(T)/128)
     int ksize, stride, ups_shift, H, W;
+    int pad;  // zero rows / columns before the image (ksize / 2, or 0 for the bottom/right-only padding of Downsample(padding=0))
 };
 
 struct GemmP {
@@ -150,9 +151,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
             cb = kb - tap * sp.cpb;
             dy = tap / sp.ksize;
             dx = tap - dy * sp.ksize;
-            const int pad = sp.ksize >> 1;
-            dy -= pad;
-            dx -= pad;
+            dy -= sp.pad;
+            dx -= sp.pad;
         }
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
@@ -561,6 +561,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
             d.cpb = g.k / bke;
             d.nkb = g.ksize * g.ksize * d.cpb;
             d.ksize = g.ksize;
+            d.pad = g.asym ? 0 : g.ksize / 2;
             d.stride = g.stride;
             d.ups_shift = g.ups == 2 ? 1 : 0;
             d.H = g.H;
@@ -569,6 +570,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
             d.cpb = 1;
             d.nkb = g.k / bke;
             d.ksize = 1;
+            d.pad = 0;
             d.stride = 1;
             d.ups_shift = 0;
         }

@@ -121,6 +121,7 @@ class ConvSpec:
     stride: int
     lora: Optional[LoraPack] = None
     time: Optional[tuple[str, LinSpec]] = None  # (context key, Linear(1280 -> cout)) of a RangeAdapter2d
+    asym: bool = False  # padding only after the last row / column (fl.Downsample(padding=0))
 
 
 class Pool:
@@ -323,7 +324,7 @@ class Lowering:
             return LinSpec(wp, bp, self._lora_pack_linear(loras, n_out, k_in, perm), geglu=True)
         return LinSpec(self._w(w), self._w(b), self._lora_pack_linear(loras, n_out, k_in, None))
 
-    def conv_spec(self, node: Any) -> ConvSpec:
+    def conv_spec(self, node: Any, asym: bool = False) -> ConvSpec:
         time = None
         if isa(node, "RangeAdapter2d"):
             ch = kids(node)
@@ -339,7 +340,7 @@ class Lowering:
         _expect(kh == kw and kh in (1, 3), f"conv kernel {kh}x{kw} not supported")
         _expect(leaf.stride[0] == leaf.stride[1] and leaf.stride[0] in (1, 2), "conv stride not supported")
         pad = leaf.padding if isinstance(leaf.padding, tuple) else (leaf.padding, leaf.padding)
-        _expect(tuple(pad) == (kh // 2, kh // 2), "only 'same'-style padding k//2 is supported")
+        _expect(tuple(pad) == ((0, 0) if asym else (kh // 2, kh // 2)), "only 'same'-style padding k//2 (or Downsample's explicit bottom/right pad) is supported")
         _expect(leaf.groups == 1 and tuple(leaf.dilation) == (1, 1), "grouped / dilated conv not supported")
         _expect((i * self.es) % 128 == 0, f"conv in_channels {i} not 128-byte aligned")
         wp = self.cache.get(("convw",) + PackCache.ident(w), lambda: native.pack_conv_weight(self.cvt(w)))
@@ -383,7 +384,7 @@ class Lowering:
 
             lora = self.cache.get(key, make)
             self.stats["lora_sites"] += 1
-        return ConvSpec(wp, self._w(leaf.bias), i, o, kh, leaf.stride[0], lora, time)
+        return ConvSpec(wp, self._w(leaf.bias), i, o, kh, leaf.stride[0], lora, time, asym)
 
     # -- emitters: GEMM family -------------------------------------------------------------------------------
     def lora_down(self, x: Tensor, lora: LoraPack) -> Tensor:
@@ -429,12 +430,12 @@ class Lowering:
         H, W = a.H * ups, a.W * ups
         OH, OW = (H + spec.stride - 1) // spec.stride, (W + spec.stride - 1) // spec.stride
         out = self.pool.get(a.B * OH * OW, spec.cout)
-        segs = [(a.image(), spec.w, spec.ksize, spec.stride, ups)]
+        segs = [(a.image(), spec.w, spec.ksize, spec.stride, ups, int(spec.asym))]
         t = None
         if spec.lora is not None:
             kd, ku, st = spec.lora.conv  # type: ignore[misc]
             t = self.pool.get(a.B * OH * OW, spec.lora.a_cat.shape[0])
-            native.conv_gemm([(a.image(), spec.lora.a_cat, kd, st, ups)], t, a.B, OH, OW)
+            native.conv_gemm([(a.image(), spec.lora.a_cat, kd, st, ups, int(spec.asym))], t, a.B, OH, OW)
             segs.append((Act(t, a.B, OH, OW).image(), spec.lora.bs_cat, ku, 1, 1))
         b = spec.b if isinstance(bias, str) else bias
         if shortcut is not None:
@@ -447,7 +448,7 @@ class Lowering:
         # partials are summed in a fixed order by a second launch, so the result stays bit-reproducible.
         M_out = a.B * OH * OW
         tiles128 = ((M_out + 127) // 128) * ((spec.cout + 127) // 128)
-        total_kb = sum(w.shape[1] for _, w, _, _, _ in segs) * self.es // 128
+        total_kb = sum(sg[1].shape[1] for sg in segs) * self.es // 128
         tile, ksplit, ws = 0, 1, None
         if tiles128 <= 192 and total_kb >= 96:
             tile, ksplit = 1, 3
@@ -917,10 +918,12 @@ class UNetLowering(Lowering):
         elif isa(m, "Downsample"):
             ch = kids(m)
             conv = ch[-1]
-            _expect(all(isa(c, "SetContext") for c in ch[:-1]), "Downsample with explicit zero padding (padding=0) is not lowered")
+            _expect(all(isa(c, "SetContext", "Lambda") for c in ch[:-1]), "unexpected Downsample layout")
             if any(isa(c, "SetContext") for c in ch[:-1]):
                 ctx.shapes.append((cur.H, cur.W))
-            spec = self.conv_spec(conv)
+            explicit_pad = any(isa(c, "Lambda") for c in ch[:-1])  # padding=0 variant: F.pad(x, (0, 1, 0, 1)) + unpadded conv
+            _expect(explicit_pad == (m.padding == 0), "Downsample padding attribute and layout disagree")
+            spec = self.conv_spec(conv, asym=explicit_pad)
             _expect(spec.stride == 2 and spec.ksize == 3, "unexpected Downsample convolution")
             out = self.conv(cur, spec)
         elif isa(m, "Upsample"):

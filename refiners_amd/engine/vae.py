@@ -58,6 +58,54 @@ class VAEDecoderLowering(UNetLowering):
             native.nhwc_to_nchw(y.tokens(), out, y.C)
             self.pool.put(y.t)
 
+    def lower_encoder(self, enc: Any, image: Tensor, out: Tensor, encoder_scale: float) -> None:
+        """Encoder (auto_encoder.py:83-141) + encoder_scale (317-320): (B, 3, 8h, 8w) in [-1, 1] -> latents (B, 4, h, w)."""
+        ch = kids(enc)
+        _expect(len(ch) == 4 and isa(ch[0], "Conv2d") and all(isa(c, "Chain") for c in ch[1:]), "unexpected Encoder layout")
+        B, C, H, W = image.shape
+        ctx = UNetContext(self, B)
+        with self.in_step():
+            cpad = (C + self.kblk - 1) // self.kblk * self.kblk  # 3 input channels -> one 128-byte block of zero-padded channels
+            x0 = torch.zeros(B * H * W, cpad, device=self.device, dtype=self.dtype)
+            self.keepalive = [x0]
+            a0 = Act(x0, B, H, W)
+            native.nchw_to_nhwc(image, a0.tokens())
+            cur = self.conv(a0, self._padded_conv_spec(ch[0], cpad, ch[0].out_channels))
+            for stage in kids(ch[1]):
+                for m in kids(stage):
+                    if isa(m, "Resnet"):
+                        nxt = self.resnet(m, cur)
+                    elif isa(m, "Residual") and len(kids(m)) == 2 and isa(kids(m)[1], "SelfAttention2d"):
+                        nxt = self.attention_2d(m, cur)
+                    elif isa(m, "Downsample"):
+                        nxt = self.piece(m, cur, ctx, H, W)
+                        cur = None
+                    else:
+                        nxt = self.torch_node(m, cur)
+                    if cur is not None:
+                        self.pool.put(cur.t)
+                    cur = nxt
+            gn, act, conv = kids(ch[2])
+            _expect(isa(gn, "GroupNorm") and isa(act, "SiLU") and isa(conv, "Conv2d"), "unexpected Encoder output block")
+            g = self.groupnorm(cur, gn, silu=True)
+            self.pool.put(cur.t)
+            y = self.conv(g, self.conv_spec(conv))
+            self.pool.put(g.t)
+            quant, cut = kids(ch[3])
+            _expect(isa(quant, "Conv2d") and quant.kernel_size == (1, 1) and isa(cut, "Slicing") and cut.dim == 1 and cut.start == 0 and cut.step == 1, "unexpected quantisation tail")
+            keep = cut.end or quant.out_channels
+            _expect(out.shape[1] == keep and quant.in_channels <= 8, "unexpected latent width")
+            moments = torch.empty(B, y.C, y.H, y.W, device=self.device, dtype=self.dtype)
+            self.keepalive.append(moments)
+            native.nhwc_to_nchw(y.tokens(), moments, y.C)
+            self.pool.put(y.t)
+            # Conv1x1(8 -> 8), Slicing(end=4) and the encoder_scale factor as one tiny kernel on the 4 kept output channels
+            wq = self.cache.get(("vae_q_w", encoder_scale, keep) + PackCache.ident(quant.weight),
+                                lambda: (quant.weight.detach().to(self.device, torch.float32).reshape(quant.out_channels, quant.in_channels)[:keep] * encoder_scale).to(self.dtype).contiguous())
+            bq = self.cache.get(("vae_q_b", encoder_scale, keep) + PackCache.ident(quant.bias),
+                                lambda: (quant.bias.detach().to(self.device, torch.float32)[:keep] * encoder_scale).to(self.dtype).contiguous())
+            native.pointwise_nchw(moments, wq, bq, out)
+
     def _stem_from(self, conv: Any, x: Tensor) -> Act:
         io_x, self.io = getattr(self, "io", None), type("IO", (), {"x": x})()
         try:
@@ -136,5 +184,37 @@ class CompiledVAEDecoder:
             self.low, self.key = low, key
             self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
         self.x.copy_(latents)
+        native.replay(self.low.step)
+        return self.out.clone()
+
+
+class CompiledVAEEncoder:
+    """`latents = CompiledVAEEncoder(vae)(image)` == `vae.encode(image)` (image in [-1, 1], (B, 3, 8h, 8w))."""
+
+    def __init__(self, vae: Any) -> None:
+        native.load()
+        self.vae = vae
+        self.cache = PackCache()
+        self.key: Any = None
+        self.stats: dict[str, Any] = {}
+
+    @torch.no_grad()
+    def __call__(self, image: Tensor) -> Tensor:
+        from ..fluxion.tree import tree_epoch
+
+        enc = kids(self.vae)[0]
+        dtype = enc.dtype
+        key = (tree_epoch(), tuple(image.shape), dtype, image.device, float(self.vae.encoder_scale))
+        if key != self.key:
+            B, _, H, W = image.shape
+            assert H % 8 == 0 and W % 8 == 0, "the autoencoder downsamples by 8"
+            self.x = torch.empty(tuple(image.shape), device=image.device, dtype=dtype)
+            self.out = torch.empty(B, 4, H // 8, W // 8, device=image.device, dtype=dtype)
+            low = VAEDecoderLowering(image.device, dtype, self.cache)
+            low.lower_encoder(enc, self.x, self.out, float(self.vae.encoder_scale))
+            self.cache.sweep()
+            self.low, self.key = low, key
+            self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
+        self.x.copy_(image)
         native.replay(self.low.step)
         return self.out.clone()

@@ -39,6 +39,7 @@ class GemmSeg(C.Structure):
         ("ups", C.c_int32),
         ("H", C.c_int32),
         ("W", C.c_int32),
+        ("asym", C.c_int32),
     ]
 
 
@@ -371,7 +372,7 @@ def gemm(
 
 
 def conv_gemm(
-    segs: Sequence[tuple[Tensor, Tensor, int, int, int]],
+    segs: Sequence[tuple],
     out: Tensor,
     B: int,
     OH: int,
@@ -398,14 +399,16 @@ def conv_gemm(
     a.nseg = len(segs)
     a.conv = 1
     a.B, a.OH, a.OW = B, OH, OW
-    for s, (img, w, ksize, stride, ups) in enumerate(segs):
+    for s, seg in enumerate(segs):
+        img, w, ksize, stride, ups = seg[:5]
+        asym = seg[5] if len(seg) > 5 else 0
         assert img.dim() == 4 and img.stride(3) == 1, "conv segment must be an NHWC tensor [B,H,W,C]"
         b, h, wd, c = img.shape
         assert img.stride(1) == wd * img.stride(2) and img.stride(0) == h * img.stride(1), "pixels must be uniformly strided"
         assert w.shape[1] == ksize * ksize * c and w.stride(1) == 1
         sg = a.seg[s]
         sg.x, sg.ldx, sg.w, sg.ldw, sg.k = img.data_ptr(), img.stride(2), w.data_ptr(), w.stride(0), c
-        sg.ksize, sg.stride, sg.ups, sg.H, sg.W = ksize, stride, ups, h, wd
+        sg.ksize, sg.stride, sg.ups, sg.H, sg.W, sg.asym = ksize, stride, ups, h, wd, asym
     a.zeros = zero_page(img0.device).data_ptr()
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, False)
     _fill_split(a, tile, ksplit, ws)

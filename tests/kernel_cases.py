@@ -166,6 +166,18 @@ def conv_case(B, Cin, Cout, H, W, dtype, *, ksize=3, stride=1, ups=1, split=0, b
     return _cmp(got, ref, dtype)
 
 
+def conv_asym_case(B, Cin, Cout, H, W, dtype, seed=58):
+    """fl.Downsample(padding=0): F.pad(x, (0, 1, 0, 1)) + 3x3 stride-2 conv without padding."""
+    x = _rand(B, Cin, H, W, dtype=dtype, seed=seed)
+    w = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=(Cin * 9) ** -0.5)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2)
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+    OH, OW = ref.shape[2], ref.shape[3]
+    out = torch.empty(B * OH * OW, Cout, dtype=dtype, device=DEV)
+    native.conv_gemm([(x.permute(0, 2, 3, 1).contiguous(), native.pack_conv_weight(w), 3, 2, 1, 1)], out, B, OH, OW, bias=b)
+    return _cmp(out.float().reshape(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, dtype)
+
+
 def conv_first_case(B, H, W, dtype, seed=60):
     """4 -> 320 input conv through im2col (K = 36 padded to one 128-byte block)."""
     Cin, Cout = 4, 320
@@ -351,6 +363,7 @@ def all_cases():
             (f"gemm_{tag}_vt_1024x1280", lambda dt=dt: gemm_vt_case(1024, 1280, 1280, dt)),
             (f"conv_{tag}_3x3_320_32", lambda dt=dt: conv_case(2, 320, 320, 32, 32, dt, rowbias=True)),
             (f"conv_{tag}_3x3_s2", lambda dt=dt: conv_case(2, 320, 320, 32, 32, dt, stride=2)),
+            (f"conv_{tag}_3x3_s2_asym_pad", lambda dt=dt: conv_asym_case(2, 128, 128, 32, 48, dt)),
             (f"conv_{tag}_3x3_ups2", lambda dt=dt: conv_case(1, 640, 640, 16, 16, dt, ups=2)),
             (f"conv_{tag}_1x1_res", lambda dt=dt: conv_case(2, 320, 640, 16, 16, dt, ksize=1, res=True)),
             (f"conv_{tag}_3x3_split_960", lambda dt=dt: conv_case(1, 960, 320, 16, 16, dt, split=640, rowbias=True, res=True)),

@@ -310,3 +310,23 @@ def test_token_counts_that_are_not_multiples_of_64():
     print(f"24x40 latents f32: l2 {l2:.2e} max {mx:.2e}")
     assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
     assert torch.equal(x1, (sd.set_inputs(inp["x"].cuda(), clip_text_embedding=inp["text"].cuda(), pooled_text_embedding=inp["pooled"].cuda(), time_ids=inp["time_ids"].cuda()), sd.step(3))[1])
+
+
+def test_vae_encoder_matches_reference():
+    """VAE encode (image -> latents, img2img entry): Downsample(padding=0) = bottom/right-only padding in the conv kernel."""
+    import json
+
+    from refiners_amd.engine.vae import CompiledVAEEncoder
+    from refiners_amd.latent_diffusion.vae import SDXLAutoencoder
+    from tests.golden_cases import VAE_CASE
+
+    shapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "vae_keys.json").read_text()).items()}
+    sd = S.synth.synth_state_dict(shapes, VAE_CASE["weight_seed"])
+    pic = (torch.rand((1, 3, 8 * VAE_CASE["latent_hw"][0], 8 * VAE_CASE["latent_hw"][1]), generator=S.synth._gen("vae.image", VAE_CASE["input_seed"])) * 2 - 1).cuda()
+    vae = SDXLAutoencoder(device="meta")
+    vae.load_state_dict({k: v.cuda() for k, v in sd.items()}, assign=True)
+    fast = CompiledVAEEncoder(vae)
+    lat = fast(pic)
+    l2, mx = S.rel_err(lat, S.golden("vae_encode")["latents"])
+    print(f"vae encode f32: l2 {l2:.2e} max {mx:.2e} launches {fast.stats['step_ops']} fallbacks {fast.stats['fallback_nodes']}")
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)

@@ -36,3 +36,17 @@ def test_vae_mirror_matches_reference(vae_inputs):
         img = vae.decode(z)
     l2, mx = S.rel_err(img, S.golden("vae_decode")["image"])
     assert l2 < TOL and mx < TOL, (l2, mx)
+
+
+def test_vae_encode_oracle_and_mirror_match_reference(vae_inputs):
+    _, sd, _ = vae_inputs
+    pic = torch.rand((1, 3, 8 * VAE_CASE["latent_hw"][0], 8 * VAE_CASE["latent_hw"][1]), generator=synth._gen("vae.image", VAE_CASE["input_seed"])) * 2 - 1
+    gold = S.golden("vae_encode")["latents"]
+    l2, mx = S.rel_err(vae_oracle.vae_encode(sd, pic), gold)
+    assert l2 < TOL and mx < TOL, (l2, mx)
+    vae = SDXLAutoencoder(device="meta")
+    vae.load_state_dict(sd, assign=True)
+    with torch.no_grad():
+        lat = vae.encode(pic)
+    l2, mx = S.rel_err(lat, gold)
+    assert l2 < TOL and mx < TOL, (l2, mx)
