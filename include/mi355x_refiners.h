@@ -124,7 +124,7 @@ int mi355x_gemm(const mi355x_gemm_args* args, void* stream);
  * Q, K, out are token-major: element (b, token, h*D + d) at base + b*batch_stride + token*ld + h*D + d.
  * V is passed TRANSPOSED (produced that way by mi355x_gemm with the operands swapped): element (h*D + d, b, key) at
  * vt + (h*D + d)*ldvt + b*vt_batch_stride + key; every V^T row must be readable (and finite) up to the next
- * multiple of 64 keys.  D must be 64 (SDXL; SD1.5's 40/80/160 are zero-padded by the host to 64/96.. not yet built).
+ * multiple of 64 keys.  D must be 64 (every SDXL attention); other head shapes go through mi355x_attention_general.
  */
 typedef struct {
     const void* k;
@@ -152,6 +152,45 @@ typedef struct {
 } mi355x_attn_args;
 
 int mi355x_attention(const mi355x_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * mi355x_attention_general -- out = out_scale * softmax(scale * Q K^T [+ causal mask]) V for head shapes other than 64:
+ * a QK width Dqk and a V width Dv that need not be equal, one K/V stream.
+ *
+ * Replaces the same ScaledDotProductAttention.forward (src/refiners/fluxion/layers/attentions.py:60-202) where the head
+ * dimension is not 64: SD1.5's 8 heads over 320/640/1280 channels (Dqk = Dv = 40/80/160,
+ * src/refiners/foundationals/latent_diffusion/stable_diffusion_1/unet.py:30-45), `is_causal=True`
+ * (attentions.py:15-34; key j attends to query i iff j <= i, both counted inside the sample), and the SegmentAnything
+ * ViT attention with decomposed relative position bias (src/refiners/foundationals/segment_anything/image_encoder.py:
+ * 82-127): the host appends the per-query bias rows (rel_h | rel_w) to Q / scale and one-hot row/column indicators to K,
+ * so that Q'K'^T = QK^T + bias / scale exactly; then Dqk = 80 + h + w (padded to a multiple of 8 elements) and Dv = 80.
+ *
+ * Layouts as for mi355x_attention (Q, K, out token-major; V transposed, rows readable and finite up to the next
+ * multiple of 64 keys).  Dqk * sizeof(dtype) % 16 == 0, Dv % 4 == 0; supported (Dqk, Dv) up to (64,64), (96,80),
+ * (128,80), (160,160), (224,80); anything else returns MI355X_ESHAPE.
+ */
+typedef struct {
+    int32_t dtype;
+    int32_t B, H, Lq, Lk;
+    int32_t Dqk, Dv;
+    int32_t causal;
+    const void* q;
+    int64_t ldq;
+    int64_t q_batch_stride;
+    const void* k;
+    int64_t ldk;
+    int64_t k_batch_stride;
+    const void* vt;
+    int64_t ldvt;
+    int64_t vt_batch_stride;
+    void* out;
+    int64_t ldo;
+    int64_t o_batch_stride;
+    float scale;
+    float out_scale;
+} mi355x_attn_general_args;
+
+int mi355x_attention_general(const mi355x_attn_general_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * mi355x_layernorm -- rows of C: out = (x - mean) * rsqrt(var + eps) * gamma + beta
@@ -212,6 +251,13 @@ int mi355x_patchify_nchw(int32_t dtype, const void* x, void* out, int32_t B, int
 /* out[i][0:C] = idx[i] >= 0 ? x[idx[i]][0:C] : 0   (row gather with zero fill: WindowPartition / WindowMerge of
  * segment_anything/image_encoder.py:202-236 as static index tables).  C * sizeof(dtype) must be a multiple of 16. */
 int mi355x_gather_rows(int32_t dtype, const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int64_t n_rows, int32_t C, void* stream);
+/* SegmentAnything's decomposed relative position bias (src/refiners/foundationals/segment_anything/image_encoder.py:82-127)
+ * as extra query columns.  src row per head: [q*scale (d) | P1 (2*S1-1) | P2 (2*S2-1) | pad] (Lp columns), P1[r] = q.E1[2*S1-2-r],
+ * P2[r] = q.E2[2*S2-2-r] (tables folded into the projection weights by the host).  Token t of a sample is at (a, b) = (t / S2, t % S2).
+ * out row per head: [q*scale (d) | P1[S1-1-a : 2*S1-1-a] | P2[S2-1-b : 2*S2-1-b] | 0] (Dq columns): against K' = [k | onehot(a') |
+ * onehot(b') | 0] the product is scale*q.k + q.E1[a-a'+S1-1] + q.E2[b-b'+S2-1], the logits of RelativePositionAttention. */
+int mi355x_relpos_pack(int32_t dtype, const void* src, int64_t lds, void* out, int64_t ldo, int64_t M, int32_t H, int32_t d, int32_t S1, int32_t S2,
+                       int32_t Lp, int32_t Dq, void* stream);
 /* 1x1 convolution of an NCHW image with at most 8 input and 8 output channels (the VAE decoder's 4 -> 4 conv on the latents,
  * src/refiners/foundationals/latent_diffusion/auto_encoder.py:185-187): out[b][o][p] = bias[o] + sum_c w[o][c] x[b][c][p]. */
 int mi355x_pointwise_nchw(int32_t dtype, const void* x, const void* w, const void* bias, void* out, int32_t B, int32_t Ci, int32_t Co,

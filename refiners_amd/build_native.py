@@ -13,7 +13,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libmi355x_refiners.so"
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "attention_general.hip", "norm.hip", "elementwise.hip"]
 HEADERS = ["common.cuh", "../../include/mi355x_refiners.h"]
 ARCH = "gfx950"
 

@@ -322,3 +322,41 @@ extern "C" int mi355x_pointwise_nchw(int32_t dtype, const void* x, const void* w
                                          static_cast<const T*>(bias), static_cast<T*>(out), B, Ci, Co, HW));
     return LAUNCH_OK();
 }
+
+// ---- SegmentAnything decomposed relative position bias -> extra query columns --------------------------------------------
+// src row (one token), per head: [ q * scale (d) | P1 (2*S1 - 1) | P2 (2*S2 - 1) | pad ]  (Lp columns), where
+// P1[r] = q . E1[2*S1 - 2 - r] and P2[r] = q . E2[2*S2 - 2 - r] come out of the same GEMM as q (embedding tables folded into
+// the projection weights, reversed).  Token t of a sample sits at grid position (a, b) = (t / S2, t % S2); its bias against a key
+// at (a', b') is q . E1[a - a' + S1 - 1] + q . E2[b - b' + S2 - 1] = P1[S1 - 1 - a + a'] + P2[S2 - 1 - b + b'], i.e. two
+// CONTIGUOUS windows of the P columns.  out row per head: [ q * scale (d) | P1 window (S1) | P2 window (S2) | 0 pad ] (Dq columns)
+// which mi355x_attention_general multiplies with K' = [ k | onehot(a') | onehot(b') | 0 ].
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_pack_kernel(const T* __restrict__ src, int64_t lds, T* __restrict__ out, int64_t ldo, int64_t M, int H, int d,
+                                                           int S1, int S2, int Lp, int Dq) {
+    const int64_t total = M * H * Dq;
+    const int L = S1 * S2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / ((int64_t)H * Dq);
+        const int rem = (int)(i - row * H * Dq);
+        const int hd = rem / Dq, col = rem - hd * Dq;
+        const int t = (int)(row % L), a = t / S2, b = t - a * S2;
+        const T* s = src + row * lds + (int64_t)hd * Lp;
+        T v;
+        if (col < d) v = s[col];
+        else if (col < d + S1) v = s[d + (S1 - 1 - a) + (col - d)];
+        else if (col < d + S1 + S2) v = s[d + (2 * S1 - 1) + (S2 - 1 - b) + (col - d - S1)];
+        else v = from_f32<T>(0.f);
+        out[row * ldo + rem] = v;
+    }
+}
+
+extern "C" int mi355x_relpos_pack(int32_t dtype, const void* src, int64_t lds, void* out, int64_t ldo, int64_t M, int32_t H, int32_t d, int32_t S1,
+                                  int32_t S2, int32_t Lp, int32_t Dq, void* stream) {
+    if (!src || !out || M <= 0 || H <= 0 || d <= 0 || S1 <= 0 || S2 <= 0) return MI355X_EARG;
+    if (Lp < d + 2 * S1 - 1 + 2 * S2 - 1 || Dq < d + S1 + S2 || lds < (int64_t)H * Lp || ldo < (int64_t)H * Dq) return MI355X_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(M * H * Dq);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((relpos_pack_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(src), lds, static_cast<T*>(out), ldo, M, H, d,
+                                         S1, S2, Lp, Dq));
+    return LAUNCH_OK();
+}

@@ -504,16 +504,26 @@ class Lowering:
         Lq = M // B
         out = self.pool.get(M, C)
         d = C // heads
-        if d == 64:
+        kind = self.head_kernel(d)
+        if kind is not None:
             q3 = q.as_strided((B, Lq, C), (Lq * q.stride(0), q.stride(0), 1))
             st = []
             for k, vt, Lk, osc in streams:
                 lkp = k.shape[0] // B
                 kv = k.as_strided((B, lkp, C), (lkp * k.stride(0), k.stride(0), 1))  # k may be a column slice of a packed [Q|K] buffer
                 st.append((kv, vt.view(C, B, vt.shape[1] // B), Lk, osc))
-            native.attention(q3, out.view(B, Lq, C), heads, st)
+            if kind == "flash64":
+                native.attention(q3, out.view(B, Lq, C), heads, st)
+                return out
+            # other head dims (SD1.5: 40 / 80 / 160): one launch per K/V stream, the image-prompt stream is accumulated
+            for i, (kv, vt3, Lk, osc) in enumerate(st):
+                dst = out if i == 0 else self.pool.get(M, C)
+                native.attention_general(q3, kv, vt3, dst.view(B, Lq, C), heads, Lk, out_scale=osc)
+                if i > 0:
+                    native.axpby(out, 1.0, dst, 1.0, out)
+                    self.pool.put(dst)
             return out
-        # head dims the flash kernel does not cover (SD1.5: 40 / 80 / 160): torch SDPA on the same token-major tensors
+        # head dims no kernel covers (the VAE's single 512-wide head): torch SDPA on the same token-major tensors
         assert v_plain is not None
 
         def run() -> None:
@@ -531,6 +541,15 @@ class Lowering:
         self.stats["fallback_nodes"].append(f"SDPA(head_dim={d})")
         return out
 
+    def head_kernel(self, d: int) -> Optional[str]:
+        """Which attention kernel serves head dim d: mi355x_attention (64), mi355x_attention_general (<= 160, 16-byte rows), none."""
+        if d == 64:
+            return "flash64"
+        es = 4 if self.dtype == torch.float32 else 2
+        if d <= 160 and (d * es) % 16 == 0 and d % 4 == 0:
+            return "general"
+        return None
+
     @staticmethod
     def _pad_keys(n: int) -> int:
         return (n + 63) // 64 * 64
@@ -543,7 +562,7 @@ class Lowering:
         k = self.pool.get(src.shape[0], C)
         self.pool.pin(k)
         self.linear(src, ks, out=k)
-        if C // heads == 64:
+        if self.head_kernel(C // heads) is not None:
             vt = self.pool.get(C, src.shape[0])
             self.pool.pin(vt)
             self.linear_T(src, vs, vt)
@@ -562,7 +581,7 @@ class Lowering:
         qs, ks, vs = self.linear_spec(qn), self.linear_spec(kn), self.linear_spec(vn)
         _expect(qs.b is None and ks.b is None and vs.b is None, "q/k/v bias not supported")
         M, C = x.shape
-        native_path = (C // heads) == 64
+        native_path = self.head_kernel(C // heads) is not None
         if qs.lora is None and ks.lora is None:
             wqk = self.cache.get(("qk",) + PackCache.ident(qs.w, ks.w), lambda: torch.cat([qs.w, ks.w], 0).contiguous())
             qk = self.pool.get(M, 2 * C)

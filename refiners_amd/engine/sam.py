@@ -11,10 +11,16 @@ turned into a launch program; tokens stay channels-last [B*64*64, C] end to end.
   Neck                -> GEMM (1x1 conv) | LayerNorm (LayerNorm2d == per-token LN in this layout) | implicit-GEMM 3x3 | LayerNorm
   SAMViTAdapter hook  -> one copy of the token buffer after the first global-attention layer
 
-NOT native yet: the attention itself.  ViT-H has 16 heads of 80 and an additive decomposed relative-position bias
-(image_encoder.py:82-127); the flash kernel of csrc/attention.hip covers head_dim 64 without bias, so each of the 32
-attentions runs the node's own torch forward on the GPU (listed in stats["fallback_nodes"]).  Everything else (5.45 of
-the encoder's 5.96 TFLOP) is on the hand-written kernels.
+The attention (16 heads of 80 + the additive decomposed relative-position bias of image_encoder.py:82-127) runs on
+mi355x_attention_general: the bias is bilinear in the query, bias[q, (a', b')] = q . E1[a - a' + S - 1] + q . E2[b - b' + S - 1],
+so it is carried by EXTRA COLUMNS of Q and K instead of an L x L matrix:
+
+  QP GEMM   h -> per head [ q / sqrt(d) | q . E1[r] for all 2S-1 offsets | q . E2[r] | pad ]   (tables folded into the weights)
+  relpos_pack  -> Q' = [ q / sqrt(d) | the S offsets this token's row needs | the S its column needs | 0 ]   (contiguous windows)
+  K' GEMM   h -> [ k | onehot(a') | onehot(b') | 0 ]   (the one-hot part is a constant residual operand of the GEMM)
+  V^T GEMM  (no bias: softmax rows sum to one, so V's bias passes through attention unchanged and is folded into the
+             output projection's bias, b_o' = b_o + W_o b_v)
+  attention_general(Q', K', V^T, scale = 1)  ==  softmax(q k^T / sqrt(d) + bias) v, the score matrix never touches HBM.
 """
 from __future__ import annotations
 
@@ -81,35 +87,47 @@ class SAMLowering(Lowering):
         windowed = isa(r1[1], "WindowPartition")
         _expect(windowed == isa(r1[3], "WindowMerge") and (windowed or isa(r1[1], "Identity")), "inconsistent window partition / merge")
         M, C = tok.shape
-        h = self.layernorm(tok, r1[0])
+        h = h_full = self.layernorm(tok, r1[0])
         if windowed:
             ws = layer.window_size
             part, merge, nwin = self._window_tables(B, gh, gw, ws)
-            hw = self.pool.get(nwin * ws * ws, C)
-            native.gather_rows(h, part, hw)
-            self.pool.put(h)
-            h, shape = hw, (nwin, ws, ws)
+            h = self.pool.get(nwin * ws * ws, C)
+            native.gather_rows(h_full, part, h)
+            shape = (nwin, ws, ws)
         else:
             shape = (B, gh, gw)
-        qkv = self.linear(h, self.linear_spec(fsa[0]))
-        self.pool.put(h)
-        att = self.pool.get(qkv.shape[0], C)
         node = fsa[1]
+        qkv_spec, out_spec = self.linear_spec(fsa[0]), self.linear_spec(fsa[2])
+        aligned = windowed or (gh * gw) % 64 == 0  # global attention over a key count that is not a multiple of 64: no padded V^T source
+        packs = self.relpos_packs(qkv_spec, out_spec, node, shape) if qkv_spec.lora is None and out_spec.lora is None and aligned else None
+        if packs is not None:
+            att = self.relpos_attention(h, h_full, packs, node, shape, B, gh, gw, layer.window_size if windowed else None)
+            self.pool.put(h)
+            if windowed:
+                self.pool.put(h_full)
+            out_bias = packs["bo"]
+        else:
+            qkv = self.linear(h, qkv_spec)
+            self.pool.put(h)
+            if windowed:
+                self.pool.put(h_full)
+            att = self.pool.get(qkv.shape[0], C)
 
-        def attend(att: Tensor = att, qkv: Tensor = qkv, shape: tuple = shape, node: Any = node) -> None:
-            # the node's own torch forward (head_dim 80 + relative position bias: not covered by the flash kernel);
-            # arguments are bound NOW: `att` is rebound to the merged buffer a few lines below
-            att.view(*shape, C).copy_(node(qkv.view(*shape, 3 * C)))
+            def attend(att: Tensor = att, qkv: Tensor = qkv, shape: tuple = shape, node: Any = node) -> None:
+                # the node's own torch forward (shapes mi355x_attention_general does not cover, or un-merged LoRAs);
+                # arguments are bound NOW: `att` is rebound to the merged buffer a few lines below
+                att.view(*shape, C).copy_(node(qkv.view(*shape, 3 * C)))
 
-        self.python(attend, "torch:RelativePositionAttention")
-        self.stats["fallback_nodes"].append(f"RelativePositionAttention(head_dim={node.head_dim})")
-        self.pool.put(qkv)
+            self.python(attend, "torch:RelativePositionAttention")
+            self.stats["fallback_nodes"].append(f"RelativePositionAttention(head_dim={node.head_dim})")
+            self.pool.put(qkv)
+            out_bias = out_spec.b
         if windowed:
             am = self.pool.get(M, C)
             native.gather_rows(att, merge, am)
             self.pool.put(att)
             att = am
-        self.linear(att, self.linear_spec(fsa[2]), res=tok, out=tok)
+        native.gemm([(att, out_spec.w)], tok, bias=out_bias, res=tok)
         self.pool.put(att)
         _expect(len(r2) == 2 and isa(r2[0], "LayerNorm") and isa(r2[1], "FeedForward"), "unexpected MLP residual")
         ff = kids(r2[1])
@@ -124,6 +142,101 @@ class SAMLowering(Lowering):
             flat = early.view(M, C)
             self.python(lambda flat=flat, tok=tok: flat.copy_(tok), "copy:early_vit_embedding")
         return tok
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def relpos_packs(self, qkv: Any, out: Any, node: Any, shape: tuple) -> Optional[dict[str, Any]]:
+        """Weights of the three projections re-packed for the bias-as-columns attention (module docstring), or None when
+        the shape is outside what mi355x_attention_general instantiates."""
+        H, d, C = node.num_heads, node.head_dim, node.embedding_dim
+        S1, S2 = shape[1], shape[2]
+        # (the reference unpacks spatial_size as (width, height) but indexes the grid (first, second); every SAM config is square)
+        _expect(S1 == S2 and tuple(node.spatial_size) == (S1, S2), "RelativePositionAttention on a non-square / mismatching grid")
+        _expect(tuple(node.vertical_embedding.shape) == (2 * S1 - 1, d) and tuple(node.horizontal_embedding.shape) == (2 * S2 - 1, d), "unexpected relative position tables")
+        Dq = (d + S1 + S2 + 7) // 8 * 8
+        Lp = (d + 2 * S1 - 1 + 2 * S2 - 1 + 7) // 8 * 8
+        if not ((Dq <= 128 or Dq <= 224) and d <= 80 and d % 4 == 0) or qkv.w.shape[0] != 3 * C:
+            return None
+        o1, o2 = d + 2 * S1 - 1, d + 2 * S1 - 1 + 2 * S2 - 1
+        ident = PackCache.ident(*(t for t in (qkv.w, qkv.b, out.w, out.b, node.vertical_embedding, node.horizontal_embedding) if t is not None))
+
+        def make() -> dict[str, Any]:
+            f = dict(device=self.device, dtype=torch.float32)
+            if self.device.type == "meta":
+                z = lambda *sh: torch.empty(*sh, device=self.device, dtype=self.dtype)  # noqa: E731
+                return dict(wqp=z(H * Lp, C), bqp=z(H * Lp), wkp=z(H * Dq, C), bkp=z(H * Dq), wv=z(C, C), bo=z(C))
+            W = qkv.w.detach().to(**f)
+            b = qkv.b.detach().to(**f) if qkv.b is not None else torch.zeros(3 * C, **f)
+            Wq, Wk, Wv = W[:C].view(H, d, C), W[C : 2 * C].view(H, d, C), W[2 * C :]
+            bq, bk, bv = b[:C].view(H, d), b[C : 2 * C].view(H, d), b[2 * C :]
+            E1 = node.vertical_embedding.detach().to(**f).flip(0)    # first grid axis;  P1[r] = q . E1_table[2*S1 - 2 - r]
+            E2 = node.horizontal_embedding.detach().to(**f).flip(0)  # second grid axis
+            wqp, bqp = torch.zeros(H, Lp, C, **f), torch.zeros(H, Lp, **f)
+            wqp[:, :d], bqp[:, :d] = Wq * d ** -0.5, bq * d ** -0.5
+            wqp[:, d:o1], bqp[:, d:o1] = torch.einsum("rd,hdc->hrc", E1, Wq), torch.einsum("rd,hd->hr", E1, bq)
+            wqp[:, o1:o2], bqp[:, o1:o2] = torch.einsum("rd,hdc->hrc", E2, Wq), torch.einsum("rd,hd->hr", E2, bq)
+            wkp, bkp = torch.zeros(H, Dq, C, **f), torch.zeros(H, Dq, **f)
+            wkp[:, :d], bkp[:, :d] = Wk, bk
+            bo = out.w.detach().to(**f) @ bv + (out.b.detach().to(**f) if out.b is not None else 0)
+            c = lambda t: t.to(self.dtype).contiguous()  # noqa: E731
+            return dict(wqp=c(wqp.view(H * Lp, C)), bqp=c(bqp.view(-1)), wkp=c(wkp.view(H * Dq, C)), bkp=c(bkp.view(-1)), wv=c(Wv), bo=c(bo))
+
+        packs = dict(self.cache.get(("sam_relpos", S1, S2) + ident, make))
+        packs.update(Dq=Dq, Lp=Lp, S1=S1, S2=S2)
+        return packs
+
+    def _onehot_rows(self, n: int, H: int, d: int, S1: int, S2: int, Dq: int) -> Tensor:
+        """[n * S1 * S2, H * Dq]: ones at (d + a) and (d + S1 + b) of every head for the token at grid position (a, b)."""
+        def make() -> Tensor:
+            t = torch.zeros(S1 * S2, H, Dq, device=self.device, dtype=self.dtype)
+            if self.device.type != "meta":
+                idx = torch.arange(S1 * S2, device=self.device)
+                t[idx, :, d + idx // S2] = 1
+                t[idx, :, d + S1 + idx % S2] = 1
+            return t.view(S1 * S2, H * Dq).repeat(n, 1).contiguous()
+
+        return self.cache.get(("sam_onehot", n, H, d, S1, S2, Dq, self.dtype), make)
+
+    def relpos_attention(self, h: Tensor, h_full: Tensor, packs: dict[str, Any], node: Any, shape: tuple, B: int, gh: int, gw: int, ws: Optional[int]) -> Tensor:
+        """h: [n * L, C] (window-partitioned rows of h_full when ws is set) -> attention output [n * L, C] (before WindowMerge)."""
+        H, d, C = node.num_heads, node.head_dim, node.embedding_dim
+        n, S1, S2 = shape
+        L, Dq, Lp = S1 * S2, packs["Dq"], packs["Lp"]
+        Mw = n * L
+        qp = self.pool.get(Mw, H * Lp)
+        native.gemm([(h, packs["wqp"])], qp, bias=packs["bqp"])
+        q = self.pool.get(Mw, H * Dq)
+        native.relpos_pack(qp, q, H, d, S1, S2, Lp, Dq)
+        self.pool.put(qp)
+        k = self.pool.get(Mw, H * Dq)
+        native.gemm([(h, packs["wkp"])], k, bias=packs["bkp"], res=self._onehot_rows(n, H, d, S1, S2, Dq))
+        lkp = (L + 63) // 64 * 64
+        if lkp == L:
+            vt = self.pool.get(C, Mw)
+            native.gemm([(packs["wv"], h)], vt)
+        else:
+            # every window's V^T columns start on a 64-key boundary: a second gather of the SAME LayerNorm output with
+            # the windows padded to lkp rows (zero rows -> zero V^T columns, which masked keys multiply by exactly 0)
+            part_v = self._window_tables_padded(B, gh, gw, ws, lkp)
+            hv = self.pool.get(n * lkp, C)
+            native.gather_rows(h_full, part_v, hv)
+            vt = self.pool.get(C, n * lkp)
+            native.gemm([(packs["wv"], hv)], vt)
+            self.pool.put(hv)
+        att = self.pool.get(Mw, C)
+        native.attention_general(q.view(n, L, H * Dq), k.view(n, L, H * Dq), vt.view(C, n, lkp), att.view(n, L, C), H, L, scale=1.0)
+        self.pool.put(q)
+        self.pool.put(k)
+        self.pool.put(vt)
+        return att
+
+    def _window_tables_padded(self, B: int, Hh: int, W: int, ws: int, lkp: int) -> Tensor:
+        def make() -> Tensor:
+            part, _merge, nwin = self._window_tables(B, Hh, W, ws)
+            t = torch.full((nwin, lkp), -1, dtype=torch.int32, device=self.device)
+            t[:, : ws * ws] = part.view(nwin, ws * ws)
+            return t.reshape(-1).contiguous()
+
+        return self.cache.get(("windows_padded", B, Hh, W, ws, lkp), make)
 
     def neck(self, neck: Any, tok: Tensor, B: int, gh: int, gw: int, out: Tensor) -> None:
         ch = kids(neck)

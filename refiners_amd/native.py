@@ -103,6 +103,33 @@ class AttnArgs(C.Structure):
     ]
 
 
+class AttnGeneralArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("Lq", C.c_int32),
+        ("Lk", C.c_int32),
+        ("Dqk", C.c_int32),
+        ("Dv", C.c_int32),
+        ("causal", C.c_int32),
+        ("q", C.c_void_p),
+        ("ldq", C.c_int64),
+        ("q_batch_stride", C.c_int64),
+        ("k", C.c_void_p),
+        ("ldk", C.c_int64),
+        ("k_batch_stride", C.c_int64),
+        ("vt", C.c_void_p),
+        ("ldvt", C.c_int64),
+        ("vt_batch_stride", C.c_int64),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
+        ("o_batch_stride", C.c_int64),
+        ("scale", C.c_float),
+        ("out_scale", C.c_float),
+    ]
+
+
 class LayerNormArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32),
@@ -143,6 +170,7 @@ EXPORTS = [
     "mi355x_device_info",
     "mi355x_gemm",
     "mi355x_attention",
+    "mi355x_attention_general",
     "mi355x_layernorm",
     "mi355x_groupnorm_ws_floats",
     "mi355x_groupnorm",
@@ -157,6 +185,7 @@ EXPORTS = [
     "mi355x_patchify_nchw",
     "mi355x_gather_rows",
     "mi355x_pointwise_nchw",
+    "mi355x_relpos_pack",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -181,6 +210,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_device_info.argtypes = [C.c_char_p, C.c_int32]
     lib.mi355x_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
     lib.mi355x_attention.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
+    lib.mi355x_attention_general.argtypes = [C.POINTER(AttnGeneralArgs), C.c_void_p]
     lib.mi355x_layernorm.argtypes = [C.POINTER(LayerNormArgs), C.c_void_p]
     lib.mi355x_groupnorm.argtypes = [C.POINTER(GroupNormArgs), C.c_void_p]
     lib.mi355x_groupnorm_ws_floats.argtypes = [C.c_int32, C.c_int32, C.c_int32]
@@ -196,6 +226,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_patchify_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     lib.mi355x_gather_rows.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     lib.mi355x_pointwise_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    lib.mi355x_relpos_pack.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     if lib.mi355x_abi_version() != 2:
@@ -469,6 +500,36 @@ def attention(
     return out
 
 
+def attention_general(
+    q: Tensor,
+    k: Tensor,
+    vt: Tensor,
+    out: Tensor,
+    num_heads: int,
+    Lk: int,
+    scale: Optional[float] = None,
+    causal: bool = False,
+    out_scale: float = 1.0,
+) -> Tensor:
+    """Head shapes other than 64.  q [B, Lq, H*Dqk], k [B, Lk(+), H*Dqk], vt [H*Dv, B, Lkp] (Lkp = Lk rounded up to 64,
+    finite padding), out [B, Lq, H*Dv] -- all views with a contiguous last dimension."""
+    a = AttnGeneralArgs()
+    B, Lq, HD = q.shape
+    assert HD % num_heads == 0 and vt.shape[0] % num_heads == 0 and out.shape[2] == vt.shape[0]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1 and out.stride(2) == 1
+    a.dtype = dtype_code(q.dtype)
+    a.B, a.H, a.Lq, a.Lk = B, num_heads, Lq, Lk
+    a.Dqk, a.Dv, a.causal = HD // num_heads, vt.shape[0] // num_heads, int(causal)
+    a.q, a.ldq, a.q_batch_stride = q.data_ptr(), q.stride(1), q.stride(0)
+    a.k, a.ldk, a.k_batch_stride = k.data_ptr(), k.stride(1), k.stride(0)
+    a.vt, a.ldvt, a.vt_batch_stride = vt.data_ptr(), vt.stride(0), vt.stride(1)
+    a.out, a.ldo, a.o_batch_stride = out.data_ptr(), out.stride(1), out.stride(0)
+    a.scale = scale if scale is not None else a.Dqk ** -0.5
+    a.out_scale = out_scale
+    _launch("mi355x_attention_general", (C.byref(a),), "mi355x_attention_general")
+    return out
+
+
 def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Tensor) -> Tensor:
     a = LayerNormArgs()
     assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
@@ -578,6 +639,15 @@ def gather_rows(x: Tensor, idx: Tensor, out: Tensor) -> Tensor:
     assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == out.shape[0]
     _launch("mi355x_gather_rows", (dtype_code(x.dtype), x.data_ptr(), x.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), out.shape[0], x.shape[1]),
             "mi355x_gather_rows", keep=(idx,))
+    return out
+
+
+def relpos_pack(src: Tensor, out: Tensor, heads: int, d: int, S1: int, S2: int, Lp: int, Dq: int) -> Tensor:
+    """src [M, heads*Lp] -> out [M, heads*Dq]: the per-token windows of the folded relative-position products (see the header)."""
+    assert src.dim() == 2 and out.dim() == 2 and src.stride(1) == 1 and out.stride(1) == 1 and src.shape[0] == out.shape[0]
+    assert src.shape[1] >= heads * Lp and out.shape[1] >= heads * Dq
+    _launch("mi355x_relpos_pack", (dtype_code(src.dtype), src.data_ptr(), src.stride(0), out.data_ptr(), out.stride(0), src.shape[0], heads, d, S1, S2, Lp, Dq),
+            "mi355x_relpos_pack")
     return out
 
 

@@ -237,6 +237,62 @@ def attention_case(B, H, Lq, Lk, dtype, *, ip_tokens=0, ip_scale=0.7, spike=Fals
     return _cmp(out, ref, dtype)
 
 
+def attention_general_case(B, H, Lq, Lk, Dqk, Dv, dtype, *, causal=False, spike=False, seed=170):
+    """softmax(Q K^T / sqrt(Dqk) [causal]) V with Dqk != Dv allowed, against torch in fp32."""
+    q = _rand(B, Lq, H * Dqk, dtype=dtype, seed=seed)
+    k = _rand(B, Lk, H * Dqk, dtype=dtype, seed=seed + 1)
+    v = _rand(B, Lk, H * Dv, dtype=dtype, seed=seed + 2)
+    if spike:
+        k[:, Lk - 3] *= 6.0
+        k[:, Lk // 2] *= 4.0
+    Lkp = (Lk + 63) // 64 * 64
+    qh = q.float().reshape(B, Lq, H, Dqk).transpose(1, 2)
+    kh = k.float().reshape(B, Lk, H, Dqk).transpose(1, 2)
+    vh = v.float().reshape(B, Lk, H, Dv).transpose(1, 2)
+    logits = qh @ kh.transpose(-1, -2) / math.sqrt(Dqk)
+    if causal:
+        keep = torch.ones(Lq, Lk, dtype=torch.bool, device=q.device).tril()
+        logits = logits.masked_fill(~keep, float("-inf"))
+    ref = (torch.softmax(logits, dim=-1) @ vh).transpose(1, 2).reshape(B, Lq, H * Dv)
+    out = torch.full((B, Lq, H * Dv), float("nan"), dtype=dtype, device=DEV)
+    native.attention_general(q, k, _vt_from_v(v, Lkp), out, H, Lk, causal=causal)
+    return _cmp(out, ref, dtype)
+
+
+def attention_relpos_case(B, H, gh, gw, D, dtype, seed=180):
+    """SegmentAnything-style decomposed relative position bias folded into extra QK columns:
+    logits[q, (kh, kw)] = scale * q.k + rel_h[q, kh] + rel_w[q, kw]   (image_encoder.py:82-127)."""
+    L = gh * gw
+    scale = D ** -0.5
+    q = _rand(B, L, H * D, dtype=dtype, seed=seed)
+    k = _rand(B, L, H * D, dtype=dtype, seed=seed + 1)
+    v = _rand(B, L, H * D, dtype=dtype, seed=seed + 2)
+    rel_h = _rand(B, H, L, gh, dtype=dtype, seed=seed + 3)
+    rel_w = _rand(B, H, L, gw, dtype=dtype, seed=seed + 4)
+    qh = q.float().reshape(B, L, H, D).transpose(1, 2)
+    kh = k.float().reshape(B, L, H, D).transpose(1, 2)
+    vh = v.float().reshape(B, L, H, D).transpose(1, 2)
+    bias = (rel_h.float()[..., :, None] + rel_w.float()[..., None, :]).reshape(B, H, L, L)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale + bias, dim=-1) @ vh).transpose(1, 2).reshape(B, L, H * D)
+    Dq = (D + gh + gw + 7) // 8 * 8
+    qa = torch.zeros(B, L, H, Dq, dtype=dtype, device=DEV)
+    ka = torch.zeros(B, L, H, Dq, dtype=dtype, device=DEV)
+    qa[..., :D] = (q.reshape(B, L, H, D).float() * scale).to(dtype)
+    qa[..., D : D + gh] = rel_h.transpose(1, 2)
+    qa[..., D + gh : D + gh + gw] = rel_w.transpose(1, 2)
+    ka[..., :D] = k.reshape(B, L, H, D)
+    idx = torch.arange(L, device=DEV)
+    ka[:, idx, :, D + idx // gw] = 1
+    ka[:, idx, :, D + gh + idx % gw] = 1
+    out = torch.full((B, L, H * D), float("nan"), dtype=dtype, device=DEV)
+    Lkp = (L + 63) // 64 * 64
+    native.attention_general(qa.reshape(B, L, H * Dq), ka.reshape(B, L, H * Dq), _vt_from_v(v, Lkp), out, H, L, scale=1.0)
+    if dtype == torch.bfloat16:  # q * scale is rounded to bf16 once more than in the reference: compare with that rounding applied
+        qs = (q.reshape(B, L, H, D).float() * scale).to(dtype).float().transpose(1, 2)
+        ref = (torch.softmax(qs @ kh.transpose(-1, -2) + bias, dim=-1) @ vh).transpose(1, 2).reshape(B, L, H * D)
+    return _cmp(out, ref, dtype)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 def layernorm_case(M, Cc, dtype, seed=80):
     x = _rand(M, Cc, dtype=dtype, seed=seed) * 2 + 0.5
@@ -374,6 +430,18 @@ def all_cases():
             (f"attn_{tag}_cross_77", lambda dt=dt: attention_case(2, 10, 1024, 77, dt)),
             (f"attn_{tag}_cross_77_ip4", lambda dt=dt: attention_case(2, 10, 512, 77, dt, ip_tokens=4)),
             (f"attn_{tag}_Lq_edge_200", lambda dt=dt: attention_case(1, 2, 200, 128, dt)),
+            (f"attng_{tag}_d40_self", lambda dt=dt: attention_general_case(2, 8, 1024, 1024, 40, 40, dt)),
+            (f"attng_{tag}_d40_cross77", lambda dt=dt: attention_general_case(2, 8, 320, 77, 40, 40, dt)),
+            (f"attng_{tag}_d80_self", lambda dt=dt: attention_general_case(2, 8, 256, 256, 80, 80, dt, spike=True)),
+            (f"attng_{tag}_d160_self", lambda dt=dt: attention_general_case(2, 8, 64, 64, 160, 160, dt)),
+            (f"attng_{tag}_d160_cross77", lambda dt=dt: attention_general_case(1, 8, 200, 77, 160, 160, dt)),
+            (f"attng_{tag}_d128", lambda dt=dt: attention_general_case(1, 4, 130, 190, 128, 128, dt)),
+            (f"attng_{tag}_d64_causal", lambda dt=dt: attention_general_case(2, 12, 77, 77, 64, 64, dt, causal=True)),
+            (f"attng_{tag}_d80_causal_long", lambda dt=dt: attention_general_case(1, 4, 300, 300, 80, 80, dt, causal=True)),
+            (f"attng_{tag}_qk112_v80", lambda dt=dt: attention_general_case(2, 4, 196, 196, 112, 80, dt)),
+            (f"attng_{tag}_qk208_v80", lambda dt=dt: attention_general_case(1, 2, 512, 512, 208, 80, dt)),
+            (f"attng_{tag}_relpos_14x14", lambda dt=dt: attention_relpos_case(2, 4, 14, 14, 80, dt)),
+            (f"attng_{tag}_relpos_32x32", lambda dt=dt: attention_relpos_case(1, 2, 32, 32, 80, dt)),
             (f"layernorm_{tag}_640", lambda dt=dt: layernorm_case(1000, 640, dt)),
             (f"layernorm_{tag}_1280", lambda dt=dt: layernorm_case(2048, 1280, dt)),
             (f"groupnorm_{tag}_320_4096", lambda dt=dt: groupnorm_case(2, 320, 4096, dt)),

@@ -267,6 +267,17 @@ def test_sam_vit_h_float32_matches_reference():
         print(f"sam {k}: l2 {l2:.2e} max {mx:.2e}")
         assert l2 < F32_TOL and mx < F32_TOL, (k, l2, mx)
     print("sam launches", fast.stats["step_ops"], "fallbacks", len(fast.stats["fallback_nodes"]))
+    assert fast.stats["fallback_nodes"] == []  # the relative-position attention runs on mi355x_attention_general
+    # bf16 storage, same weights and image: norm-wise against the float32 golden
+    vit.to(dtype=torch.bfloat16)
+    fast16 = CompiledSAMViT(vit)
+    neck16 = fast16(image.to(torch.bfloat16))
+    early16 = vit.layer(("Transformer", 7), torch.nn.Module).use_context("hq_sam")["early_vit_embedding"]
+    got16 = sam_sample(neck16.float().cpu(), early16.float().cpu())
+    for k in ("neck", "early"):
+        l2, mx = S.rel_err(got16[k], gold[k])
+        print(f"sam bf16 {k}: l2 {l2:.2e} max {mx:.2e}")
+        assert l2 < 3e-2, (k, l2, mx)
 
 
 def test_vae_decoder_matches_reference():

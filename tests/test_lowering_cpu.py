@@ -91,9 +91,11 @@ def test_merged_lora_mode_adds_no_step_launch():
     assert len(low.step) == 981 and low.stats["lora_sites"] == 722 and low.stats["ip_sites"] == 70
 
 
-def test_sd1_tree_lowers_with_torch_sdpa_for_its_head_dims():
+def test_sd1_tree_lowers_onto_the_general_attention_kernel_for_its_head_dims():
     low = _dry(SD1UNet(4, device="meta"), 1, 32, 32, torch.float32, {("cross_attention_block", "clip_text_embedding"): (77, 768)}, pooled=False)
-    assert Counter(low.stats["fallback_nodes"]) == Counter({"SDPA(head_dim=40)": 10, "SDPA(head_dim=80)": 10, "SDPA(head_dim=160)": 12})
+    assert low.stats["fallback_nodes"] == []
+    names = Counter(op[2] for op in low.step)
+    assert names["mi355x_attention_general"] == 32 and names["mi355x_attention"] == 0
 
 
 def test_inputs_are_read_where_the_context_store_keeps_them():
