@@ -83,3 +83,7 @@ def sam_sample(neck_out, early):
 
 # ------------------------------------------------------------------------------------------------ next-1: VAE decode
 VAE_CASE = dict(weight_seed=0, input_seed=13, latent_hw=(16, 24), latent_std=0.13)
+
+
+# ------------------------------------------------------------------------------------------------ next-2: prompt encoder
+CLIP_CASE = dict(weight_seed=0, prompts=("a photograph of an astronaut riding a horse on mars, highly detailed, 4k, dramatic lighting", ""))

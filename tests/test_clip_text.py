@@ -1,0 +1,58 @@
+"""Prompt encoder: CPU oracle and host mirror vs the real reference's DoubleTextEncoder;
+the re-implemented BPE tokenizer vs the reference's (build container only: needs the vocabulary file)."""
+import json
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import clip_oracle
+from refiners_amd import synth
+from refiners_amd.clip import CLIPTokenizer
+from refiners_amd.latent_diffusion.text_encoder import DoubleTextEncoder
+from tests import support as S
+from tests.golden_cases import CLIP_CASE
+
+TOL = 2e-4
+REF_VOCAB = Path("/root/reference/src/refiners/foundationals/clip/bpe_simple_vocab_16e6.txt.gz")
+
+
+@pytest.fixture(scope="module")
+def clip_inputs():
+    shapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "double_text_encoder_keys.json").read_text()).items()}
+    return shapes, synth.synth_state_dict(shapes, CLIP_CASE["weight_seed"]), S.golden("double_text_encoder")
+
+
+def test_prompt_encoder_oracle_matches_reference(clip_inputs):
+    _, sd, gold = clip_inputs
+    emb, pooled = clip_oracle.double_text_encoder(sd, gold["tokens_l"], gold["tokens_g"])
+    for got, want in ((emb, gold["text_embedding"]), (pooled, gold["pooled"])):
+        l2, mx = S.rel_err(got, want)
+        assert l2 < TOL and mx < TOL, (l2, mx)
+
+
+def test_prompt_encoder_mirror_matches_reference(clip_inputs):
+    shapes, sd, gold = clip_inputs
+    enc = DoubleTextEncoder(device="meta")
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == shapes and list(enc.state_dict()) == list(shapes)
+    enc.load_state_dict(sd, assign=True)
+    # feed the golden token ids through the tree below the tokenizers (the vocabulary file does not travel)
+    for tok in [m for m in enc.modules() if isinstance(m, CLIPTokenizer)]:
+        tok.forward = (lambda t: (lambda _text: gold["tokens_g" if t.pad_token_id == 0 else "tokens_l"].long()))(tok)  # type: ignore[method-assign]
+    with torch.no_grad():
+        emb, pooled = enc(list(CLIP_CASE["prompts"]))
+    for got, want in ((emb, gold["text_embedding"]), (pooled, gold["pooled"])):
+        l2, mx = S.rel_err(got, want)
+        assert l2 < TOL and mx < TOL, (l2, mx)
+
+
+@pytest.mark.skipif(not REF_VOCAB.is_file(), reason="needs the CLIP BPE vocabulary that ships with refiners")
+def test_tokenizer_matches_reference_token_ids():
+    gold = S.golden("double_text_encoder")
+    for pad, key in ((49407, "tokens_l"), (0, "tokens_g")):
+        tok = CLIPTokenizer(vocabulary_path=REF_VOCAB, pad_token_id=pad)
+        assert torch.equal(tok(list(CLIP_CASE["prompts"])).to(torch.int32), gold[key])
+    tok = CLIPTokenizer(vocabulary_path=REF_VOCAB)
+    # known-answer ids of openai/CLIP's tokenizer for a few words (start, ..., end)
+    assert tok.encode("a cute cat").tolist() == [49406, 320, 2242, 2368, 49407]
+    assert tok("hello world").shape == (1, 77) and int(tok("x" * 500).shape[1]) == 77
