@@ -68,7 +68,8 @@ int mi355x_device_info(char* buf, int32_t buflen);
  * unless geglu, where value/gate rows are interleaved in groups of 32 so that one lane holds both).
  * Long-K / small-MN problems (the 32x32-resolution convolutions: 320 tiles, K = 11520) can be split along K (`ksplit`).
  * Epilogue order: + bias[n] ; + rowbias[(m / rows_per_group)*ld_rowbias + n] ; geglu: v = a * gelu_erf(g) ;
- * (or v = gelu_erf(v) when geglu == 2: fl.GeLU, src/refiners/fluxion/layers/activations.py:83-125) ;
+ * (or v = gelu_erf(v) when geglu == 2, v = v * sigmoid(1.702 v) when geglu == 3: fl.GeLU with approximation NONE / SIGMOID,
+ * src/refiners/fluxion/layers/activations.py:83-125) ;
  * + res[m*ldres + n] ; convert to dtype ; store out[m*ldo + n].
  */
 #define MI355X_MAX_SEG 3
@@ -100,7 +101,7 @@ typedef struct {
     const void* rowbias;    /* [M / rows_per_group][ld_rowbias] or NULL (RangeAdapter2d time-embedding bias) */
     int64_t ld_rowbias;
     int32_t rows_per_group;
-    int32_t geglu;          /* epilogue activation: 0 none, 1 GEGLU (value * gelu_erf(gate), packed rows), 2 gelu_erf on every column */
+    int32_t geglu;          /* epilogue activation: 0 none, 1 GEGLU (value * gelu_erf(gate), packed rows), 2 gelu_erf, 3 quick-GELU on every column */
     const void* res;        /* [M][ldres] or NULL */
     int64_t ldres;
     const void* zeros;      /* >= 256 zero bytes in device memory; required when conv == 1 */

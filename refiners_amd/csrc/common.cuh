@@ -103,6 +103,8 @@ MI_DEV int xcd_remap(int bid, int nblk) {
 // would be denormal are flushed to 0, which is what an online softmax wants.
 MI_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 MI_DEV float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// CLIP's "quick GELU" (GeLUApproximation.SIGMOID, fluxion/layers/activations.py:83-118)
+MI_DEV float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 MI_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // 16-byte vector of T, for epilogues and elementwise kernels.

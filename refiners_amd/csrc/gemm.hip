@@ -40,7 +40,7 @@ struct GemmP {
     int64_t ld_rowbias;  // elements
     int rows_per_group;
     int geglu;
-    int gelu;  // plain erf-GELU on every output column (after bias / row bias, before the residual)
+    int gelu;  // activation on every output column (after bias / row bias, before the residual): 1 = erf-GELU, 2 = x * sigmoid(1.702 x)
     const char* res;
     int64_t ldres;  // elements
     const char* zeros;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
             }
             if (p.gelu) {
 #pragma unroll
-                for (int e = 0; e < RUN; ++e) v[e] = gelu_exact(v[e]);
+                for (int e = 0; e < RUN; ++e) v[e] = p.gelu == 1 ? gelu_exact(v[e]) : quick_gelu(v[e]);
             }
             if (p.geglu) {
                 if constexpr (NT == 4) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                     float val = v[e];
                     if (bias) val += to_f32(bias[nn]);
                     if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
-                    if (p.gelu) val = gelu_exact(val);
+                    if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
                     if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
                     out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
                 }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
             float val = v[r];
             if (bias) val += to_f32(bias[nn]);
             if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
-            if (p.gelu) val = gelu_exact(val);
+            if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
             if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
             out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
         }
@@ -582,7 +582,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     p.ld_rowbias = a->ld_rowbias;
     p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
     p.geglu = a->geglu == 1 ? 1 : 0;
-    p.gelu = a->geglu == 2 ? 1 : 0;
+    p.gelu = a->geglu == 2 ? 1 : (a->geglu == 3 ? 2 : 0);
     p.res = static_cast<const char*>(a->res);
     p.ldres = a->ldres;
     p.zeros = static_cast<const char*>(a->zeros);

@@ -478,7 +478,7 @@ class Lowering:
         return out
 
     # -- attention ---------------------------------------------------------------------------------------------
-    def _split_attention(self, att: Any) -> tuple[list[Any], Any, Any, Optional[Any]]:
+    def _split_attention(self, att: Any, allow_causal: bool = False) -> tuple[list[Any], Any, Any, Optional[Any]]:
         """Attention | SelfAttention | CrossAttentionAdapter(Attention) -> ([q, k, v nodes], sdpa-like, out node, ip)."""
         if isa(att, "CrossAttentionAdapter"):
             att = kids(att)[0]
@@ -494,7 +494,7 @@ class Lowering:
             sc = kids(sd)
             _expect(len(sc) == 2 and isa(sc[0], "ScaledDotProductAttention") and isa(sc[1], "ImageCrossAttention"), "unexpected Sum around SDPA")
             ip, sd = sc[1], sc[0]
-        _expect(isa(sd, "ScaledDotProductAttention") and not sd.is_causal, "causal or unknown SDPA node")
+        _expect(isa(sd, "ScaledDotProductAttention") and (allow_causal or not sd.is_causal), "causal or unknown SDPA node")
         _expect(sd.num_heads == att.num_heads, "head count mismatch")
         return kids(ch[0]), sd, ch[2], ip
 

@@ -396,7 +396,7 @@ def gemm(
         sg.ksize, sg.stride, sg.ups, sg.H, sg.W = 1, 1, 1, 0, 0
         keep.append((x, w))
     assert not (geglu and gelu)
-    _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, 2 if gelu else geglu)
+    _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, (3 if gelu == "quick" else 2) if gelu else geglu)
     _fill_split(a, tile, ksplit, ws)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm")
     return out
@@ -470,7 +470,7 @@ def _fill_epilogue(a: GemmArgs, out: Tensor, bias, rowbias, rows_per_group, res,
         a.res, a.ldres = res.data_ptr(), res.stride(0)
     else:
         a.res, a.ldres = None, 0
-    a.geglu = int(geglu)  # 0 none, 1 GEGLU, 2 GELU
+    a.geglu = int(geglu)  # 0 none, 1 GEGLU, 2 GELU (erf), 3 quick GELU
 
 
 def attention(

@@ -355,6 +355,17 @@ def cfg_ddim_case(n, dtype, seed=120):
     return _cmp(x, ref, dtype)
 
 
+def gemm_quick_gelu_case(M, K, N, dtype, seed=36):
+    """CLIP-L's FeedForward activation, x * sigmoid(1.702 x) (GeLUApproximation.SIGMOID), as the GEMM epilogue."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, w)], out, bias=b, gelu="quick")
+    y = x.float() @ w.float().t() + b.float()
+    return _cmp(out, y * torch.sigmoid(1.702 * y), dtype)
+
+
 def gemm_gelu_case(M, K, N, dtype, seed=35):
     x = _rand(M, K, dtype=dtype, seed=seed)
     w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
@@ -454,6 +465,7 @@ def all_cases():
             (f"cfg_ddim_{tag}", lambda dt=dt: cfg_ddim_case(4 * 128 * 128, dt)),
             (f"gemm_{tag}_gelu_res_1000x640x384", lambda dt=dt: gemm_gelu_case(1000, 640, 384, dt)),
             (f"gemm_{tag}_gelu_Nedge", lambda dt=dt: gemm_gelu_case(300, 640, 200, dt)),
+            (f"gemm_{tag}_quick_gelu_154x768x3072", lambda dt=dt: gemm_quick_gelu_case(154, 768, 3072, dt)),
             (f"patchify_gather_{tag}", lambda dt=dt: patchify_gather_case(dt)),
             (f"sinusoidal_{tag}_timestep", lambda dt=dt: sinusoidal_case(2, 320, 1, dt)),
             (f"sinusoidal_{tag}_time_ids", lambda dt=dt: sinusoidal_case(12, 256, 6, dt)),

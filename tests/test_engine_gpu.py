@@ -341,3 +341,48 @@ def test_vae_encoder_matches_reference():
     l2, mx = S.rel_err(lat, S.golden("vae_encode")["latents"])
     print(f"vae encode f32: l2 {l2:.2e} max {mx:.2e} launches {fast.stats['step_ops']} fallbacks {fast.stats['fallback_nodes']}")
     assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+
+
+def test_prompt_encoder_matches_reference():
+    """SDXL's DoubleTextEncoder (CLIP-L + CLIP-G, causal attention) on the engine, from
+    the reference tokenizer's token ids; float32 vs the real reference's output, bf16 norm-wise vs the same."""
+    import json
+
+    from refiners_amd.engine.text import CompiledDoubleTextEncoder
+    from refiners_amd.latent_diffusion.text_encoder import DoubleTextEncoder
+    from tests.golden_cases import CLIP_CASE
+
+    shapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "double_text_encoder_keys.json").read_text()).items()}
+    sd = S.synth.synth_state_dict(shapes, CLIP_CASE["weight_seed"])
+    gold = S.golden("double_text_encoder")
+    for dtype, tol in ((torch.float32, F32_TOL), (torch.bfloat16, 3e-2)):
+        enc = DoubleTextEncoder(device="meta")
+        enc.load_state_dict({k: v.to("cuda", dtype) for k, v in sd.items()}, assign=True)
+        fast = CompiledDoubleTextEncoder(enc)
+        emb, pooled = fast(tokens=(gold["tokens_l"], gold["tokens_g"]))
+        assert emb.shape == (2, 77, 2048) and pooled.shape == (2, 1280) and fast.stats["fallback_nodes"] == []
+        for name, got, want in (("text_embedding", emb, gold["text_embedding"]), ("pooled", pooled, gold["pooled"])):
+            l2, mx = S.rel_err(got.float().cpu(), want)
+            print(f"prompt encoder {dtype} {name}: l2 {l2:.2e} max {mx:.2e} launches {fast.stats['step_ops']}")
+            assert l2 < tol, (dtype, name, l2, mx)
+            if dtype == torch.float32:
+                assert mx < tol
+        # a second call with other token ids reuses the program (same shapes) and must not see stale inputs
+        emb2, _ = fast(tokens=(gold["tokens_l"].flip(0), gold["tokens_g"].flip(0)))
+        l2, _ = S.rel_err(emb2.float().cpu(), gold["text_embedding"].flip(0))
+        assert l2 < tol
+        if dtype == torch.bfloat16:  # informational: engine vs the unfused torch tree on the same GPU
+            import time
+
+            toks = (gold["tokens_l"].cuda(), gold["tokens_g"].cuda())
+            for tk in [m for m in enc.modules() if type(m).__name__ == "CLIPTokenizer"]:
+                tk.forward = (lambda t: (lambda _text: (toks[1] if t.pad_token_id == 0 else toks[0]).long()))(tk)
+            for fn, label in ((lambda: fast(tokens=toks), "engine"), (lambda: enc(["a", "b"]), "unfused torch")):
+                with torch.no_grad():
+                    fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize()
+                print(f"prompt encoder bf16 {label}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms for 2 prompts")

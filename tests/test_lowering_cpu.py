@@ -126,3 +126,18 @@ def test_scale_and_structure_changes_move_the_tree_epoch():
     adapter.eject()
     e3 = tree_epoch()
     assert e0 < e1 < e2 < e3
+
+
+def test_prompt_encoder_lowers_without_fallbacks():
+    """DoubleTextEncoder (CLIP-L + CLIP-G) -> 395 launches, 43 causal attentions, nothing left on torch."""
+    from refiners_amd.engine.text import TextLowering
+    from refiners_amd.latent_diffusion.text_encoder import DoubleTextEncoder
+
+    dev, dt = torch.device("meta"), torch.bfloat16
+    enc = DoubleTextEncoder(device="meta", dtype=dt)
+    ti = lambda n: torch.empty(n, device=dev, dtype=torch.int32)  # noqa: E731
+    low = TextLowering(dev, dt, None, "merged")
+    low.lower_double(enc, ti(154), ti(154), ti(2), 2, 77, torch.empty(154, 2048, device=dev, dtype=dt), torch.empty(2, 1280, device=dev, dtype=dt))
+    names = Counter(op[2] for op in low.step)
+    assert names["mi355x_attention_general"] == 43 and names["mi355x_layernorm"] == 87 and low.stats["fallback_nodes"] == []
+    assert all(op[0] is not None for op in low.step)  # no Python glue in the program
