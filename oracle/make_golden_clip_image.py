@@ -1,0 +1,42 @@
+"""Golden vectors for the IP-Adapter image-prompt encoder: the REAL reference's
+CLIPImageEncoderH + ImageProjection (SDXL widths) on CPU float32, synthetic per-key weights, one 224x224 image.
+Run in the build container only:  python oracle/make_golden_clip_image.py"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT / "oracle" / "shim"), "/root/reference/src", str(ROOT)]
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+from refiners.foundationals.clip.image_encoder import CLIPImageEncoderH  # noqa: E402
+from refiners.foundationals.latent_diffusion.image_prompt import ImageProjection  # noqa: E402
+
+from refiners_amd import synth  # noqa: E402
+from tests.golden_cases import CLIP_IMAGE_CASE  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+
+def main() -> None:
+    enc = CLIPImageEncoderH(device="meta")
+    proj = ImageProjection(clip_image_embedding_dim=1024, clip_text_embedding_dim=2048, num_tokens=4, device="meta")
+    shapes, pshapes = synth.model_shapes(enc), synth.model_shapes(proj)
+    (GOLD / "clip_image_h_keys.json").write_text(json.dumps({"encoder": {k: list(v) for k, v in shapes.items()}, "image_proj": {k: list(v) for k, v in pshapes.items()}}))
+    enc.load_state_dict(synth.synth_state_dict(shapes, CLIP_IMAGE_CASE["weight_seed"]), assign=True)
+    proj.load_state_dict(synth.synth_state_dict(pshapes, CLIP_IMAGE_CASE["weight_seed"] + 1), assign=True)
+    image = torch.randn((1, 3, 224, 224), generator=synth._gen("clip.image", CLIP_IMAGE_CASE["input_seed"]))
+    with torch.no_grad():
+        emb = enc(image)
+        # IPAdapter._compute_clip_image_embedding + compute_clip_image_embedding (image_prompt.py:457-510), one image
+        tokens = torch.cat((proj(torch.zeros_like(emb)), proj(emb)))
+    save_file({"embedding": emb.contiguous(), "clip_image_embedding": tokens.contiguous()}, str(GOLD / "clip_image_h.safetensors"))
+    print(tuple(emb.shape), tuple(tokens.shape), float(emb.std()), float(tokens.std()))
+
+
+if __name__ == "__main__":
+    main()

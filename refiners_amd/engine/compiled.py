@@ -34,6 +34,26 @@ def _ident(t: Optional[Tensor]) -> Any:
     return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
 
 
+class Program:
+    """A lowered launch list replayed directly the first time and as ONE HIP graph afterwards (every buffer is static)."""
+
+    def __init__(self, ops: list, use_graph: bool) -> None:
+        self.ops, self.use_graph = ops, use_graph
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def run(self) -> None:
+        if self.use_graph and self.graph is not None:
+            self.graph.replay()
+            return
+        native.replay(self.ops)  # also the warm-up: first-launch work (function attributes) must not be captured
+        if self.use_graph:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                native.replay(self.ops)
+            self.graph = g
+
+
 class CompiledUNet:
     def __init__(self, unet: Any, use_graph: bool = True, lora_mode: str = "fused") -> None:
         native.load()  # fail loudly: there is no fallback for a missing HIP library

@@ -31,6 +31,7 @@ from torch import Tensor
 
 from .. import native
 from ..fluxion.tree import tree_epoch
+from .compiled import Program
 from .lowering import Act, Lowering, PackCache, Unsupported, _expect, cname, isa, kids
 
 
@@ -263,10 +264,11 @@ class CompiledSAMViT:
     """`fast = CompiledSAMViT(vit); embedding = fast(image)` == `vit(image)`; with a SAMViTAdapter injected the early ViT
     embedding is written to context "hq_sam".early_vit_embedding exactly like the SetContext node does."""
 
-    def __init__(self, vit: Any, lora_mode: str = "merged") -> None:
+    def __init__(self, vit: Any, lora_mode: str = "merged", use_graph: bool = True) -> None:
         native.load()
         self.vit = vit
         self.lora_mode = lora_mode
+        self.use_graph = use_graph
         self.cache = PackCache()
         self.key: Any = None
         self.stats: dict[str, Any] = {}
@@ -292,9 +294,11 @@ class CompiledSAMViT:
             low.lower(self.vit, self.x, self.out, self.early)
             self.cache.sweep()
             self.low, self.key = low, key
+            # the torch fallback of an attention (un-merged LoRA, odd shapes) allocates: not capturable
+            self.program = Program(low.step, self.use_graph and not low.stats["fallback_nodes"])
             self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
         self.x.copy_(image)
-        native.replay(self.low.step)
+        self.program.run()
         hook = self._hook()
         if hook is not None:
             hook(self.early.clone())  # SetContext.__call__: stores into the parent's context, as the unfused tree does

@@ -24,6 +24,7 @@ from torch import Tensor
 
 from .. import native
 from ..fluxion.tree import tree_epoch
+from .compiled import Program
 from .lowering import Lowering, PackCache, _expect, cname, isa, kids
 
 
@@ -41,11 +42,12 @@ class TextLowering(Lowering):
         native.axpby(x, 1.0, pos, 1.0, x)
         return x
 
-    def causal_self_attention(self, x: Tensor, B: int, L: int, ln: Any, att: Any) -> Tensor:
-        """x += W_o causal-SDPA(W_q h + b_q, W_k h + b_k, W_v h + b_v) + b_o, h = LN(x)   (clip/text_encoder.py:41-54,
-        fluxion/layers/attentions.py:319-385)."""
+    def biased_self_attention(self, x: Tensor, B: int, L: int, ln: Any, att: Any) -> Tensor:
+        """x += W_o SDPA(W_q h + b_q, W_k h + b_k, W_v h + b_v) + b_o, h = LN(x); causal for the text encoders
+        (clip/text_encoder.py:41-54), bidirectional for the image encoders (clip/image_encoder.py:80-84);
+        fluxion/layers/attentions.py:319-385."""
         (qn, kn, vn), sd, on, ip = self._split_attention(att, allow_causal=True)
-        _expect(ip is None and bool(sd.is_causal), "expected a plain causal SelfAttention")
+        _expect(ip is None, "expected a plain SelfAttention")
         heads = sd.num_heads
         M, C = x.shape
         d = C // heads
@@ -74,7 +76,7 @@ class TextLowering(Lowering):
         o = self.pool.get(M, C)
         q3 = qk.as_strided((B, L, C), (L * qk.stride(0), qk.stride(0), 1))
         k3 = qk[:, C:].as_strided((B, L, C), (L * qk.stride(0), qk.stride(0), 1))
-        native.attention_general(q3, k3, vt.view(C, B, lkp), o.view(B, L, C), heads, L, causal=True)
+        native.attention_general(q3, k3, vt.view(C, B, lkp), o.view(B, L, C), heads, L, causal=bool(sd.is_causal))
         self.pool.put(qk)
         if lkp == L:
             self.pool.put(vt)
@@ -107,7 +109,7 @@ class TextLowering(Lowering):
         _expect(len(ch) == 2 and all(isa(c, "Residual") for c in ch), "unexpected TransformerLayer layout")
         r1, r2 = kids(ch[0]), kids(ch[1])
         _expect(len(r1) == 2 and isa(r1[0], "LayerNorm") and isa(r1[1], "SelfAttention") and len(r2) == 2 and isa(r2[0], "LayerNorm"), "unexpected TransformerLayer residuals")
-        x = self.causal_self_attention(x, B, L, r1[0], r1[1])
+        x = self.biased_self_attention(x, B, L, r1[0], r1[1])
         return self.feed_forward_gelu(x, r2[0], r2[1])
 
     def encoder_body(self, nodes: Sequence[Any], x: Optional[Tensor], tokens: Tensor, B: int, L: int) -> Tensor:
@@ -177,10 +179,11 @@ class CompiledDoubleTextEncoder:
     """`fast = CompiledDoubleTextEncoder(double_text_encoder); emb, pooled = fast(prompts)` == `double_text_encoder(prompts)`
     ((B, 77, 2048), (B, 1280)); `fast(tokens=(tokens_l, tokens_g))` skips the host tokenizers."""
 
-    def __init__(self, enc: Any, lora_mode: str = "merged") -> None:
+    def __init__(self, enc: Any, lora_mode: str = "merged", use_graph: bool = True) -> None:
         native.load()
         self.enc = enc
         self.lora_mode = lora_mode
+        self.use_graph = use_graph
         self.cache = PackCache()
         self.key: Any = None
         self.stats: dict[str, Any] = {}
@@ -213,24 +216,25 @@ class CompiledDoubleTextEncoder:
             low = TextLowering(dev, dtype, self.cache, self.lora_mode)
             low.lower_double(self.enc, self.tok_l, self.tok_g, self.eot, B, L, self.emb, self.pooled)
             self.cache.sweep()
-            self.low, self.key = low, key
+            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
             self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
         self.tok_l.copy_(tok_l.reshape(-1))
         self.tok_g.copy_(tok_g.reshape(-1))
         # first end-of-text position per prompt (TextEncoderWithPooling.set_end_of_text_index, xl/text_encoder.py:48-51)
         first = (tok_g == tg.end_of_text_token_id).to(torch.int32).argmax(dim=1).to(torch.int32)
         self.eot.copy_(first + torch.arange(B, device=dev, dtype=torch.int32) * L)
-        native.replay(self.low.step)
+        self.program.run()
         return self.emb.view(B, L, -1).clone(), self.pooled.clone()
 
 
 class CompiledTextEncoder:
     """`fast = CompiledTextEncoder(clip_text_encoder); hidden = fast(prompts)` == `clip_text_encoder(prompts)` (B, 77, C)."""
 
-    def __init__(self, enc: Any, lora_mode: str = "merged") -> None:
+    def __init__(self, enc: Any, lora_mode: str = "merged", use_graph: bool = True) -> None:
         native.load()
         self.enc = enc
         self.lora_mode = lora_mode
+        self.use_graph = use_graph
         self.cache = PackCache()
         self.key: Any = None
         self.stats: dict[str, Any] = {}
@@ -249,8 +253,8 @@ class CompiledTextEncoder:
             low = TextLowering(dev, dtype, self.cache, self.lora_mode)
             low.lower_encoder(self.enc, self.tok, B, L, self.out)
             self.cache.sweep()
-            self.low, self.key = low, key
+            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
             self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
         self.tok.copy_(tok.reshape(-1))
-        native.replay(self.low.step)
+        self.program.run()
         return self.out.view(B, L, -1).clone()

@@ -87,3 +87,4 @@ VAE_CASE = dict(weight_seed=0, input_seed=13, latent_hw=(16, 24), latent_std=0.1
 
 # ------------------------------------------------------------------------------------------------ next-2: prompt encoder
 CLIP_CASE = dict(weight_seed=0, prompts=("a photograph of an astronaut riding a horse on mars, highly detailed, 4k, dramatic lighting", ""))
+CLIP_IMAGE_CASE = dict(weight_seed=0, input_seed=21)

@@ -56,3 +56,45 @@ def test_tokenizer_matches_reference_token_ids():
     # known-answer ids of openai/CLIP's tokenizer for a few words (start, ..., end)
     assert tok.encode("a cute cat").tolist() == [49406, 320, 2242, 2368, 49407]
     assert tok("hello world").shape == (1, 77) and int(tok("x" * 500).shape[1]) == 77
+
+
+# ------------------------------------------------------------------------------------------------ image prompt side
+@pytest.fixture(scope="module")
+def image_inputs():
+    from tests.golden_cases import CLIP_IMAGE_CASE
+
+    keys = json.loads((S.GOLD / "clip_image_h_keys.json").read_text())
+    shapes = {k: tuple(v) for k, v in keys["encoder"].items()}
+    pshapes = {k: tuple(v) for k, v in keys["image_proj"].items()}
+    sd = synth.synth_state_dict(shapes, CLIP_IMAGE_CASE["weight_seed"])
+    psd = synth.synth_state_dict(pshapes, CLIP_IMAGE_CASE["weight_seed"] + 1)
+    image = torch.randn((1, 3, 224, 224), generator=synth._gen("clip.image", CLIP_IMAGE_CASE["input_seed"]))
+    return shapes, pshapes, sd, psd, image, S.golden("clip_image_h")
+
+
+def test_image_prompt_oracle_matches_reference(image_inputs):
+    _, _, sd, psd, image, gold = image_inputs
+    emb = clip_oracle.clip_image_encoder(sd, image)
+    l2, mx = S.rel_err(emb, gold["embedding"])
+    assert l2 < TOL and mx < TOL, (l2, mx)
+    l2, mx = S.rel_err(clip_oracle.image_prompt_tokens(psd, emb), gold["clip_image_embedding"])
+    assert l2 < TOL and mx < TOL, (l2, mx)
+
+
+def test_image_prompt_mirror_matches_reference(image_inputs):
+    from refiners_amd.clip_image import CLIPImageEncoderH
+    from refiners_amd.latent_diffusion.adapters import ImageProjection
+
+    shapes, pshapes, sd, psd, image, gold = image_inputs
+    enc = CLIPImageEncoderH(device="meta")
+    proj = ImageProjection(clip_image_embedding_dim=1024, clip_text_embedding_dim=2048, num_tokens=4, device="meta")
+    assert list(enc.state_dict()) == list(shapes) and {k: tuple(v.shape) for k, v in enc.state_dict().items()} == shapes
+    assert {k: tuple(v.shape) for k, v in proj.state_dict().items()} == pshapes
+    enc.load_state_dict(sd, assign=True)
+    proj.load_state_dict(psd, assign=True)
+    with torch.no_grad():
+        emb = enc(image)
+        tokens = torch.cat((proj(torch.zeros_like(emb)), proj(emb)))
+    for got, want in ((emb, gold["embedding"]), (tokens, gold["clip_image_embedding"])):
+        l2, mx = S.rel_err(got, want)
+        assert l2 < TOL and mx < TOL, (l2, mx)

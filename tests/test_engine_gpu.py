@@ -386,3 +386,36 @@ def test_prompt_encoder_matches_reference():
                         fn()
                     torch.cuda.synchronize()
                 print(f"prompt encoder bf16 {label}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms for 2 prompts")
+
+
+def test_image_prompt_encoder_matches_reference():
+    """CLIPImageEncoderH + ImageProjection on the engine (IP-Adapter image prompt ->
+    the (2, 4, 2048) [negative ; conditional] tokens); float32 vs the real reference's output, bf16 norm-wise."""
+    import json
+
+    from refiners_amd.clip_image import CLIPImageEncoderH
+    from refiners_amd.engine.image_prompt import CompiledImagePrompt
+    from refiners_amd.latent_diffusion.adapters import ImageProjection
+    from tests.golden_cases import CLIP_IMAGE_CASE
+
+    keys = json.loads((S.GOLD / "clip_image_h_keys.json").read_text())
+    sd = S.synth.synth_state_dict({k: tuple(v) for k, v in keys["encoder"].items()}, CLIP_IMAGE_CASE["weight_seed"])
+    psd = S.synth.synth_state_dict({k: tuple(v) for k, v in keys["image_proj"].items()}, CLIP_IMAGE_CASE["weight_seed"] + 1)
+    image = torch.randn((1, 3, 224, 224), generator=S.synth._gen("clip.image", CLIP_IMAGE_CASE["input_seed"])).cuda()
+    gold = S.golden("clip_image_h")
+    for dtype, tol in ((torch.float32, F32_TOL), (torch.bfloat16, 3e-2)):
+        enc = CLIPImageEncoderH(device="meta")
+        enc.load_state_dict({k: v.to("cuda", dtype) for k, v in sd.items()}, assign=True)
+        proj = ImageProjection(clip_image_embedding_dim=1024, clip_text_embedding_dim=2048, num_tokens=4, device="meta")
+        proj.load_state_dict({k: v.to("cuda", dtype) for k, v in psd.items()}, assign=True)
+        emb = CompiledImagePrompt(enc)(image.to(dtype))
+        fast = CompiledImagePrompt(enc, proj)
+        tokens = fast(image.to(dtype))
+        tokens_again = fast(image.to(dtype))  # second call = HIP-graph replay of the same program
+        assert torch.equal(tokens, tokens_again) and fast.stats["fallback_nodes"] == []
+        for name, got, want in (("embedding", emb, gold["embedding"]), ("clip_image_embedding", tokens, gold["clip_image_embedding"])):
+            l2, mx = S.rel_err(got.float().cpu(), want)
+            print(f"image prompt {dtype} {name}: l2 {l2:.2e} max {mx:.2e} launches {fast.stats['step_ops']}")
+            assert l2 < tol, (dtype, name, l2, mx)
+            if dtype == torch.float32:
+                assert mx < tol

@@ -141,3 +141,19 @@ def test_prompt_encoder_lowers_without_fallbacks():
     names = Counter(op[2] for op in low.step)
     assert names["mi355x_attention_general"] == 43 and names["mi355x_layernorm"] == 87 and low.stats["fallback_nodes"] == []
     assert all(op[0] is not None for op in low.step)  # no Python glue in the program
+
+
+def test_image_prompt_encoder_lowers_without_fallbacks():
+    """CLIPImageEncoderH + ImageProjection -> 265 launches, 32 bidirectional attentions over 257 tokens (heads of 80)."""
+    from refiners_amd.clip_image import CLIPImageEncoderH
+    from refiners_amd.engine.image_prompt import ImagePromptLowering
+    from refiners_amd.latent_diffusion.adapters import ImageProjection
+
+    dev, dt = torch.device("meta"), torch.bfloat16
+    enc, proj = CLIPImageEncoderH(device="meta", dtype=dt), ImageProjection(1024, 2048, 4, device="meta", dtype=dt)
+    low = ImagePromptLowering(dev, dt, None, "merged")
+    both = torch.empty(2, 1024, device=dev, dtype=dt)
+    low.lower_image_encoder(enc, torch.empty(1, 3, 224, 224, device=dev, dtype=dt), torch.empty(1, device=dev, dtype=torch.int32), both[1:])
+    low.lower_image_projection(proj, both, torch.empty(8, 2048, device=dev, dtype=dt))
+    names = Counter(op[2] for op in low.step)
+    assert names["mi355x_attention_general"] == 32 and low.stats["fallback_nodes"] == [] and all(op[0] is not None for op in low.step)
