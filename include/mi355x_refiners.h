@@ -73,6 +73,7 @@ int mi355x_device_info(char* buf, int32_t buflen);
  * + res[m*ldres + n] ; convert to dtype ; store out[m*ldo + n].
  */
 #define MI355X_MAX_SEG 3
+#define MI355X_MAX_PREFETCH 2
 
 typedef struct {
     const void* x;
@@ -111,6 +112,13 @@ typedef struct {
                                applies the epilogue.  Not combinable with geglu. */
     void* ws;               /* split-K scratch, >= ksplit * M * N * 4 bytes, 16-byte aligned (ignored unless ksplit > 1) */
     int64_t ws_bytes;
+    /* Optional weight prefetch for LATER launches: up to MI355X_MAX_PREFETCH read-only byte spans (weights that launches after this one will stream).
+       `prefetch_blocks` extra workgroups of this launch (rounded up to a multiple of 8; 0 = library default) touch one word per 64
+       bytes so that those lines sit in the 256 MB Infinity Cache by the time they are needed: SDXL reads 5.1 GB of weights once
+       per step, i.e. every kernel would otherwise start on HBM misses.  No effect on the result. */
+    const void* prefetch[MI355X_MAX_PREFETCH];
+    int64_t prefetch_bytes[MI355X_MAX_PREFETCH];
+    int32_t prefetch_blocks;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

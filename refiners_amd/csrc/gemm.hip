@@ -48,6 +48,12 @@ struct GemmP {
     int ksplit, kb_per_split, grid0;  // split-K: ksplit workgroups per tile, each accumulating kb_per_split K blocks
     float* partial;                   // [ksplit][M][N] float32 partial sums (split-K only)
     int tile_hint;                    // 0 = heuristic, 1..5 = caller's choice
+    int krot;                         // debug: rotate each workgroup's K-block order (single-segment, non-split launches)
+    // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
+    // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
+    const char* pf_ptr[MI355X_MAX_PREFETCH];
+    int64_t pf_bytes[MI355X_MAX_PREFETCH];
+    int pf_blocks, pf_mode;           // pf_mode: 1 = plain loads, 2 = non-temporal loads (L2 evict-first)
     int pn, hm, hn;  // XCD rasterisation: the 8 XCDs own a pm x pn grid of hm x hn-tile regions
     int vec_ok;
 };
@@ -69,8 +75,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int wm = wid / WN, wn = wid % WN;
     // XCD-aware rasterisation: workgroup b runs on XCD b % 8 (observed dispatch rule, a speed assumption only); each XCD
     // owns one rectangular region of the tile grid so that its private L2 sees as few distinct operand rows as possible.
-    const int split = p.ksplit > 1 ? blockIdx.x / p.grid0 : 0;
-    const int bx = blockIdx.x - split * p.grid0;
+    if ((int)blockIdx.x < p.pf_blocks) {  // prefetch role (see GemmP::pf_ptr): one 4-byte read per 64 bytes, 8 independent loads in flight
+        int acc = 0;
+        const int64_t stride = (int64_t)p.pf_blocks * NTHR * 64;
+        constexpr int U = 8;
+#pragma unroll
+        for (int sp = 0; sp < MI355X_MAX_PREFETCH; ++sp) {
+            const char* base = p.pf_ptr[sp];
+            const int64_t bytes = base ? p.pf_bytes[sp] : 0;
+            for (int64_t off = ((int64_t)blockIdx.x * NTHR + tid) * 64; off < bytes; off += stride * U) {
+                int v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t o = off + u * stride;
+                    const int* src = reinterpret_cast<const int*>(base + (o < bytes ? o : off));
+                    v[u] = p.pf_mode == 2 ? __builtin_nontemporal_load(src) : *src;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc ^= v[u];
+            }
+        }
+        if (acc == 0x5a5a1234 && p.pf_bytes[0] < 0) *reinterpret_cast<int*>(p.out) = acc;  // never taken: keeps the loads alive
+        return;
+    }
+    const int bid = blockIdx.x - p.pf_blocks;
+    const int split = p.ksplit > 1 ? bid / p.grid0 : 0;
+    const int bx = bid - split * p.grid0;
     int tm, tn;
     if (p.pn > 0) {  // rectangular regions (exact split of the tile grid, grid0 = 8 * hm * hn)
         const int xcd = bx & 7, idx = bx >> 3;
@@ -131,6 +161,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     int seg = 0, kb = 0;  // kb = block index inside the current segment
     int total_kb = 0;
     for (int s = 0; s < p.nseg; ++s) total_kb += p.seg[s].nkb;
+    // K rotation: workgroups that run concurrently on one XCD start at different K blocks (and wrap around), so that at any
+    // instant they read different 128-byte columns of the operand rows instead of all hammering the same L2 channels
+    const bool rotate = p.krot && p.nseg == 1 && p.ksplit == 1;
+    if (rotate) kb = ((bx >> 3) * p.krot) % total_kb;
     if (p.ksplit > 1) {  // this workgroup's share of the K blocks: [first, first + total_kb)
         const int first = split * p.kb_per_split;
         total_kb = min(p.kb_per_split, total_kb - first);
@@ -179,7 +213,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         // advance
         if (++kb == sp.nkb) {
             kb = 0;
-            ++seg;
+            if (!rotate) ++seg;
         }
     };
     auto compute = [&](int buf) {
@@ -384,6 +418,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
     }
 }
 
+int g_pf_blocks = 64;  // default number of prefetch workgroups when the caller gives spans but no count (0 = prefetch off)
+int g_pf_mode = 1;    // 1 = plain loads, 2 = non-temporal
+
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int ABL = 0>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
     constexpr int LDS = NSTAGE * (BM + BN) * 128;
@@ -426,7 +463,13 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
         }
     }
     q.grid0 = q.tiles_m * q.tiles_n;
-    const int grid = q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
+    bool any_pf = false;
+    for (int i = 0; i < MI355X_MAX_PREFETCH; ++i) any_pf = any_pf || (q.pf_ptr[i] && q.pf_bytes[i] > 0);
+    if (!any_pf || g_pf_blocks == 0) q.pf_blocks = 0;
+    else if (q.pf_blocks <= 0) q.pf_blocks = g_pf_blocks;
+    q.pf_blocks = (q.pf_blocks + 7) / 8 * 8;  // a multiple of 8: compute block b still lands on XCD b % 8
+    q.pf_mode = g_pf_mode;
+    const int grid = q.pf_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64), LDS, stream, q);
     if (q.ksplit > 1) {
         const int64_t work = (int64_t)q.M * ((q.N + 3) / 4);
@@ -439,6 +482,7 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
 
 int g_tile = 0;    // 0 = heuristic, 1..4 = force a tile configuration (probing / A-B runs)
 int g_stages = 0;  // 0 = heuristic, 2..4 = force the LDS pipeline depth
+int g_krot = 0;    // 0 = off, n = workgroup i of an XCD starts its K loop at block (i * n) % nkb
 
 // Tile configurations (all 4 waves, 2 x 2):  1: 128x128   2: 128x64   3: 64x128   4: 64x64
 // The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
@@ -524,6 +568,15 @@ extern "C" int mi355x_set_option(const char* name, int value) {
         g_stages = value;
         return MI355X_OK;
     }
+    if (name && name[0] == 'p') {  // "pfblocks" / "pfmode"
+        if (name[2] == 'b') g_pf_blocks = value < 0 ? 0 : (value + 7) / 8 * 8;
+        else g_pf_mode = value;
+        return MI355X_OK;
+    }
+    if (name && name[0] == 'k') {  // "krot"
+        g_krot = value;
+        return MI355X_OK;
+    }
     if (name && name[0] == 't') {  // "tile"
         g_tile = value;
         return MI355X_OK;
@@ -593,6 +646,12 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     p.vec_ok = vec ? 1 : 0;
     if (p.geglu && (!vec || a->N % 64)) return MI355X_ESHAPE;
     p.tile_hint = a->tile;
+    p.krot = g_krot;
+    for (int i = 0; i < MI355X_MAX_PREFETCH; ++i) {
+        p.pf_ptr[i] = static_cast<const char*>(a->prefetch[i]);
+        p.pf_bytes[i] = a->prefetch[i] ? a->prefetch_bytes[i] : 0;
+    }
+    p.pf_blocks = a->prefetch_blocks;
     p.ksplit = 1;
     p.partial = nullptr;
     if (a->ksplit > 1) {

@@ -18,6 +18,8 @@ reason is recorded in `.stats["fallback_nodes"]` (node-level torch fallback) or 
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Optional
 
 import torch
@@ -37,9 +39,12 @@ def _ident(t: Optional[Tensor]) -> Any:
 class Program:
     """A lowered launch list replayed directly the first time and as ONE HIP graph afterwards (every buffer is static)."""
 
-    def __init__(self, ops: list, use_graph: bool) -> None:
+    def __init__(self, ops: list, use_graph: bool, weight_prefetch: Optional[bool] = None) -> None:
         self.ops, self.use_graph = ops, use_graph
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        if weight_prefetch is None:
+            weight_prefetch = os.environ.get("REFINERS_AMD_WEIGHT_PREFETCH", "1") != "0"
+        self.prefetch = native.link_weight_prefetch(ops, enable=weight_prefetch)  # every GEMM pulls the next one's weights into the Infinity Cache
 
     def run(self) -> None:
         if self.use_graph and self.graph is not None:
@@ -60,6 +65,7 @@ class CompiledUNet:
         self.unet = unet
         self.use_graph = use_graph
         self.lora_mode = lora_mode  # see Lowering.__init__
+        self.weight_prefetch = os.environ.get("REFINERS_AMD_WEIGHT_PREFETCH", "1") != "0"
         self.cache = PackCache()
         self.low: Optional[UNetLowering] = None
         self.io: Optional[UNetIO] = None
@@ -113,8 +119,12 @@ class CompiledUNet:
         low = UNetLowering(dev, dtype, self.cache, self.lora_mode)
         low.lower(self.unet, io)
         self.cache.sweep()
+        # the step program is replayed step after step: let every GEMM / conv pull the weights of the launches behind it into
+        # the Infinity Cache (weights are read exactly once per step, so otherwise every kernel starts on DRAM misses)
+        pf = native.link_weight_prefetch(low.step, enable=self.weight_prefetch)
         self.low, self.io, self.graph, self.prologue_key = low, io, None, None
-        self.stats = dict(low.stats, step_ops=len(low.step), prologue_ops=len(low.prologue), pool_bytes=low.step_pool.bytes() + low.prologue_pool.bytes())
+        self.stats = dict(low.stats, step_ops=len(low.step), prologue_ops=len(low.prologue), pool_bytes=low.step_pool.bytes() + low.prologue_pool.bytes(),
+                          weight_prefetch=pf)
 
     def _out_channels(self) -> int:
         last = [m for m in self.unet.modules() if isa(m, "Conv2d")][-1]

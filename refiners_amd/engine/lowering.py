@@ -418,7 +418,7 @@ class Lowering:
         if spec.lora is not None:
             t = self.lora_down(x, spec.lora)
             segs.append((spec.lora.bs_cat, t))
-        native.gemm(segs, out_t)
+        native.gemm(segs, out_t, weight_operand="x")
         self.pool.put(t)
         return out_t
 

@@ -213,7 +213,7 @@ class SAMLowering(Lowering):
         lkp = (L + 63) // 64 * 64
         if lkp == L:
             vt = self.pool.get(C, Mw)
-            native.gemm([(packs["wv"], h)], vt)
+            native.gemm([(packs["wv"], h)], vt, weight_operand="x")
         else:
             # every window's V^T columns start on a 64-key boundary: a second gather of the SAME LayerNorm output with
             # the windows padded to lkp rows (zero rows -> zero V^T columns, which masked keys multiply by exactly 0)
@@ -221,7 +221,7 @@ class SAMLowering(Lowering):
             hv = self.pool.get(n * lkp, C)
             native.gather_rows(h_full, part_v, hv)
             vt = self.pool.get(C, n * lkp)
-            native.gemm([(packs["wv"], hv)], vt)
+            native.gemm([(packs["wv"], hv)], vt, weight_operand="x")
             self.pool.put(hv)
         att = self.pool.get(Mw, C)
         native.attention_general(q.view(n, L, H * Dq), k.view(n, L, H * Dq), vt.view(C, n, lkp), att.view(n, L, C), H, L, scale=1.0)

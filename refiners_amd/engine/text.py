@@ -66,12 +66,12 @@ class TextLowering(Lowering):
         lkp = self._pad_keys(L)
         if lkp == L:
             vt = self.pool.get(C, M)
-            native.gemm([(vs.w, h)], vt)
+            native.gemm([(vs.w, h)], vt, weight_operand="x")
         else:  # every sample's V^T columns start on a 64-key boundary; the padding is zeroed once, here
             vt = torch.zeros(C, B * lkp, device=self.device, dtype=self.dtype)
             self.__dict__.setdefault("_keep", []).append(vt)
             for b in range(B):
-                native.gemm([(vs.w, h[b * L : (b + 1) * L])], vt[:, b * lkp : b * lkp + L])
+                native.gemm([(vs.w, h[b * L : (b + 1) * L])], vt[:, b * lkp : b * lkp + L], weight_operand="x")
         self.pool.put(h)
         o = self.pool.get(M, C)
         q3 = qk.as_strided((B, L, C), (L * qk.stride(0), qk.stride(0), 1))

@@ -43,6 +43,9 @@ class GemmSeg(C.Structure):
     ]
 
 
+MAX_PREFETCH = 2  # == MI355X_MAX_PREFETCH
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32),
@@ -68,6 +71,9 @@ class GemmArgs(C.Structure):
         ("ksplit", C.c_int32),
         ("ws", C.c_void_p),
         ("ws_bytes", C.c_int64),
+        ("prefetch", C.c_void_p * MAX_PREFETCH),
+        ("prefetch_bytes", C.c_int64 * MAX_PREFETCH),
+        ("prefetch_blocks", C.c_int32),
     ]
 
 
@@ -379,9 +385,15 @@ def gemm(
     tile: int = 0,
     ksplit: int = 1,
     ws: Optional[Tensor] = None,
+    prefetch: Optional[Tensor] = None,
+    weight_operand: str = "w",
 ) -> Tensor:
-    """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s])."""
+    """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
+    weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch."""
     a = GemmArgs()
+    a.weight_is_x = weight_operand == "x"
+    if prefetch is not None:
+        a.prefetch[0], a.prefetch_bytes[0] = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     x0, w0 = segs[0]
     a.dtype = dtype_code(x0.dtype)
     a.M = M if M is not None else x0.shape[0]
@@ -445,6 +457,49 @@ def conv_gemm(
     _fill_split(a, tile, ksplit, ws)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm(conv)")
     return out
+
+
+def weight_spans(a: GemmArgs) -> list[tuple[int, int]]:
+    """(address, bytes) of the weight operands of a recorded GEMM / conv launch, one per K segment: N rows of ldw elements
+    (or, for a launch recorded with weight_operand="x" -- the transposed projections -- M rows of ldx elements)."""
+    es = 4 if a.dtype == 0 else 2
+    out = []
+    for s in range(a.nseg):
+        sg = a.seg[s]
+        if getattr(a, "weight_is_x", False):
+            out.append((int(sg.x or 0), int(a.M) * int(sg.ldx) * es))
+        else:
+            out.append((int(sg.w or 0), int(a.N) * int(sg.ldw) * es))
+    return out
+
+
+def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 19, bytes_per_block: int = 128 << 10, min_blocks: int = 32,
+                         max_blocks: int = 128) -> dict:
+    """Post-pass over a recorded program that is replayed again and again (a denoising step, an encoder): every GEMM / conv
+    launch gets the weight operands of the NEXT GEMM / conv launch as its `prefetch` spans (the last one wraps around to the
+    first).  Weights are read exactly once per replay from HBM (5.1 GB per SDXL step), so without this every kernel starts on
+    cold lines and its short K loop cannot hide DRAM latency: in place, launches run 25-40 % slower than the same launch on
+    hot weights; with the weights pulled into the Infinity Cache one launch ahead the step is 7-8 % shorter
+    (tools/probe_prefetch.py, tools/probe_step.py, profiles/r01_t*).  A burst of 32-128 prefetch workgroups at the head of
+    the grid beats a thin continuous stream: one workgroup sustains only ~20 GB/s of misses."""
+    gemms = [e[1][0]._obj for e in ops if e[0] is not None and e[2].startswith("mi355x_gemm")]
+    linked = nbytes_total = 0
+    for i, a in enumerate(gemms):
+        for s in range(MAX_PREFETCH):
+            a.prefetch[s], a.prefetch_bytes[s] = None, 0
+        a.prefetch_blocks = 0
+        if not enable or len(gemms) < 2:
+            continue
+        spans = [(p, b) for p, b in weight_spans(gemms[(i + 1) % len(gemms)]) if p and b >= min_bytes][:MAX_PREFETCH]
+        if not spans:
+            continue
+        for s, (p, b) in enumerate(spans):
+            a.prefetch[s], a.prefetch_bytes[s] = p, b
+        total = sum(b for _, b in spans)
+        a.prefetch_blocks = max(min_blocks, min(max_blocks, -(-total // bytes_per_block)))
+        linked += 1
+        nbytes_total += total
+    return {"linked": linked, "bytes": nbytes_total, "launches": len(gemms)}
 
 
 def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor]) -> None:
