@@ -278,6 +278,7 @@ def main() -> None:
         "roofline": roofline, "cpu_baseline": cpu,
         "extra": {"params": n_params, "launches_per_step": pipe.engine.stats["step_ops"], "prologue_launches": pipe.engine.stats["prologue_ops"],
                   "fallback_nodes": pipe.engine.stats["fallback_nodes"], "arena_bytes": pipe.engine.stats["pool_bytes"],
+                  "weight_prefetch": pipe.engine.stats.get("weight_prefetch"),
                   "weights_broadcast_s": round(bcast_s, 3), "broadcast_launches": n_bcast, "setup_s": round(setup_s, 1),
                   "output_finite": finite, "device": native.device_info(),
                   "throughput_operating_point": batched,

@@ -42,9 +42,10 @@ struct AttnP {
     int qtiles;
 };
 
-template <typename T, int NW, int NSTREAM, bool GLDS>
+template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
-    constexpr int D = 64, BKV = 64, BQW = 32;
+    // NJQ = 16-query groups per wave (2 = 32 queries; 1 = 16 queries: twice the waves per query, for launches too small to fill the chip)
+    constexpr int D = 64, BKV = 64, BQW = 16 * NJQ;
     constexpr int ES = sizeof(T);
     constexpr int ROWB = D * ES;  // K rows and V^T rows have the same byte length (D == BKV)
     constexpr int CPR = ROWB / 16;
@@ -71,9 +72,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     const int q0 = qt * (BQW * NW) + wid * BQW;
 
     // ---- Q fragments (B operand), straight from global ----
-    frag_t qf[2][NS];
+    frag_t qf[NJQ][NS];
 #pragma unroll
-    for (int jq = 0; jq < 2; ++jq) {
+    for (int jq = 0; jq < NJQ; ++jq) {
         int qr = q0 + 16 * jq + c16;
         qr = qr < p.Lq ? qr : p.Lq - 1;
         const char* qp = p.q + (int64_t)b * p.qbsb + (int64_t)qr * p.ldqb + (int64_t)h * ROWB;
@@ -93,12 +94,12 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     }
     frag_t kr[LI], vr[LI];
 
-    f32x4 res[4][2];
+    f32x4 res[4][NJQ];
     if constexpr (NSTREAM > 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jq = 0; jq < 2; ++jq) res[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int jq = 0; jq < NJQ; ++jq) res[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
 #pragma unroll
@@ -139,13 +140,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
             }
         };
 
-        f32x4 o[4][2];
+        f32x4 o[4][NJQ];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jq = 0; jq < 2; ++jq) o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float mrun[2] = {-INFINITY, -INFINITY};
-        float lsum[2] = {0.f, 0.f};
+            for (int jq = 0; jq < NJQ; ++jq) o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float mrun[NJQ], lsum[NJQ];
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) mrun[jq] = -INFINITY, lsum[jq] = 0.f;
 
         // all waves must be done reading LDS of the previous stream before it is overwritten
         __syncthreads();
@@ -179,16 +181,16 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
             const char* vs = ks + TILEB;
 
             // ---- S^T = K Q^T ----
-            f32x4 st[4][2];
+            f32x4 st[4][NJQ];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                st[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                st[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jq = 0; jq < NJQ; ++jq) st[t][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const frag_t kf = lds_read_frag(ks, tile_off<ROWB>(16 * t + c16, 4 * s + g));
-                    mma_step<T>(st[t][0], kf, qf[0][s]);
-                    mma_step<T>(st[t][1], kf, qf[1][s]);
+#pragma unroll
+                    for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(st[t][jq], kf, qf[jq][s]);
                 }
             }
             // ---- mask the tail tile ----
@@ -199,14 +201,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (kv0 + 16 * t + 4 * g + r >= Lk) {
-                            st[t][0][r] = -INFINITY;
-                            st[t][1][r] = -INFINITY;
+#pragma unroll
+                            for (int jq = 0; jq < NJQ; ++jq) st[t][jq][r] = -INFINITY;
                         }
                     }
             }
             // ---- online softmax (per lane: one query column per jq) ----
 #pragma unroll
-            for (int jq = 0; jq < 2; ++jq) {
+            for (int jq = 0; jq < NJQ; ++jq) {
                 float mx = st[0][jq][0];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -235,9 +237,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
             if constexpr (IS_BF16) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    frag_t pb[2];
+                    frag_t pb[NJQ];
 #pragma unroll
-                    for (int jq = 0; jq < 2; ++jq) {
+                    for (int jq = 0; jq < NJQ; ++jq) {
                         bf16x8 pk;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -254,20 +256,18 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                         const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
                         const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
                         const frag_t vf = frag_t{va[0], va[1], vb[0], vb[1]};
-                        mma_step<T>(o[i][0], vf, pb[0]);
-                        mma_step<T>(o[i][1], vf, pb[1]);
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, pb[jq]);
                     }
                 }
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const frag_t p0 = __builtin_bit_cast(frag_t, st[t][0]);
-                    const frag_t p1 = __builtin_bit_cast(frag_t, st[t][1]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const frag_t vf = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * t + g));
-                        mma_step<T>(o[i][0], vf, p0);
-                        mma_step<T>(o[i][1], vf, p1);
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, __builtin_bit_cast(frag_t, st[t][jq]));
                     }
                 }
             }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
 
         // ---- finish this stream ----
 #pragma unroll
-        for (int jq = 0; jq < 2; ++jq) {
+        for (int jq = 0; jq < NJQ; ++jq) {
             float l = lsum[jq];
             l += __shfl_xor(l, 16);
             l += __shfl_xor(l, 32);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     // ---- store: lane owns d = 16g + 4i + r (16 consecutive) of query 16jq + c16 ----
     constexpr int EPC = DT<T>::EPC;
 #pragma unroll
-    for (int jq = 0; jq < 2; ++jq) {
+    for (int jq = 0; jq < NJQ; ++jq) {
         const int qr = q0 + 16 * jq + c16;
         if (qr >= p.Lq) continue;
         T* op = reinterpret_cast<T*>(p.out + (int64_t)b * p.obsb + (int64_t)qr * p.ldob + (int64_t)h * ROWB) + 16 * g;
@@ -317,17 +317,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
 
 int g_attn_glds = 0;  // register-staged K/V loader by default: measured faster than glds for attention (probe_attn3)
 
-template <typename T, int NW, int NSTREAM, bool GLDS>
+template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ = 2>
 int launch_attn(const AttnP& p0, hipStream_t stream) {
     constexpr int LDS = (GLDS ? 3 : 2) * 2 * 64 * 64 * sizeof(T);
-    auto kfn = attn_kernel<T, NW, NSTREAM, GLDS>;
+    auto kfn = attn_kernel<T, NW, NSTREAM, GLDS, NJQ>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     AttnP p = p0;
-    p.qtiles = (p.Lq + 32 * NW - 1) / (32 * NW);
+    p.qtiles = (p.Lq + 16 * NJQ * NW - 1) / (16 * NJQ * NW);
     const int grid = p.qtiles * p.H * p.B;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
@@ -347,9 +347,10 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
 
 template <typename T>
 int launch_attn_t(const AttnP& p, hipStream_t stream) {
-    // 128-query workgroups unless that leaves the 256 CUs with fewer than two workgroups each
-    int nw = g_attn_nw;
-    if (nw != 2 && nw != 4) nw = 4;  // 2-wave workgroups never won on MI355X (profiles/r01_c_probe_attention.log)
+    int nw = g_attn_nw;  // 2 / 4: waves of 32 queries; 14 / 18: 4 / 8 waves of 16 queries
+    if (nw == 0) nw = 4;  // 2-wave workgroups never won on MI355X (profiles/r01_c_probe_attention.log)
+    if (nw == 14) return p.nstream == 2 ? launch_attn<T, 4, 2, false, 1>(p, stream) : launch_attn<T, 4, 1, false, 1>(p, stream);
+    if (nw == 18) return p.nstream == 2 ? launch_attn<T, 8, 2, false, 1>(p, stream) : launch_attn<T, 8, 1, false, 1>(p, stream);
     return nw == 2 ? launch_attn_nw<T, 2>(p, stream) : launch_attn_nw<T, 4>(p, stream);
 }
 

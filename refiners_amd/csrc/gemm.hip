@@ -487,18 +487,32 @@ int g_krot = 0;    // 0 = off, n = workgroup i of an XCD starts its K loop at bl
 // Tile configurations (all 4 waves, 2 x 2):  1: 128x128   2: 128x64   3: 64x128   4: 64x64
 // The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
 // how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.
+int g_alt = 0;  // probing: alternative tile / stage heuristics
+inline int pick_stages_default(const GemmP&, int);
 inline int pick_tile(const GemmP& p, bool conv) {
     // measured on MI355X over the UNet's shapes (tools/probe_gemm.py, profiles/r01_b_probe_gemm_tiles.log)
     if (g_tile >= 1 && g_tile <= 5) return g_tile;
     if (p.tile_hint >= 1 && p.tile_hint <= 5) return p.tile_hint;
     const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (g_alt >= 1 && g_alt <= 3 && !conv && !p.geglu && b128 <= 256) {  // probing: the N = 1280 class of the SDXL step
+        int total_kb = 0;
+        for (int s = 0; s < p.nseg; ++s) total_kb += p.seg[s].nkb;
+        if (g_alt != 3 || total_kb >= 64) return 3;
+    }
     if (conv) return 3;  // 64 x 128 wins for every conv shape of the UNet (r01_b probe: 339 / 540 / 570 TF at 32^2 / 64^2 / 128^2)
     if (p.geglu) return 1;
     if (b128 <= 256) return 4;
     if (b128 < 1000) return 2;
     return 1;
 }
-inline int pick_stages(const GemmP&, int) {
+inline int pick_stages(const GemmP& p, int tile) {
+    if (g_stages == 0 && (g_alt == 1 || g_alt == 3) && tile == 3 && !p.geglu && p.seg[0].ksize == 1 && p.seg[0].stride == 1) {
+        const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        if (b128 <= 256) return 3;
+    }
+    return pick_stages_default(p, tile);
+}
+inline int pick_stages_default(const GemmP&, int) {
     // two LDS stages everywhere: deeper pipelines cost a resident workgroup per CU (LDS), and on these short-K GEMMs
     // co-resident workgroups hide latency better than prefetch depth does (same probe).
     if (g_stages >= 2 && g_stages <= 4) return g_stages;
@@ -571,6 +585,10 @@ extern "C" int mi355x_set_option(const char* name, int value) {
     if (name && name[0] == 'p') {  // "pfblocks" / "pfmode"
         if (name[2] == 'b') g_pf_blocks = value < 0 ? 0 : (value + 7) / 8 * 8;
         else g_pf_mode = value;
+        return MI355X_OK;
+    }
+    if (name && name[0] == 'h') {  // "heur"
+        g_alt = value;
         return MI355X_OK;
     }
     if (name && name[0] == 'k') {  // "krot"

@@ -30,11 +30,10 @@ def main():
 
     native.link_weight_prefetch(ops, enable=False)
     print(f"no prefetch: {t():.2f} ms", flush=True)
-    for kw in (dict(), dict(min_blocks=64), dict(min_blocks=128, max_blocks=128), dict(bytes_per_block=64 << 10, max_blocks=256)):
-        st = native.link_weight_prefetch(ops, **kw)
-        print(f"prefetch {kw}: {t():.2f} ms  {st}", flush=True)
-    native.link_weight_prefetch(ops, enable=False)
-    print(f"no prefetch again: {t():.2f} ms", flush=True)
+    native.link_weight_prefetch(ops)
+    for alt in (0, 1, 2, 3, 0):
+        native.load().mi355x_set_option(b"heur", alt)
+        print(f"prefetch on, heuristic alternative {alt}: {t():.2f} ms", flush=True)
 
 
 if __name__ == "__main__":
