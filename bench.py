@@ -71,8 +71,8 @@ def op_flops(entry) -> float:
 def pmc_traffic(family: str):
     """HBM-side bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are
     separate profiler runs, they cannot be taken inside this process): FETCH_SIZE doubled per MI355X_MICROARCH.md, KiB -> B."""
-    f = ROOT / "profiles" / "r01_g_pmc_traffic.json"
     try:
+        f = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]  # the latest committed pass
         fam = json.loads(f.read_text())["families"][family]
         return {"fetch_bytes_per_launch": round(fam["FETCH_SIZE"]["bytes_per_launch"]), "write_bytes_per_launch": round(fam["WRITE_SIZE"]["bytes_per_launch"]),
                 "source": f"profiles/{f.name}"}
@@ -105,6 +105,7 @@ def main() -> None:
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informational extras (VAE decode, 4-images-per-GPU point): for profiler passes")
     ap.add_argument("--lora-mode", choices=["fused", "merged"], default="merged",
                     help="merged: W' = W + sum s B A formed at lowering time (one launch per adapted layer); fused: run-time LoRA K segments")
     args = ap.parse_args()
@@ -227,6 +228,8 @@ def main() -> None:
     # ---- next-1 (outside the metric): VAE decode of the finished latents, for an end-to-end images/s figure ---------
     vae_ms = None
     try:
+        if args.no_extra:
+            raise RuntimeError("skipped (--no-extra)")
         from refiners_amd.engine.vae import CompiledVAEDecoder
         from refiners_amd.latent_diffusion.vae import SDXLAutoencoder
 
@@ -246,7 +249,7 @@ def main() -> None:
 
     # ---- throughput-oriented operating point (outside the metric): 4 images per GPU through the same engine -------------
     batched = None
-    if world == 1 and n_img == 1 and args.workload == "bare":
+    if world == 1 and n_img == 1 and args.workload == "bare" and not args.no_extra:
         try:
             inp4 = synth.sdxl_inputs(4, LATENT, seed=300)
             pipe4 = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=not args.no_graph, lora_mode=args.lora_mode)

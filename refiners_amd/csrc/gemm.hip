@@ -75,7 +75,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int wm = wid / WN, wn = wid % WN;
     // XCD-aware rasterisation: workgroup b runs on XCD b % 8 (observed dispatch rule, a speed assumption only); each XCD
     // owns one rectangular region of the tile grid so that its private L2 sees as few distinct operand rows as possible.
-    if ((int)blockIdx.x < p.pf_blocks) {  // prefetch role (see GemmP::pf_ptr): one 4-byte read per 64 bytes, 8 independent loads in flight
+    const int pf_first = p.pf_mode >= 3 ? (int)gridDim.x - p.pf_blocks : 0;  // pf_mode 3: prefetchers at the tail of the grid (probe)
+    if ((int)blockIdx.x >= pf_first && (int)blockIdx.x < pf_first + p.pf_blocks) {  // prefetch role (see GemmP::pf_ptr): one 4-byte read per 64 bytes, 8 independent loads in flight
         int acc = 0;
         const int64_t stride = (int64_t)p.pf_blocks * NTHR * 64;
         constexpr int U = 8;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         for (int sp = 0; sp < MI355X_MAX_PREFETCH; ++sp) {
             const char* base = p.pf_ptr[sp];
             const int64_t bytes = base ? p.pf_bytes[sp] : 0;
-            for (int64_t off = ((int64_t)blockIdx.x * NTHR + tid) * 64; off < bytes; off += stride * U) {
+            for (int64_t off = ((int64_t)(blockIdx.x - pf_first) * NTHR + tid) * 64; off < bytes; off += stride * U) {
                 int v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         if (acc == 0x5a5a1234 && p.pf_bytes[0] < 0) *reinterpret_cast<int*>(p.out) = acc;  // never taken: keeps the loads alive
         return;
     }
-    const int bid = blockIdx.x - p.pf_blocks;
+    const int bid = p.pf_mode >= 3 ? (int)blockIdx.x : (int)blockIdx.x - p.pf_blocks;
     const int split = p.ksplit > 1 ? bid / p.grid0 : 0;
     const int bx = bid - split * p.grid0;
     int tm, tn;

@@ -31,9 +31,10 @@ def main():
     native.link_weight_prefetch(ops, enable=False)
     print(f"no prefetch: {t():.2f} ms", flush=True)
     native.link_weight_prefetch(ops)
-    for alt in (0, 1, 2, 3, 0):
-        native.load().mi355x_set_option(b"heur", alt)
-        print(f"prefetch on, heuristic alternative {alt}: {t():.2f} ms", flush=True)
+    for mode in (1, 3, 1, 3):
+        native.load().mi355x_set_option(b"pfmode", mode)
+        print(f"prefetch workgroups at the {'head' if mode == 1 else 'tail'} of the grid: {t():.2f} ms", flush=True)
+    native.load().mi355x_set_option(b"pfmode", 1)
 
 
 if __name__ == "__main__":
