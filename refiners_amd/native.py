@@ -460,16 +460,18 @@ def conv_gemm(
 
 
 def weight_spans(a: GemmArgs) -> list[tuple[int, int]]:
-    """(address, bytes) of the weight operands of a recorded GEMM / conv launch, one per K segment: N rows of ldw elements
-    (or, for a launch recorded with weight_operand="x" -- the transposed projections -- M rows of ldx elements)."""
+    """(address, bytes) of the weight operands of a recorded GEMM / conv launch, one per K segment: N rows of ldw elements,
+    the last row counted to its K-th element only (the operand may be a column slice of a wider tensor); for a launch
+    recorded with weight_operand="x" -- the transposed projections -- M rows of ldx elements."""
     es = 4 if a.dtype == 0 else 2
     out = []
     for s in range(a.nseg):
         sg = a.seg[s]
+        k = int(sg.k) * (int(sg.ksize) ** 2 if a.conv else 1)
         if getattr(a, "weight_is_x", False):
-            out.append((int(sg.x or 0), int(a.M) * int(sg.ldx) * es))
+            out.append((int(sg.x or 0), ((int(a.M) - 1) * int(sg.ldx) + k) * es))
         else:
-            out.append((int(sg.w or 0), int(a.N) * int(sg.ldw) * es))
+            out.append((int(sg.w or 0), ((int(a.N) - 1) * int(sg.ldw) + k) * es))
     return out
 
 

@@ -355,6 +355,24 @@ def cfg_ddim_case(n, dtype, seed=120):
     return _cmp(x, ref, dtype)
 
 
+def gemm_prefetch_case(M, K, N, dtype, ksplit=1, seed=37):
+    """mi355x_gemm_args.prefetch: extra workgroups at the head of the grid touch another buffer; the tile -> workgroup mapping is
+    shifted by them, the result must be bit-identical to the launch without prefetch (also under split-K)."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2)
+    r = _rand(M, N, dtype=dtype, seed=seed + 3)
+    other = _rand(1237, 129, dtype=dtype, seed=seed + 4)  # a span whose size is no multiple of anything
+    ws = torch.empty(max(ksplit, 1) * M * N, dtype=torch.float32, device=DEV) if ksplit > 1 else None
+    out0 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    out1 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, w)], out0, bias=b, res=r, ksplit=ksplit, ws=ws)
+    native.gemm([(x, w)], out1, bias=b, res=r, ksplit=ksplit, ws=ws, prefetch=other)
+    assert torch.equal(out0, out1), "prefetch workgroups changed the result"
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    return _cmp(out1, ref, dtype)
+
+
 def gemm_quick_gelu_case(M, K, N, dtype, seed=36):
     """CLIP-L's FeedForward activation, x * sigmoid(1.702 x) (GeLUApproximation.SIGMOID), as the GEMM epilogue."""
     x = _rand(M, K, dtype=dtype, seed=seed)
@@ -466,6 +484,9 @@ def all_cases():
             (f"gemm_{tag}_gelu_res_1000x640x384", lambda dt=dt: gemm_gelu_case(1000, 640, 384, dt)),
             (f"gemm_{tag}_gelu_Nedge", lambda dt=dt: gemm_gelu_case(300, 640, 200, dt)),
             (f"gemm_{tag}_quick_gelu_154x768x3072", lambda dt=dt: gemm_quick_gelu_case(154, 768, 3072, dt)),
+            (f"gemm_{tag}_prefetch_300x640x200", lambda dt=dt: gemm_prefetch_case(300, 640, 200, dt)),
+            (f"gemm_{tag}_prefetch_2048x1280x1280", lambda dt=dt: gemm_prefetch_case(2048, 1280, 1280, dt)),
+            (f"gemm_{tag}_prefetch_splitk3", lambda dt=dt: gemm_prefetch_case(512, 1920, 384, dt, ksplit=3)),
             (f"patchify_gather_{tag}", lambda dt=dt: patchify_gather_case(dt)),
             (f"sinusoidal_{tag}_timestep", lambda dt=dt: sinusoidal_case(2, 320, 1, dt)),
             (f"sinusoidal_{tag}_time_ids", lambda dt=dt: sinusoidal_case(12, 256, 6, dt)),

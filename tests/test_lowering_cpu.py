@@ -157,3 +157,34 @@ def test_image_prompt_encoder_lowers_without_fallbacks():
     low.lower_image_projection(proj, both, torch.empty(8, 2048, device=dev, dtype=dt))
     names = Counter(op[2] for op in low.step)
     assert names["mi355x_attention_general"] == 32 and low.stats["fallback_nodes"] == [] and all(op[0] is not None for op in low.step)
+
+
+def test_weight_prefetch_links_every_gemm_to_the_next_ones_weights():
+    """native.link_weight_prefetch: launch i carries the weight span(s) of launch i+1 (wrapping around), spans stay inside
+    the operand, transposed projections contribute their x-slot weights, and enable=False clears everything."""
+    import ctypes as C
+
+    from refiners_amd import native
+
+    def op(M, N, K, w_ptr, x_ptr=0x1000, ldw=None, weight_is_x=False, conv=0, ksize=1):
+        a = native.GemmArgs()
+        a.dtype, a.M, a.N, a.nseg, a.conv = 1, M, N, 1, conv
+        a.seg[0].k, a.seg[0].ksize, a.seg[0].w, a.seg[0].ldw = K, ksize, w_ptr, ldw or K * ksize * ksize
+        a.seg[0].x, a.seg[0].ldx = x_ptr, K
+        a.weight_is_x = weight_is_x
+        return (object(), (C.byref(a),), "mi355x_gemm(conv)" if conv else "mi355x_gemm", ())
+
+    ops = [op(2048, 1280, 1280, 0x10000000), op(2048, 10240, 1280, 0x20000000), ((None, lambda: None, "python", ())),
+           op(1280, 2048, 1280, 0x50000000, x_ptr=0x30000000, weight_is_x=True), op(2048, 1280, 320, 0x40000000, conv=1, ksize=3),
+           op(2048, 640, 640, 0x60000000, ldw=2048)]
+    st = native.link_weight_prefetch(ops)
+    g = [e[1][0]._obj for e in ops if e[0] is not None]
+    assert st["linked"] == 5 and st["launches"] == 5
+    assert (g[0].prefetch[0], g[0].prefetch_bytes[0]) == (0x20000000, 10240 * 1280 * 2)
+    assert (g[1].prefetch[0], g[1].prefetch_bytes[0]) == (0x30000000, 1280 * 1280 * 2)        # the x slot holds the parameters there
+    assert (g[2].prefetch[0], g[2].prefetch_bytes[0]) == (0x40000000, 1280 * 9 * 320 * 2)     # conv: N x (ksize^2 * C)
+    assert (g[3].prefetch[0], g[3].prefetch_bytes[0]) == (0x60000000, (639 * 2048 + 640) * 2)  # column slice: last row to K only
+    assert (g[4].prefetch[0], g[4].prefetch_bytes[0]) == (0x10000000, 1280 * 1280 * 2)        # wraps around for the next replay
+    assert all(32 <= a.prefetch_blocks <= 128 for a in g)
+    native.link_weight_prefetch(ops, enable=False)
+    assert all(not a.prefetch[0] and a.prefetch_blocks == 0 for a in g)
