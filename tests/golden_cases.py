@@ -88,3 +88,31 @@ VAE_CASE = dict(weight_seed=0, input_seed=13, latent_hw=(16, 24), latent_std=0.1
 # ------------------------------------------------------------------------------------------------ next-2: prompt encoder
 CLIP_CASE = dict(weight_seed=0, prompts=("a photograph of an astronaut riding a horse on mars, highly detailed, 4k, dramatic lighting", ""))
 CLIP_IMAGE_CASE = dict(weight_seed=0, input_seed=21)
+
+
+# ------------------------------------------------------------------------------------------------ next-3: LoRA wire format
+def kohya_sdxl_lora_keys(rank: int = 8):
+    """(key, shape) list of a CivitAI-style SDXL LoRA file restricted to the UNet's attention stacks, in FILE order
+    (diffusers module names joined by '_', `lora_down` / `lora_up` / `alpha` per module): 722 modules."""
+    out = []
+
+    def mod(name, fin, fout):
+        out.append((f"lora_unet_{name}.alpha", ()))
+        out.append((f"lora_unet_{name}.lora_down.weight", (rank, fin)))
+        out.append((f"lora_unet_{name}.lora_up.weight", (fout, rank)))
+
+    stacks = [("down_blocks_1", 640, 2, 2), ("down_blocks_2", 1280, 2, 10), ("mid_block", 1280, 1, 10), ("up_blocks_0", 1280, 3, 10), ("up_blocks_1", 640, 3, 2)]
+    for block, C, n_att, depth in stacks:
+        for a in range(n_att):
+            base = f"{block}_attentions_{a}"
+            mod(f"{base}_proj_in", C, C)
+            mod(f"{base}_proj_out", C, C)
+            for t in range(depth):
+                tb = f"{base}_transformer_blocks_{t}"
+                for proj in ("to_k", "to_out_0", "to_q", "to_v"):  # alphabetical, as safetensors files store them
+                    mod(f"{tb}_attn1_{proj}", C, C)
+                for proj, fin in (("to_k", 2048), ("to_out_0", C), ("to_q", C), ("to_v", 2048)):
+                    mod(f"{tb}_attn2_{proj}", fin, C)
+                mod(f"{tb}_ff_net_0_proj", C, 8 * C)
+                mod(f"{tb}_ff_net_2", 4 * C, C)
+    return out
