@@ -297,6 +297,13 @@ int mi355x_sinusoidal(int32_t dtype, const float* x, int64_t n, int32_t dim, int
  * step coefficients.  x is updated in place (f32 or bf16 per dtype; arithmetic in f32).
  */
 int mi355x_cfg_ddim_step(int32_t dtype, void* x, const void* unet_out, const float* coef, int64_t n, void* stream);
+/* Classifier-free guidance + one step of any solver that is linear in (x, eps, one kept quantity) -- Euler
+ * (src/refiners/foundationals/latent_diffusion/solvers/euler.py:62-100), DPM-Solver++ 2M with sde_variance 0 (solvers/dpm.py:224-329),
+ * DDIM -- after the CFG combine of latent_diffusion/model.py:142-145:
+ *   eps = u + cfg (c - u);  d = hx x + he eps;  x' = kx x + ke eps + kd d + kp hist;  hist = d;
+ *   model_in[0:n] = model_in[n:2n] = s_next x'   (Solver.scale_model_input of the NEXT step on cat(x', x'); may be NULL)
+ * coef = {cfg, hx, he, kx, ke, kd, kp, s_next}, eight floats in DEVICE memory; x, hist: n elements; unet_out: 2n (u then c). */
+int mi355x_cfg_linear_step(int32_t dtype, void* x, const void* unet_out, void* hist, void* model_in, const float* coef, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -120,6 +120,30 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(T* __restrict__ x, const 
     }
 }
 
+// Classifier-free guidance + any solver whose update is linear in (x, eps, one kept quantity): Euler, DPM-Solver++ 2M, DDIM.
+//   eps = u + cfg (c - u);  d = hx x + he eps;  x' = kx x + ke eps + kd d + kp hist;  hist = d;  model_in (both CFG halves) = s_next x'
+// coef = {cfg, hx, he, kx, ke, kd, kp, s_next} in device memory (one row of a per-step table, so a captured graph can be replayed)
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_linear_kernel(T* __restrict__ x, const T* __restrict__ uo, T* __restrict__ hist, T* __restrict__ model_in,
+                                                          const float* __restrict__ coef, int64_t n) {
+    const float cfg = coef[0], hx = coef[1], he = coef[2], kx = coef[3], ke = coef[4], kd = coef[5], kp = coef[6], sn = coef[7];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float u = to_f32(uo[i]), c = to_f32(uo[n + i]);
+        const float eps = u + cfg * (c - u);
+        const float xv = to_f32(x[i]);
+        const float d = hx * xv + he * eps;
+        const float xn = kx * xv + ke * eps + kd * d + kp * to_f32(hist[i]);
+        const T xs = from_f32<T>(xn);
+        x[i] = xs;
+        hist[i] = from_f32<T>(d);
+        if (model_in) {
+            const T mi = from_f32<T>(sn * to_f32(xs));  // the next step scales the STORED latents, as solver.scale_model_input does
+            model_in[i] = mi;
+            model_in[n + i] = mi;
+        }
+    }
+}
+
 // out[(i / group) * ldo + col0 + (i % group) * dim + j]       = cos(x[i] * 10000^(-j / half)),  j < half
 // out[(i / group) * ldo + col0 + (i % group) * dim + half + j] = sin(...)                         (float32 arithmetic)
 template <typename T>
@@ -280,6 +304,16 @@ extern "C" int mi355x_cfg_ddim_step(int32_t dtype, void* x, const void* unet_out
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = grid_for(n);
     DISPATCH_T(dtype, hipLaunchKernelGGL((cfg_ddim_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<T*>(x), static_cast<const T*>(unet_out), coef, n));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_cfg_linear_step(int32_t dtype, void* x, const void* unet_out, void* hist, void* model_in, const float* coef, int64_t n,
+                                      void* stream) {
+    if (!x || !unet_out || !hist || !coef || n <= 0) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((cfg_linear_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<T*>(x), static_cast<const T*>(unet_out),
+                                         static_cast<T*>(hist), static_cast<T*>(model_in), coef, n));
     return LAUNCH_OK();
 }
 

@@ -216,19 +216,28 @@ class CompiledUNet:
 
 
 class CompiledSDXL:
-    """One classifier-free-guidance denoising step per call: UNet on cat(x, x) + CFG combine + DDIM update
+    """One classifier-free-guidance denoising step per call: UNet on cat(x, x) + CFG combine + solver update
     (reference latent_diffusion/model.py:128-159, solvers/ddim.py:56-95), latents resident in HBM across steps.
 
-    The per-step host work is: two tiny device copies (timestep, DDIM coefficients) and one hipGraphLaunch.  The Chain
+    `solver`: None = DDIM over `num_inference_steps` (SDXL's default); or an `Euler` / `DPMSolver` of
+    refiners_amd.latent_diffusion.solvers (anything with `linear_step`): guidance + update + the next step's model-input
+    scaling then run as ONE kernel (mi355x_cfg_linear_step) and the two cat(x, x) copies disappear from the step.
+    SD1.5 UNets work too: leave `pooled_text_embedding` / `time_ids` out of `set_inputs`.
+
+    The per-step host work is: two tiny device copies (timestep, solver coefficients) and one hipGraphLaunch.  The Chain
     tree's context store is not touched per step (the reference spends ~19 000 Python calls per step on it)."""
 
-    def __init__(self, unet: Any, num_inference_steps: int = 50, condition_scale: float = 5.0, use_graph: bool = True, lora_mode: str = "fused") -> None:
+    def __init__(self, unet: Any, num_inference_steps: int = 50, condition_scale: float = 5.0, use_graph: bool = True, lora_mode: str = "fused",
+                 solver: Any = None) -> None:
         from ..latent_diffusion.sampling import DDIM
 
         self.unet = unet
         self.engine = CompiledUNet(unet, use_graph=False, lora_mode=lora_mode)
         self.use_graph = use_graph
-        self.solver = DDIM(num_inference_steps)
+        self.solver = solver if solver is not None else DDIM(num_inference_steps)
+        self.linear = hasattr(self.solver, "linear_step")
+        self.hist: Optional[Tensor] = None
+        self.primed, self.primed_key = False, None
         self.condition_scale = condition_scale
         self.x: Optional[Tensor] = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -239,13 +248,16 @@ class CompiledSDXL:
     def _tables(self, device: torch.device) -> None:
         rows = []
         for s in range(self.solver.num_inference_steps):
-            cur, sig, prev, nf = self.solver.coefficients(s)
-            rows.append([self.condition_scale, cur, sig, prev, nf, 0.0, 0.0, 0.0])
+            if self.linear:
+                rows.append([self.condition_scale, *self.solver.linear_step(s)])
+            else:
+                cur, sig, prev, nf = self.solver.coefficients(s)
+                rows.append([self.condition_scale, cur, sig, prev, nf, 0.0, 0.0, 0.0])
         self.coef_table = torch.tensor(rows, dtype=torch.float32, device=device)
         self.coef = torch.zeros(8, dtype=torch.float32, device=device)
         self.ts_table = self.solver.timesteps.to(device=device, dtype=torch.float32)
 
-    def set_inputs(self, x: Tensor, *, clip_text_embedding: Tensor, pooled_text_embedding: Tensor, time_ids: Tensor,
+    def set_inputs(self, x: Tensor, *, clip_text_embedding: Tensor, pooled_text_embedding: Optional[Tensor] = None, time_ids: Optional[Tensor] = None,
                    clip_image_embedding: Optional[Tensor] = None, conditions: Optional[dict[str, Tensor]] = None) -> None:
         """x: (N, 4, H, W) initial latents; embeddings are [negative ; conditional] stacks of 2N rows;
         `conditions` maps a ControlLora name to its (2N, 3, 8H, 8W) control image."""
@@ -258,6 +270,9 @@ class CompiledSDXL:
             self.x = torch.empty(tuple(x.shape), device=x.device, dtype=self.unet.dtype)
             self.graph = None
         self.x.copy_(x)
+        if self.linear:
+            self.hist = torch.zeros_like(self.x)
+            self.primed = False  # the model-input buffer must be (re)filled with s_0 * x before the next step
         if self.coef_table is None or self.coef_table.device != x.device:
             self._tables(x.device)
 
@@ -279,6 +294,8 @@ class CompiledSDXL:
         io, low = eng.io, eng.low
         assert io is not None and low is not None
         self.coef.copy_(self.coef_table[step])
+        if self.linear:
+            return self._linear_step(step, io, low, eng)
         if not self.use_graph:
             self._fill()
             native.replay(low.step)
@@ -295,6 +312,30 @@ class CompiledSDXL:
                 native.replay(low.step)
                 native.cfg_ddim_step(self.x, io.out, self.coef)
             self.x.copy_(keep)
+            self.graph, self.graph_key = g, eng.key
+        self.graph.replay()
+        return self.x
+
+    def _linear_step(self, step: int, io: Any, low: Any, eng: Any) -> Tensor:
+        """Euler / DPM-Solver++: the UNet program then ONE kernel (guidance, update, history, next model input)."""
+        assert self.x is not None and self.hist is not None
+        if not self.primed or self.primed_key != eng.key:  # first step of a trajectory, or the engine re-lowered into new buffers
+            self._fill()  # cat(x, x) ...
+            s0 = float(self.solver.input_scale(step))
+            if s0 != 1.0:
+                io.x.mul_(s0)  # ... through Solver.scale_model_input for THIS step; later steps get it from the kernel
+            self.primed, self.primed_key = True, eng.key
+        if not self.use_graph:
+            native.replay(low.step)
+            native.cfg_linear_step(self.x, io.out, self.hist, io.x, self.coef)
+            return self.x
+        if self.graph is None or self.graph_key != eng.key:
+            native.replay(low.step)  # warm-up outside capture; reads io.x only
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                native.replay(low.step)
+                native.cfg_linear_step(self.x, io.out, self.hist, io.x, self.coef)
             self.graph, self.graph_key = g, eng.key
         self.graph.replay()
         return self.x

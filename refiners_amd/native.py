@@ -187,6 +187,7 @@ EXPORTS = [
     "mi355x_axpby",
     "mi355x_silu",
     "mi355x_cfg_ddim_step",
+    "mi355x_cfg_linear_step",
     "mi355x_sinusoidal",
     "mi355x_patchify_nchw",
     "mi355x_gather_rows",
@@ -228,6 +229,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_axpby.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_silu.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_cfg_ddim_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mi355x_cfg_linear_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_sinusoidal.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.mi355x_patchify_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     lib.mi355x_gather_rows.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
@@ -671,6 +673,16 @@ def cfg_ddim_step(x: Tensor, unet_out: Tensor, coef: Tensor) -> Tensor:
     assert x.is_contiguous() and unet_out.is_contiguous() and unet_out.numel() == 2 * x.numel()
     assert coef.dtype == torch.float32 and coef.numel() >= 5 and coef.is_cuda
     _launch("mi355x_cfg_ddim_step", (dtype_code(x.dtype), x.data_ptr(), unet_out.data_ptr(), coef.data_ptr(), x.numel(),), "mi355x_cfg_ddim_step")
+    return x
+
+
+def cfg_linear_step(x: Tensor, unet_out: Tensor, hist: Tensor, model_in: Optional[Tensor], coef: Tensor) -> Tensor:
+    """x, hist: [N, ...] latents (in place); unet_out: [2N, ...] = (unconditional, conditional); model_in: [2N, ...] or None;
+    coef: 8 float32 on the device = (cfg, hx, he, kx, ke, kd, kp, s_next) -- see mi355x_cfg_linear_step in the header."""
+    assert x.is_contiguous() and unet_out.is_contiguous() and hist.is_contiguous() and unet_out.numel() == 2 * x.numel() == 2 * hist.numel()
+    assert coef.dtype == torch.float32 and coef.numel() >= 8 and (model_in is None or (model_in.is_contiguous() and model_in.numel() == 2 * x.numel()))
+    _launch("mi355x_cfg_linear_step", (dtype_code(x.dtype), x.data_ptr(), unet_out.data_ptr(), hist.data_ptr(), model_in.data_ptr() if model_in is not None else None,
+                                      coef.data_ptr(), x.numel()), "mi355x_cfg_linear_step")
     return x
 
 

@@ -419,3 +419,62 @@ def test_image_prompt_encoder_matches_reference():
             assert l2 < tol, (dtype, name, l2, mx)
             if dtype == torch.float32:
                 assert mx < tol
+
+
+@pytest.mark.parametrize("which", ["euler", "dpm"])
+def test_other_solvers_through_the_step_api(which):
+    """Euler and DPM-Solver++ (2M) on the same loop -- guidance + solver update + the next step's
+    model-input scaling as ONE kernel after the UNet program -- against the unfused mirror (whose solvers reproduce the real
+    reference's bit for bit, tests/test_solvers_cpu.py) looping on the same GPU in float32."""
+    from refiners_amd.latent_diffusion.sampling import SDXLDenoiser
+    from refiners_amd.latent_diffusion.solvers import DPMSolver, Euler
+
+    cfg, unet, specs, handles, inp = build("sdxl_bare", torch.float32)
+    steps = 8
+    make = (lambda: Euler(steps, device="cuda")) if which == "euler" else (lambda: DPMSolver(steps, device="cuda"))
+    x0 = inp["x"] * (float(make().init_noise_sigma) if which == "euler" else 1.0)  # Euler starts from sigma_max-scaled noise
+    for use_graph in (False, True):
+        sd = CompiledSDXL(unet, condition_scale=5.0, solver=make(), use_graph=use_graph)
+        sd.set_inputs(x0, clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"])
+        fast = sd.sample().clone()
+        ref = SDXLDenoiser(unet, make())
+        x = x0.clone()
+        with torch.no_grad():
+            for s in range(steps):
+                x = ref(x, s, clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], condition_scale=5.0)
+        l2, mx = S.rel_err(fast, x)
+        print(f"{which} {steps}-step trajectory f32 graph={use_graph}: l2 {l2:.2e} max {mx:.2e}")
+        assert l2 < F32_TOL and mx < F32_TOL, (which, use_graph, l2, mx)
+        # a second trajectory on the same compiled object (history and model-input buffer must be reset)
+        sd.set_inputs(x0, clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"])
+        again = sd.sample()
+        assert torch.equal(again, fast)
+
+
+def test_sd15_with_its_default_solver():
+    """BASELINE.json configs[0]'s model with the solver StableDiffusion_1 ships with (DPMSolver, sd1/model.py:95): SD1UNet (heads of
+    40 / 80 / 160) + classifier-free guidance + DPM-Solver++ through the same step API -- no pooled embedding, no time ids."""
+    from refiners_amd.latent_diffusion.sd1 import SD1UNet
+    from refiners_amd.latent_diffusion.solvers import DPMSolver
+
+    cfg = S.CASES["sd1_bare"]
+    unet = SD1UNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sd1", cfg["weight_seed"]), device="cuda", dtype=torch.float32)
+    x0 = torch.randn((1, 4, *cfg["latent_hw"]), generator=S.synth._gen("in.x", cfg["input_seed"])).cuda()
+    text = torch.randn((2, 77, 768), generator=S.synth._gen("in.text2", cfg["input_seed"])).cuda()
+    steps = 6
+    sd = CompiledSDXL(unet, condition_scale=7.5, solver=DPMSolver(steps, device="cuda"))
+    sd.set_inputs(x0, clip_text_embedding=text)
+    fast = sd.sample().clone()
+    assert sd.engine.stats["fallback_nodes"] == []
+    solver = DPMSolver(steps, device="cuda")
+    x = x0.clone()
+    with torch.no_grad():
+        for s in range(steps):
+            unet.set_timestep(solver.timesteps[s].unsqueeze(0))
+            unet.set_clip_text_embedding(text)
+            u, c = unet(torch.cat((x, x))).chunk(2)
+            x = solver(x, predicted_noise=u + 7.5 * (c - u), step=s)
+    l2, mx = S.rel_err(fast, x)
+    print(f"sd1.5 + DPM-Solver++ {steps} steps f32: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
