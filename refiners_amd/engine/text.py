@@ -3,7 +3,7 @@
 (`latent_diffusion/stable_diffusion_xl/text_encoder.py:14-101`), from token ids to the `clip_text_embedding` /
 `pooled_text_embedding` tensors the UNet engine consumes -- in HBM, no host round trip.
 
-Same engine as the UNet: the Chain tree (refiners_amd.clip / .latent_diffusion.text_encoder, or refiners' own classes) is
+Same engine as the UNet: the Chain tree (refiners_amd.clip / .latent_diffusion.prompt, or refiners' own classes) is
 walked once into a launch program over [B*77, C] token rows.
 
   Sum(TokenEncoder, PositionalEncoder) -> row gather from the embedding table | + position rows

@@ -9,7 +9,7 @@ import torch
 from oracle import clip_oracle
 from refiners_amd import synth
 from refiners_amd.clip import CLIPTokenizer
-from refiners_amd.latent_diffusion.text_encoder import DoubleTextEncoder
+from refiners_amd.latent_diffusion.prompt import DoubleTextEncoder
 from tests import support as S
 from tests.golden_cases import CLIP_CASE
 

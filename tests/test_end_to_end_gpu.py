@@ -14,7 +14,7 @@ from refiners_amd.engine.text import CompiledDoubleTextEncoder
 from refiners_amd.engine.vae import CompiledVAEDecoder
 from refiners_amd.latent_diffusion.sampling import DDIM, SDXLDenoiser
 from refiners_amd.latent_diffusion.sdxl import SDXLUNet
-from refiners_amd.latent_diffusion.text_encoder import DoubleTextEncoder
+from refiners_amd.latent_diffusion.prompt import DoubleTextEncoder
 from refiners_amd.latent_diffusion.vae import SDXLAutoencoder
 from tests import support as S
 from tests.golden_cases import CLIP_CASE, VAE_CASE

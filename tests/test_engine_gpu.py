@@ -349,7 +349,7 @@ def test_prompt_encoder_matches_reference():
     import json
 
     from refiners_amd.engine.text import CompiledDoubleTextEncoder
-    from refiners_amd.latent_diffusion.text_encoder import DoubleTextEncoder
+    from refiners_amd.latent_diffusion.prompt import DoubleTextEncoder
     from tests.golden_cases import CLIP_CASE
 
     shapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "double_text_encoder_keys.json").read_text()).items()}

@@ -131,7 +131,7 @@ def test_scale_and_structure_changes_move_the_tree_epoch():
 def test_prompt_encoder_lowers_without_fallbacks():
     """DoubleTextEncoder (CLIP-L + CLIP-G) -> 395 launches, 43 causal attentions, nothing left on torch."""
     from refiners_amd.engine.text import TextLowering
-    from refiners_amd.latent_diffusion.text_encoder import DoubleTextEncoder
+    from refiners_amd.latent_diffusion.prompt import DoubleTextEncoder
 
     dev, dt = torch.device("meta"), torch.bfloat16
     enc = DoubleTextEncoder(device="meta", dtype=dt)
