@@ -184,7 +184,7 @@ def main() -> None:
     groups: dict[str, list] = {}
     for e in low.step:
         if e[0] is not None:
-            groups.setdefault(e[2], []).append(e)
+            groups.setdefault(e[2].split("@")[0], []).append(e)  # launches on the side stream belong to the same family
     fam = {}
     for name, ops in groups.items():
         sec = time_ops(ops)

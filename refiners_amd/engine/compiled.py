@@ -27,7 +27,7 @@ from torch import Tensor
 
 from .. import native
 from ..fluxion.tree import tree_epoch
-from .lowering import PackCache, UNetIO, UNetLowering, Unsupported, isa, kids
+from .lowering import PackCache, UNetIO, UNetLowering, Unsupported, isa, kids, launches
 
 TOKEN_CONTEXTS = (("cross_attention_block", "clip_text_embedding"), ("ip_adapter", "clip_image_embedding"))
 
@@ -123,7 +123,7 @@ class CompiledUNet:
         # the Infinity Cache (weights are read exactly once per step, so otherwise every kernel starts on DRAM misses)
         pf = native.link_weight_prefetch(low.step, enable=self.weight_prefetch)
         self.low, self.io, self.graph, self.prologue_key = low, io, None, None
-        self.stats = dict(low.stats, step_ops=len(low.step), prologue_ops=len(low.prologue), pool_bytes=low.step_pool.bytes() + low.prologue_pool.bytes(),
+        self.stats = dict(low.stats, step_ops=launches(low.step), prologue_ops=launches(low.prologue), pool_bytes=low.step_pool.bytes() + low.prologue_pool.bytes(),
                           weight_prefetch=pf)
 
     def _out_channels(self) -> int:

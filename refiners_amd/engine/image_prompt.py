@@ -18,7 +18,7 @@ from torch import Tensor
 from .. import native
 from ..fluxion.tree import tree_epoch
 from .compiled import Program
-from .lowering import PackCache, _expect, isa, kids
+from .lowering import PackCache, _expect, isa, kids, launches
 from .text import TextLowering
 
 
@@ -136,7 +136,7 @@ class CompiledImagePrompt:
                 low.lower_image_projection(self.image_proj, self.both, self.tokens)
             self.cache.sweep()
             self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
-            self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
+            self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.x.copy_(image)
         self.program.run()
         if self.tokens is None:

@@ -25,6 +25,8 @@ The matcher works on class NAMES, so it accepts trees built from refiners_amd.fl
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass, field
 from typing import Any, Callable, Optional
@@ -47,6 +49,11 @@ def isa(m: Any, *names: str) -> bool:
 
 def kids(m: Any) -> list[Any]:
     return list(m._modules.values())
+
+
+def launches(ops: list) -> int:
+    """Number of kernel-launching entries of a recorded program (Python glue such as stream fork / join excluded)."""
+    return sum(1 for e in ops if e[0] is not None)
 
 
 def cname(m: Any) -> str:
@@ -198,6 +205,10 @@ class Lowering:
         #                       FLOPs.  Scales stay live: changing them re-lowers and re-merges the touched sites only.
         assert lora_mode in ("fused", "merged")
         self.lora_mode = lora_mode
+        # independent projections of one attention on a second stream (native.side_branch).  OFF by default: measured on
+        # MI355X the forked Q|K / V^T pair makes the SDXL step 2 % SLOWER (29.7 vs 29.0 ms; the join edges cost more than the
+        # overlap gains, both GEMMs pull from the same L2s).  Kept as a switch for larger batches / other trees.
+        self.side_branches = device.type == "cuda" and os.environ.get("REFINERS_AMD_SIDE_BRANCHES", "0") == "1"
         self.device, self.dtype = device, dtype
         self.es = 4 if dtype == torch.float32 else 2
         self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
@@ -572,6 +583,23 @@ class Lowering:
         self.linear(src, vs, out=v)
         return k, v, v
 
+    def _project_vt(self, h: Tensor, vs: LinSpec, B: int, L: int, C: int) -> Tensor:
+        """V^T [C, B * Lp] of h [B * L, Ck] (Lp = L rounded up to 64 keys)."""
+        if L % 64 == 0:
+            vt = self.pool.get(C, B * L)
+            self.linear_T(h, vs, vt)
+            return vt
+        # token counts that are not a multiple of 64 (e.g. 1216x832 px -> 38x26 = 988 tokens at the deepest level): each
+        # sample's V^T columns start on a 64-key boundary (16-byte aligned rows, readable up to the padded length),
+        # one projection launch per sample; the padding is zeroed ONCE here (the kernel masks those keys' scores
+        # but still multiplies their V by an exact 0, so it must be finite)
+        lp = (L + 63) // 64 * 64
+        vt = torch.zeros(C, B * lp, device=self.device, dtype=self.dtype)
+        self.__dict__.setdefault("_keep", []).append(vt)
+        for b in range(B):
+            self.linear_T(h[b * L : (b + 1) * L], vs, vt[:, b * lp : b * lp + L])
+        return vt
+
     def self_attention(self, x: Tensor, B: int, ln: Any, att: Any) -> Tensor:
         """x += Wo SDPA(Wq h, Wk h, Wv h), h = LN(x)   (cross_attention.py:44-49; attentions.py:319-385)."""
         (qn, kn, vn), sd, on, ip = self._split_attention(att)
@@ -582,6 +610,15 @@ class Lowering:
         _expect(qs.b is None and ks.b is None and vs.b is None, "q/k/v bias not supported")
         M, C = x.shape
         native_path = self.head_kernel(C // heads) is not None
+        L = M // B
+        # The V^T projection and the packed Q|K projection read the same h and do not depend on each other; neither fills the
+        # chip at a CFG pair's 2048 rows, so V^T is issued on the side stream (native.side_branch) and joined before attention.
+        concurrent = native_path and self.side_branches and vs.lora is None
+        vt = None
+        if concurrent:
+            native.fork()
+            with native.side_branch():
+                vt = self._project_vt(h, vs, B, L, C)
         if qs.lora is None and ks.lora is None:
             wqk = self.cache.get(("qk",) + PackCache.ident(qs.w, ks.w), lambda: torch.cat([qs.w, ks.w], 0).contiguous())
             qk = self.pool.get(M, 2 * C)
@@ -592,20 +629,10 @@ class Lowering:
             q = self.linear(h, qs)
             k = self.linear(h, ks)
         if native_path:
-            L = M // B
-            if L % 64 == 0:
-                vt = self.pool.get(C, M)
-                self.linear_T(h, vs, vt)
+            if concurrent:
+                native.join()
             else:
-                # token counts that are not a multiple of 64 (e.g. 1216x832 px -> 38x26 = 988 tokens at the deepest level): each
-                # sample's V^T columns start on a 64-key boundary (16-byte aligned rows, readable up to the padded length),
-                # one projection launch per sample; the padding is zeroed ONCE here (the kernel masks those keys' scores
-                # but still multiplies their V by an exact 0, so it must be finite)
-                lp = (L + 63) // 64 * 64
-                vt = torch.zeros(C, B * lp, device=self.device, dtype=self.dtype)
-                self.__dict__.setdefault("_keep", []).append(vt)
-                for b in range(B):
-                    self.linear_T(h[b * L : (b + 1) * L], vs, vt[:, b * lp : b * lp + L])
+                vt = self._project_vt(h, vs, B, L, C)
             o = self.sdpa(q, B, heads, [(k, vt, L, 1.0)])
             if L % 64 == 0:
                 self.pool.put(vt)

@@ -32,7 +32,7 @@ from torch import Tensor
 from .. import native
 from ..fluxion.tree import tree_epoch
 from .compiled import Program
-from .lowering import Act, Lowering, PackCache, Unsupported, _expect, cname, isa, kids
+from .lowering import Act, Lowering, PackCache, Unsupported, _expect, cname, isa, kids, launches
 
 
 class SAMLowering(Lowering):
@@ -296,7 +296,7 @@ class CompiledSAMViT:
             self.low, self.key = low, key
             # the torch fallback of an attention (un-merged LoRA, odd shapes) allocates: not capturable
             self.program = Program(low.step, self.use_graph and not low.stats["fallback_nodes"])
-            self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
+            self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.x.copy_(image)
         self.program.run()
         hook = self._hook()

@@ -25,7 +25,7 @@ from torch import Tensor
 from .. import native
 from ..fluxion.tree import tree_epoch
 from .compiled import Program
-from .lowering import Lowering, PackCache, _expect, cname, isa, kids
+from .lowering import Lowering, PackCache, _expect, cname, isa, kids, launches
 
 
 class TextLowering(Lowering):
@@ -217,7 +217,7 @@ class CompiledDoubleTextEncoder:
             low.lower_double(self.enc, self.tok_l, self.tok_g, self.eot, B, L, self.emb, self.pooled)
             self.cache.sweep()
             self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
-            self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
+            self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.tok_l.copy_(tok_l.reshape(-1))
         self.tok_g.copy_(tok_g.reshape(-1))
         # first end-of-text position per prompt (TextEncoderWithPooling.set_end_of_text_index, xl/text_encoder.py:48-51)
@@ -254,7 +254,7 @@ class CompiledTextEncoder:
             low.lower_encoder(self.enc, self.tok, B, L, self.out)
             self.cache.sweep()
             self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
-            self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
+            self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.tok.copy_(tok.reshape(-1))
         self.program.run()
         return self.out.view(B, L, -1).clone()

@@ -17,7 +17,7 @@ import torch
 from torch import Tensor
 
 from .. import native
-from .lowering import Act, PackCache, UNetContext, UNetLowering, _expect, cname, isa, kids
+from .lowering import Act, PackCache, UNetContext, UNetLowering, _expect, cname, isa, kids, launches
 
 
 class VAEDecoderLowering(UNetLowering):
@@ -182,7 +182,7 @@ class CompiledVAEDecoder:
             low.lower_decoder(dec, self.x, self.out, float(self.vae.encoder_scale))
             self.cache.sweep()
             self.low, self.key = low, key
-            self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
+            self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.x.copy_(latents)
         native.replay(self.low.step)
         return self.out.clone()
@@ -214,7 +214,7 @@ class CompiledVAEEncoder:
             low.lower_encoder(enc, self.x, self.out, float(self.vae.encoder_scale))
             self.cache.sweep()
             self.low, self.key = low, key
-            self.stats = dict(low.stats, step_ops=len(low.step), pool_bytes=low.step_pool.bytes())
+            self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.x.copy_(image)
         native.replay(self.low.step)
         return self.out.clone()

@@ -303,12 +303,70 @@ class recording:
         _recorder = self._saved
 
 
+_side_depth = 0
+_side_streams: dict[int, "torch.cuda.Stream"] = {}
+SIDE = "@side"  # suffix of the name of a recorded launch that runs on the side stream
+
+
+class side_branch:
+    """Context manager for the recorder: launches recorded inside run on a second stream, concurrently with what the main
+    stream records between `fork()` and `join()`.  At the SDXL step's problem sizes (CFG pair: 2048 rows) single GEMMs do
+    not fill 256 CUs, so independent ones -- the packed Q|K projection and the V^T projection of a self-attention -- are
+    issued side by side; under HIP-graph capture the fork / join events become graph edges."""
+
+    def __enter__(self) -> None:
+        global _side_depth
+        _side_depth += 1
+
+    def __exit__(self, *exc: object) -> None:
+        global _side_depth
+        _side_depth -= 1
+
+
+def side_stream() -> "torch.cuda.Stream":
+    dev = torch.cuda.current_device()
+    if dev not in _side_streams:
+        _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return _side_streams[dev]
+
+
+def fork() -> None:
+    """Recorded point after which the side stream may start: it waits for everything the main stream has issued so far."""
+    ev = None
+
+    def run() -> None:
+        nonlocal ev
+        if ev is None:
+            ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        side_stream().wait_event(ev)
+
+    if not record_python(run, "fork" + SIDE):
+        run()
+
+
+def join() -> None:
+    """Recorded point at which the main stream waits for everything issued on the side stream."""
+    ev = None
+
+    def run() -> None:
+        nonlocal ev
+        if ev is None:
+            ev = torch.cuda.Event()
+        ev.record(side_stream())
+        torch.cuda.current_stream().wait_event(ev)
+
+    if not record_python(run, "join" + SIDE):
+        run()
+
+
 def _launch(sym: str, args: tuple, what: str, keep: tuple = ()) -> None:
     fn = getattr(load(), sym)
     if _recorder is not None:
-        _recorder.append((fn, args, what, keep))
+        _recorder.append((fn, args, what + SIDE if _side_depth else what, keep))
         return
-    check(fn(*args, stream_ptr()), what)
+    s = side_stream().cuda_stream if _side_depth else stream_ptr()
+    check(fn(*args, s), what)
 
 
 def record_python(fn, what: str = "python") -> bool:
@@ -323,11 +381,17 @@ def record_python(fn, what: str = "python") -> bool:
 def replay(ops: list) -> None:
     """Launch a recorded program on the current stream."""
     s = stream_ptr()
+    s2 = None
     for fn, args, what, _ in ops:
         if fn is None:
             args()
             continue
-        st = fn(*args, s)
+        if what.endswith(SIDE):
+            if s2 is None:
+                s2 = side_stream().cuda_stream
+            st = fn(*args, s2)
+        else:
+            st = fn(*args, s)
         if st:
             check(st, what)
 
