@@ -239,9 +239,32 @@ def control_lora_residuals(sd: SD, ctl: dict[str, Any], x: Tensor, timestep, tex
     return out
 
 
+T2I_SDXL_BLOCKS = (3, 5, 8)  # SDXLT2IAdapter.residual_indices
+
+
+@torch.no_grad()
+def t2i_condition_encoder_xl(sd: SD, picture: Tensor) -> list[Tensor]:
+    """ConditionEncoderXL (latent_diffusion/t2i_adapter.py:132-163): PixelUnshuffle(16) -> conv3x3 -> four stages of
+    [avg-pool 2 (third stage only)] -> [1x1 shortcut when the width changes] -> 2 x (x + conv1x1(relu(conv3x3(x))))."""
+    x = F.conv2d(F.pixel_unshuffle(picture, 16), sd["Conv2d.weight"], sd["Conv2d.bias"], padding=1)
+    feats = []
+    for i in range(1, 5):
+        p = f"StatefulResidualBlocks_{i}.ResidualBlocks"
+        if i == 3:
+            x = F.avg_pool2d(x, 2, 2)
+        if f"{p}.Conv2d.weight" in sd:
+            x = F.conv2d(x, sd[f"{p}.Conv2d.weight"], sd[f"{p}.Conv2d.bias"])
+        for j in (1, 2):
+            q = f"{p}.Chain.ResidualBlock_{j}"
+            h = F.relu(F.conv2d(x, sd[f"{q}.Conv2d_1.weight"], sd[f"{q}.Conv2d_1.bias"], padding=1))
+            x = x + F.conv2d(h, sd[f"{q}.Conv2d_2.weight"], sd[f"{q}.Conv2d_2.bias"])
+        feats.append(x)
+    return feats
+
+
 @torch.no_grad()
 def sdxl_unet(sd: SD, x: Tensor, timestep: Tensor, text: Tensor, pooled: Tensor, time_ids: Tensor,
-              loras: list | None = None, ip: dict | None = None, control: list | None = None) -> Tensor:
+              loras: list | None = None, ip: dict | None = None, control: list | None = None, t2i: dict | None = None) -> Tensor:
     """SDXLUNet.forward (xl/unet.py:258-351).  x (B,4,H,W); timestep (1,) or (B,); text (B,77,2048); pooled (B,1280);
     time_ids (B,6).  Skip handling = ResidualAccumulator / ResidualConcatenator (latent_diffusion/unet.py:54-79)."""
     residuals: list[Any] = [0.0] * 10
@@ -253,10 +276,14 @@ def sdxl_unet(sd: SD, x: Tensor, timestep: Tensor, text: Tensor, pooled: Tensor,
     shapes: list = []
     for n, kinds in enumerate(SDXL_DOWN):
         x = _stage(net, f"DownBlocks.Chain_{n + 1}", kinds, "sdxl", x, temb, text, ip, shapes)
+        if t2i is not None and n in T2I_SDXL_BLOCKS:  # T2IFeatures sits in front of the ResidualAccumulator (xl/t2i_adapter.py:27-40)
+            x = x + t2i["scale"] * t2i["features"][T2I_SDXL_BLOCKS.index(n)]
         residuals[n] = x + residuals[n]
     x = residual_block(net, "MiddleBlock.ResidualBlock_1", x, temb)
     x = cross_attention_2d(net, "MiddleBlock.SDXLCrossAttention", x, text, 20, True, ip)
     x = residual_block(net, "MiddleBlock.ResidualBlock_2", x, temb)
+    if t2i is not None:  # the fourth feature map is appended to the MiddleBlock (xl/t2i_adapter.py:42-44)
+        x = x + t2i["scale"] * t2i["features"][3]
     x = x + residuals[-1]  # fl.Residual(UseContext residuals[-1]), xl/unet.py:282 (slot 9 is ControlLora's middle output or 0.0)
     for n, kinds in enumerate(SDXL_UP):
         x = torch.cat([x, residuals[-n - 2]], dim=1)

@@ -116,3 +116,7 @@ def kohya_sdxl_lora_keys(rank: int = 8):
                 mod(f"{tb}_ff_net_0_proj", C, 8 * C)
                 mod(f"{tb}_ff_net_2", 4 * C, C)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ next-4: T2I-Adapter
+T2I_CASE = dict(weight_seed=0, input_seed=31, latent_hw=(32, 32), num_steps=50, step=20, scale=0.8)
