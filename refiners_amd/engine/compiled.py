@@ -85,7 +85,8 @@ class CompiledUNet:
     def _gather(self) -> dict[str, Any]:
         c = self._contexts()
         diff = c.get("diffusion", {})
-        got: dict[str, Any] = {"timestep": diff.get("timestep"), "pooled": diff.get("pooled_text_embedding"), "time_ids": diff.get("time_ids"), "tokens": {}, "conditions": {}}
+        got: dict[str, Any] = {"timestep": diff.get("timestep"), "pooled": diff.get("pooled_text_embedding"), "time_ids": diff.get("time_ids"), "tokens": {}, "conditions": {},
+                               "t2i": {}}
         assert got["timestep"] is not None, "context diffusion.timestep is unset (call unet.set_timestep first)"
         for ctx, key in TOKEN_CONTEXTS:
             v = c.get(ctx, {}).get(key)
@@ -94,6 +95,9 @@ class CompiledUNet:
         for name, d in c.items():
             if name.startswith("control_lora_") and d.get("condition") is not None:
                 got["conditions"][name] = d["condition"]
+        for key, feats in c.get("t2iadapter", {}).items():  # T2IAdapter.set_condition_features (t2i_adapter.py:201-202)
+            if key.startswith("condition_features_") and feats is not None:
+                got["t2i"][key.removeprefix("condition_features_")] = tuple(feats)
         return got
 
     # -- lowering ----------------------------------------------------------------------------------------------
@@ -116,6 +120,8 @@ class CompiledUNet:
             io.tokens[ck] = (torch.zeros(B * lp, width, device=dev, dtype=dtype), L)
         for name, v in got["conditions"].items():
             io.conditions[name] = torch.empty(tuple(v.shape), device=dev, dtype=dtype)
+        for name, feats in got.get("t2i", {}).items():
+            io.t2i[name] = [torch.empty(tuple(f.shape), device=dev, dtype=dtype) for f in feats]
         low = UNetLowering(dev, dtype, self.cache, self.lora_mode)
         low.lower(self.unet, io)
         self.cache.sweep()
@@ -136,7 +142,8 @@ class CompiledUNet:
         assert io is not None
         ts = got["timestep"].to(device=io.timestep.device, dtype=torch.float32).reshape(-1)
         io.timestep.copy_(ts.expand(io.timestep.shape[0]) if ts.numel() == 1 else ts)
-        pk = (_ident(got["pooled"]), _ident(got["time_ids"]), tuple(_ident(v) for v in got["tokens"].values()), tuple(_ident(v) for v in got["conditions"].values()))
+        pk = (_ident(got["pooled"]), _ident(got["time_ids"]), tuple(_ident(v) for v in got["tokens"].values()), tuple(_ident(v) for v in got["conditions"].values()),
+              tuple(_ident(f) for feats in got.get("t2i", {}).values() for f in feats))
         if pk == self.prologue_key:
             return False
         if io.pooled is not None:
@@ -148,6 +155,9 @@ class CompiledUNet:
             buf.view(B, -1, v.shape[2])[:, :L].copy_(v)
         for name, v in got["conditions"].items():
             io.conditions[name].copy_(v)
+        for name, feats in got.get("t2i", {}).items():
+            for buf, f in zip(io.t2i[name], feats):
+                buf.copy_(f)
         self.prologue_key = pk
         return True
 
@@ -179,7 +189,8 @@ class CompiledUNet:
         """Same, with the side inputs given explicitly: {"timestep", "pooled", "time_ids", "tokens": {(ctx, key): t},
         "conditions": {ctx_name: t}}.  Does not stage x (the caller fills io.x).  Returns True when the prologue must run."""
         key = (self._tree_state(), tuple(x_shape), self.unet.dtype, tuple((k, tuple(v.shape)) for k, v in got["tokens"].items()),
-               tuple((k, tuple(v.shape)) for k, v in got["conditions"].items()), got["pooled"] is not None)
+               tuple((k, tuple(v.shape)) for k, v in got["conditions"].items()), got["pooled"] is not None,
+               tuple((k, tuple(tuple(f.shape) for f in feats)) for k, feats in got.get("t2i", {}).items()))
         if key != self.key:
             self._build(x_shape, device, got)
             self.key = key
@@ -258,14 +269,17 @@ class CompiledSDXL:
         self.ts_table = self.solver.timesteps.to(device=device, dtype=torch.float32)
 
     def set_inputs(self, x: Tensor, *, clip_text_embedding: Tensor, pooled_text_embedding: Optional[Tensor] = None, time_ids: Optional[Tensor] = None,
-                   clip_image_embedding: Optional[Tensor] = None, conditions: Optional[dict[str, Tensor]] = None) -> None:
+                   clip_image_embedding: Optional[Tensor] = None, conditions: Optional[dict[str, Tensor]] = None,
+                   t2i_features: Optional[dict[str, Any]] = None) -> None:
         """x: (N, 4, H, W) initial latents; embeddings are [negative ; conditional] stacks of 2N rows;
-        `conditions` maps a ControlLora name to its (2N, 3, 8H, 8W) control image."""
+        `conditions` maps a ControlLora name to its (2N, 3, 8H, 8W) control image; `t2i_features` maps a T2I-Adapter name to
+        the tuple its `compute_condition_features` returned (batch 1 or 2N)."""
         tokens = {("cross_attention_block", "clip_text_embedding"): clip_text_embedding}
         if clip_image_embedding is not None:
             tokens[("ip_adapter", "clip_image_embedding")] = clip_image_embedding
         self.inputs = {"pooled": pooled_text_embedding, "time_ids": time_ids, "tokens": tokens,
-                       "conditions": {f"control_lora_{k}": v for k, v in (conditions or {}).items()}}
+                       "conditions": {f"control_lora_{k}": v for k, v in (conditions or {}).items()},
+                       "t2i": {k: tuple(v) for k, v in (t2i_features or {}).items()}}
         if self.x is None or self.x.shape != x.shape or self.x.device != x.device:
             self.x = torch.empty(tuple(x.shape), device=x.device, dtype=self.unet.dtype)
             self.graph = None

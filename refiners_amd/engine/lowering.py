@@ -828,6 +828,7 @@ class UNetIO:
     time_ids: Optional[Tensor] = None  # [B, 6] float32
     tokens: dict[tuple[str, str], tuple[Tensor, int]] = field(default_factory=dict)  # (context, key) -> ([B*Lp, width], L)
     conditions: dict[str, Tensor] = field(default_factory=dict)  # control context name -> [B, 3, 8H, 8W]
+    t2i: dict[str, list[Tensor]] = field(default_factory=dict)  # T2I-Adapter name -> its feature maps, NCHW, batch 1 or B
 
 
 class UNetLowering(Lowering):
@@ -993,6 +994,8 @@ class UNetLowering(Lowering):
             return cur
         elif isa(m, "Residual") and len(kids(m)) == 2 and isa(kids(m)[0], "UseContext") and isa(kids(m)[1], "ConditionEncoder"):
             out = self.add_condition(m, cur)
+        elif isa(m, "T2IFeatures"):
+            out = self.add_t2i_features(m, cur)
         else:
             out = self.torch_node(m, cur)
         self._release(cur)
@@ -1099,6 +1102,29 @@ class UNetLowering(Lowering):
         _expect((e.B, e.H, e.W, e.C) == (cur.B, cur.H, cur.W, cur.C), "ConditionEncoder output does not match the UNet stem")
         out = self.pool.get(cur.M, cur.C)
         native.axpby(cur.t, 1.0, e.t, 1.0, out)
+        return Act(out, cur.B, cur.H, cur.W)
+
+    def add_t2i_features(self, m: Any, cur: Act) -> Act:
+        """x + scale * features[index]   (latent_diffusion/t2i_adapter.py:166-177): the feature map comes from the
+        T2I-Adapter's condition encoder, once per image, as NCHW; it is turned token-major in the prologue (broadcast over
+        the CFG batch when it has batch 1) and added with the node's live scale in one launch per step."""
+        feats = self.io.t2i.get(m.name)
+        _expect(feats is not None and 0 <= m.index < len(feats), f"no T2I-Adapter features registered for '{m.name}'")
+        f = feats[m.index]
+        fb, fc, fh, fw = f.shape
+        _expect((fc, fh, fw) == (cur.C, cur.H, cur.W) and fb in (1, cur.B), f"T2I feature {m.index} of '{m.name}' is {tuple(f.shape)}, the UNet has {(cur.B, cur.C, cur.H, cur.W)} here")
+        with self.in_prologue():
+            tok = self.pool.get(cur.M, cur.C)
+            self.pool.pin(tok)
+            hw = fh * fw
+            if fb == cur.B:
+                native.nchw_to_nhwc(f, tok.view(cur.B, hw, cur.C))
+            else:
+                for b in range(cur.B):
+                    native.nchw_to_nhwc(f, tok[b * hw : (b + 1) * hw].view(1, hw, cur.C))
+        out = self.pool.get(cur.M, cur.C)
+        native.axpby(cur.t, 1.0, tok, float(m.scale), out)
+        self.stats["t2i_sites"] = self.stats.get("t2i_sites", 0) + 1
         return Act(out, cur.B, cur.H, cur.W)
 
     def control_lora(self, node: Any, ctx: UNetContext, H: int, W: int) -> None:

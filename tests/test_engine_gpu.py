@@ -478,3 +478,47 @@ def test_sd15_with_its_default_solver():
     l2, mx = S.rel_err(fast, x)
     print(f"sd1.5 + DPM-Solver++ {steps} steps f32: l2 {l2:.2e} max {mx:.2e}")
     assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+
+
+def test_t2i_adapter_matches_reference():
+    """SDXLUNet + SDXLT2IAdapter -- the four `x + scale * feature` nodes on the engine (features from
+    the adapter's own torch condition encoder, once per image) against the real reference's output; the scale stays live."""
+    import json
+
+    from refiners_amd.latent_diffusion.t2i import SDXLT2IAdapter
+    from tests.golden_cases import T2I_CASE as CFG
+
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", CFG["weight_seed"]), device="cuda", dtype=torch.float32)
+    adapter = SDXLT2IAdapter(unet, name="depth", scale=CFG["scale"]).inject()
+    eshapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "t2i_keys.json").read_text()).items()}
+    adapter.condition_encoder.load_state_dict({k: v.cuda() for k, v in S.synth.synth_state_dict(eshapes, CFG["weight_seed"] + 7).items()}, assign=True)
+    inp = {k: v.cuda() for k, v in S.synth.sdxl_inputs(1, CFG["latent_hw"], CFG["input_seed"]).items()}
+    picture = torch.rand((1, 3, 8 * CFG["latent_hw"][0], 8 * CFG["latent_hw"][1]), generator=S.synth._gen("t2i.condition", CFG["input_seed"])).cuda()
+    ts = DDIM(CFG["num_steps"]).timesteps[CFG["step"]].unsqueeze(0).cuda()
+    with torch.no_grad():
+        feats = adapter.compute_condition_features(picture)
+
+    def run(fast):
+        adapter.set_condition_features(feats)
+        unet.set_timestep(ts)
+        unet.set_clip_text_embedding(inp["text"])
+        unet.set_pooled_text_embedding(inp["pooled"])
+        unet.set_time_ids(inp["time_ids"])
+        return fast(torch.cat((inp["x"], inp["x"])))
+
+    fast = CompiledUNet(unet)
+    y = run(fast)
+    l2, mx = S.rel_err(y, S.golden("sdxl_t2i")["unet_out"])
+    print(f"t2i f32: l2 {l2:.2e} max {mx:.2e} sites {fast.stats.get('t2i_sites')} fallbacks {fast.stats['fallback_nodes']}")
+    assert l2 < F32_TOL and mx < F32_TOL and fast.stats.get("t2i_sites") == 4 and fast.stats["fallback_nodes"] == []
+    adapter.scale = 0.0  # live: re-lowers with the new scale; zero scale == the bare UNet
+    y0 = run(fast)
+    adapter.eject()
+    unet.set_timestep(ts)
+    unet.set_clip_text_embedding(inp["text"])
+    unet.set_pooled_text_embedding(inp["pooled"])
+    unet.set_time_ids(inp["time_ids"])
+    bare = fast(torch.cat((inp["x"], inp["x"])))
+    l2, mx = S.rel_err(y0, bare)
+    assert mx < 1e-5, (l2, mx)
