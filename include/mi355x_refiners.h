@@ -87,6 +87,10 @@ typedef struct {
     int32_t H, W;    /* conv == 1: stored input height / width (before `ups`) */
     int32_t asym;    /* conv == 1: 0 = zero padding ksize/2 on every side; 1 = padding only after the last row / column, i.e.
                         F.pad(x, (0, 1, 0, 1)) followed by an unpadded conv (fl.Downsample(padding=0), layers/sampling.py:41-109) */
+    int32_t kblocked; /* bit 0: w is stored K-BLOCKED, [K*sizeof/128][N rows][128 bytes] (ldw ignored): the N x 128-byte slab a K step
+                         needs is contiguous.  global->LDS streaming slows down with the operand's row stride (10 TB/s at 2.5 KB rows,
+                         5 TB/s at 10 KB, 4.5 TB/s at the 23-46 KB rows of a 3x3 conv's weights: profiles/r01_aa_probe_glds.log), and
+                         weights are static, so the host re-lays them once.  bit 1: the same for x ([K blocks][M rows][128 B], conv == 0). */
 } mi355x_gemm_seg;
 
 typedef struct {
@@ -119,6 +123,8 @@ typedef struct {
     const void* prefetch[MI355X_MAX_PREFETCH];
     int64_t prefetch_bytes[MI355X_MAX_PREFETCH];
     int32_t prefetch_blocks;
+    int32_t out_kblocked;   /* geglu == 1 only: store the [M][N/2] result K-blocked, [(N/2)*sizeof/128][M][128 bytes] (ldo ignored), ready to be
+                               the x operand (kblocked bit 1) of the next GEMM -- FeedForward's second Linear reads 10 KB rows otherwise */
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

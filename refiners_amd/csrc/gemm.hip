@@ -26,6 +26,7 @@ struct SegP {
     int nkb;       // number of 128-byte K blocks in this segment
     int cpb;       // conv: K blocks per tap (= channels*sizeof(T)/128)
     int ksize, stride, ups_shift, H, W;
+    int wkb, xkb;  // operand stored K-blocked: [K block][row][128 B]
     int pad;  // zero rows / columns before the image (ksize / 2, or 0 for the bottom/right-only padding of Downsample(padding=0))
 };
 
@@ -48,6 +49,7 @@ struct GemmP {
     int ksplit, kb_per_split, grid0;  // split-K: ksplit workgroups per tile, each accumulating kb_per_split K blocks
     float* partial;                   // [ksplit][M][N] float32 partial sums (split-K only)
     int tile_hint;                    // 0 = heuristic, 1..5 = caller's choice
+    int out_kb;                       // GEGLU output stored K-blocked ([column block][M rows][128 B]) for the GEMM that consumes it as x
     int krot;                         // debug: rotate each workgroup's K-block order (single-segment, non-split launches)
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
@@ -200,14 +202,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                 const int64_t pix = ((int64_t)xb[it] * sp.H + sy) * sp.W + sx;
                 src = ok ? sp.x + pix * sp.ldxb + (int64_t)cb * 128 + xcoff[it] : p.zeros + xcoff[it];
             } else {
-                src = sp.x + (int64_t)xm[it] * sp.ldxb + (int64_t)kb * 128 + xcoff[it];
+                src = sp.xkb ? sp.x + ((int64_t)kb * p.M + xm[it]) * 128 + xcoff[it] : sp.x + (int64_t)xm[it] * sp.ldxb + (int64_t)kb * 128 + xcoff[it];
             }
             if constexpr (ABL != 3) glds16(src, xs + (it * NTHR + wid * 64) * 16);
             else asm volatile("" ::"v"(src));
         }
 #pragma unroll
         for (int it = 0; it < WI; ++it) {
-            const char* src = sp.w + (int64_t)wnrow[it] * sp.ldwb + (int64_t)kb * 128 + wcoff[it];
+            const char* src = sp.wkb ? sp.w + ((int64_t)kb * p.N + wnrow[it]) * 128 + wcoff[it] : sp.w + (int64_t)wnrow[it] * sp.ldwb + (int64_t)kb * 128 + wcoff[it];
             if constexpr (ABL != 3) glds16(src, ws + (it * NTHR + wid * 64) * 16);
             else asm volatile("" ::"v"(src));
         }
@@ -336,7 +338,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                             for (int e = 0; e < EPC; ++e) o[c * EPC + e] += rv.get(e);
                         }
                     }
-                    T* op = out + (int64_t)m * p.ldo + no;
+                    constexpr int BKE = 128 / (int)sizeof(T);  // elements per 128-byte K block of the consumer
+                    T* op = p.out_kb ? out + ((int64_t)(no / BKE) * p.M + m) * BKE + no % BKE : out + (int64_t)m * p.ldo + no;
 #pragma unroll
                     for (int c = 0; c < HR / EPC; ++c) {
                         Vec16<T> ov;
@@ -621,8 +624,12 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     for (int s = 0; s < a->nseg; ++s) {
         const mi355x_gemm_seg& g = a->seg[s];
         if (!g.x || !g.w || g.k <= 0 || g.k % bke) return MI355X_ESHAPE;
-        if (!aligned16(g.x) || !aligned16(g.w) || (g.ldx * es) % 16 || (g.ldw * es) % 16) return MI355X_ESHAPE;
+        const bool wkb = g.kblocked & 1, xkb = (g.kblocked & 2) != 0;
+        if (xkb && a->conv) return MI355X_ESHAPE;  // the conv loader gathers taps from an image: only its weights can be K-blocked
+        if (!aligned16(g.x) || !aligned16(g.w) || (!xkb && (g.ldx * es) % 16) || (!wkb && (g.ldw * es) % 16)) return MI355X_ESHAPE;
         SegP& d = p.seg[s];
+        d.wkb = wkb ? 1 : 0;
+        d.xkb = xkb ? 1 : 0;
         d.x = static_cast<const char*>(g.x);
         d.w = static_cast<const char*>(g.w);
         d.ldxb = g.ldx * es;
@@ -664,6 +671,8 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     if (a->res) vec = vec && aligned16(a->res) && (a->ldres * es) % 16 == 0;
     p.vec_ok = vec ? 1 : 0;
     if (p.geglu && (!vec || a->N % 64)) return MI355X_ESHAPE;
+    p.out_kb = a->out_kblocked ? 1 : 0;
+    if (p.out_kb && (!p.geglu || a->res || a->N % 256 || a->ksplit > 1)) return MI355X_ESHAPE;  // only the fused-GEGLU store path writes it
     p.tile_hint = a->tile;
     p.krot = g_krot;
     for (int i = 0; i < MI355X_MAX_PREFETCH; ++i) {

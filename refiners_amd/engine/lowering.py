@@ -205,6 +205,7 @@ class Lowering:
         #                       FLOPs.  Scales stay live: changing them re-lowers and re-merges the touched sites only.
         assert lora_mode in ("fused", "merged")
         self.lora_mode = lora_mode
+        self.kblock_policy = int(os.environ.get("REFINERS_AMD_KBLOCK", "2"))
         # independent projections of one attention on a second stream (native.side_branch).  OFF by default: measured on
         # MI355X the forked Q|K / V^T pair makes the SDXL step 2 % SLOWER (29.7 vs 29.0 ms; the join edges cost more than the
         # overlap gains, both GEMMs pull from the same L2s).  Kept as a switch for larger batches / other trees.
@@ -403,20 +404,29 @@ class Lowering:
         native.gemm([(x, lora.a_cat)], t)
         return t
 
-    def linear(self, x: Tensor, spec: LinSpec, *, res: Optional[Tensor] = None, out: Optional[Tensor] = None,
-               rows: Optional[int] = None, lora_t: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
+    def kblocked(self, w: Tensor) -> Any:
+        """The K-blocked copy of a weight matrix whose rows are long enough for the re-layout to pay (native.KBlocked): row
+        strides of 5 KB and more halve the kernel's global -> LDS streaming rate; a 3x3 convolution's packed weights have
+        23-46 KB rows.  Policy REFINERS_AMD_KBLOCK: 0 = never, 1 = rows of >= 5120 bytes, 2 (default) = every weight (SDXL step 32.1 -> 31.1 -> 30.3 ms on one box)."""
+        row_bytes = w.shape[1] * w.element_size()
+        if self.kblock_policy == 0 or (self.kblock_policy == 1 and row_bytes < 5120) or w.device.type == "meta" or not w.is_contiguous():
+            return w
+        return self.cache.get(("kblocked",) + PackCache.ident(w), lambda: native.KBlocked(w))
+
+    def linear(self, x: Any, spec: LinSpec, *, res: Optional[Tensor] = None, out: Optional[Tensor] = None,
+               rows: Optional[int] = None, lora_t: Optional[Tensor] = None, gelu: bool = False, out_kblocked: bool = False) -> Tensor:
         """out[M, N(/2 if geglu)] = epi(x W^T + b (+ LoRA) (+ res)).  `lora_t` lets callers share one down-projection
         launch between Linears that read the same x."""
         M = x.shape[0]
         n_cols = spec.N // 2 if spec.geglu else spec.N
         if out is None:
             out = self.pool.get(M, n_cols)
-        segs = [(x, spec.w)]
+        segs = [(x, self.kblocked(spec.w))]
         t = None
         if spec.lora is not None:
             t = lora_t if lora_t is not None else self.lora_down(x, spec.lora)
             segs.append((t, spec.lora.bs_cat))
-        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu)
+        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked)
         if t is not None and lora_t is None:
             self.pool.put(t)
         return out
@@ -441,7 +451,7 @@ class Lowering:
         H, W = a.H * ups, a.W * ups
         OH, OW = (H + spec.stride - 1) // spec.stride, (W + spec.stride - 1) // spec.stride
         out = self.pool.get(a.B * OH * OW, spec.cout)
-        segs = [(a.image(), spec.w, spec.ksize, spec.stride, ups, int(spec.asym))]
+        segs = [(a.image(), self.kblocked(spec.w), spec.ksize, spec.stride, ups, int(spec.asym))]
         t = None
         if spec.lora is not None:
             kd, ku, st = spec.lora.conv  # type: ignore[misc]
@@ -690,9 +700,13 @@ class Lowering:
         """x += W2 GEGLU(W1 LN(x))   (cross_attention.py:69-72): GEGLU is the epilogue of the first GEMM."""
         _expect(isa(glu, "GLU") and isa(glu.activation, "GeLU") and glu.activation.approximation.value == "none", "only GLU(GeLU(exact)) is fused")
         h = self.layernorm(x, ln)
-        ff = self.linear(h, self.linear_spec(w1, geglu=True))
+        s1, s2 = self.linear_spec(w1, geglu=True), self.linear_spec(w2)
+        # the intermediate [M, 4C] has 10 KB rows at C = 1280: the second GEMM would stream it at half rate, so the GEGLU epilogue
+        # stores it K-blocked (same bytes, [column block][M][128 B]) whenever the kernel's vector store path applies
+        blocked = self.kblock_policy > 0 and s1.lora is None and s2.lora is None and s1.N % 256 == 0 and self.device.type != "meta"
+        ff = self.linear(h, s1, out_kblocked=blocked)
         self.pool.put(h)
-        self.linear(ff, self.linear_spec(w2), res=x, out=x)
+        self.linear(native.KBlocked.adopt(ff.view(-1), ff.shape[0], ff.shape[1]) if blocked else ff, s2, res=x, out=x)
         self.pool.put(ff)
         return x
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 from pathlib import Path
-from typing import Optional, Sequence
+from typing import Any, Optional, Sequence
 
 import torch
 from torch import Tensor
@@ -40,7 +40,53 @@ class GemmSeg(C.Structure):
         ("H", C.c_int32),
         ("W", C.c_int32),
         ("asym", C.c_int32),
+        ("kblocked", C.c_int32),
     ]
+
+
+class KBlocked:
+    """A weight matrix [N, K] re-laid K-BLOCKED for mi355x_gemm: `t` is [K * itemsize / 128][N][128 / itemsize], so the
+    N x 128-byte slab one K step of the kernel streams is contiguous (mi355x_gemm_seg.kblocked).  global -> LDS streaming
+    runs at 10 TB/s on 2.5 KB rows but 5 TB/s on 10 KB rows and 4.5 TB/s on the 23-46 KB rows of a 3x3 convolution's
+    weights (profiles/r01_aa_probe_glds.log); weights are static, so the host pays for the re-layout once."""
+
+    def __init__(self, w: Tensor, _adopt: Optional[tuple[int, int]] = None) -> None:
+        if _adopt is not None:  # `w` already IS the blocked buffer of an [n, k] matrix (written that way by a kernel)
+            self.N, self.K = _adopt
+            self.t = w
+            return
+        assert w.dim() == 2 and w.stride(1) == 1
+        n, k = w.shape
+        blk = 128 // w.element_size()
+        assert k % blk == 0, f"K = {k} is not a multiple of {blk}"
+        self.N, self.K = n, k
+        self.t = w.reshape(n, k // blk, blk).permute(1, 0, 2).contiguous()
+
+    @classmethod
+    def adopt(cls, buf: Tensor, rows: int, k: int) -> "KBlocked":
+        """Wrap a contiguous buffer of rows * k elements that a kernel fills in blocked order (mi355x_gemm_args.out_kblocked)."""
+        assert buf.is_contiguous() and buf.numel() == rows * k
+        return cls(buf, _adopt=(rows, k))
+
+    def dense(self) -> Tensor:
+        """Back to a row-major [N, K] tensor (tests / debugging)."""
+        blk = 128 // self.t.element_size()
+        return self.t.view(self.K // blk, self.N, blk).permute(1, 0, 2).reshape(self.N, self.K)
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        return (self.N, self.K)
+
+    def data_ptr(self) -> int:
+        return self.t.data_ptr()
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.t.dtype
+
+    @property
+    def device(self) -> torch.device:
+        return self.t.device
 
 
 MAX_PREFETCH = 2  # == MI355X_MAX_PREFETCH
@@ -74,6 +120,7 @@ class GemmArgs(C.Structure):
         ("prefetch", C.c_void_p * MAX_PREFETCH),
         ("prefetch_bytes", C.c_int64 * MAX_PREFETCH),
         ("prefetch_blocks", C.c_int32),
+        ("out_kblocked", C.c_int32),
     ]
 
 
@@ -430,10 +477,15 @@ def pack_conv_weight(w: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ call wrappers
-def _seg_plain(x: Tensor, w: Tensor) -> tuple:
-    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1], (x.shape, w.shape)
-    assert x.stride(1) == 1 and w.stride(1) == 1
-    return (x, x.stride(0), w, w.stride(0), x.shape[1], 1, 1, 1, 0, 0)
+def _seg_plain(x: Any, w: Any) -> tuple:
+    """(x, ldx, w, ldw, k, kblocked flags) of one plain K segment; either operand may be a KBlocked weight."""
+    assert tuple(x.shape)[1] == tuple(w.shape)[1], (x.shape, w.shape)
+    flags = (1 if isinstance(w, KBlocked) else 0) | (2 if isinstance(x, KBlocked) else 0)
+    ldx = x.K if isinstance(x, KBlocked) else x.stride(0)
+    ldw = w.K if isinstance(w, KBlocked) else w.stride(0)
+    for t in (x, w):
+        assert isinstance(t, KBlocked) or (t.dim() == 2 and t.stride(1) == 1)
+    return (x, ldx, w, ldw, tuple(x.shape)[1], flags)
 
 
 def gemm(
@@ -453,11 +505,13 @@ def gemm(
     ws: Optional[Tensor] = None,
     prefetch: Optional[Tensor] = None,
     weight_operand: str = "w",
+    out_kblocked: bool = False,
 ) -> Tensor:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
     weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch."""
     a = GemmArgs()
     a.weight_is_x = weight_operand == "x"
+    a.out_kblocked = int(out_kblocked)
     if prefetch is not None:
         a.prefetch[0], a.prefetch_bytes[0] = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     x0, w0 = segs[0]
@@ -471,7 +525,7 @@ def gemm(
         t = _seg_plain(x, w)
         sg = a.seg[s]
         sg.x, sg.ldx, sg.w, sg.ldw, sg.k = t[0].data_ptr(), t[1], t[2].data_ptr(), t[3], t[4]
-        sg.ksize, sg.stride, sg.ups, sg.H, sg.W = 1, 1, 1, 0, 0
+        sg.ksize, sg.stride, sg.ups, sg.H, sg.W, sg.kblocked = 1, 1, 1, 0, 0, t[5]
         keep.append((x, w))
     assert not (geglu and gelu)
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, (3 if gelu == "quick" else 2) if gelu else geglu)
@@ -514,10 +568,11 @@ def conv_gemm(
         assert img.dim() == 4 and img.stride(3) == 1, "conv segment must be an NHWC tensor [B,H,W,C]"
         b, h, wd, c = img.shape
         assert img.stride(1) == wd * img.stride(2) and img.stride(0) == h * img.stride(1), "pixels must be uniformly strided"
-        assert w.shape[1] == ksize * ksize * c and w.stride(1) == 1
+        assert tuple(w.shape)[1] == ksize * ksize * c and (isinstance(w, KBlocked) or w.stride(1) == 1)
         sg = a.seg[s]
-        sg.x, sg.ldx, sg.w, sg.ldw, sg.k = img.data_ptr(), img.stride(2), w.data_ptr(), w.stride(0), c
+        sg.x, sg.ldx, sg.w, sg.ldw, sg.k = img.data_ptr(), img.stride(2), w.data_ptr(), (w.K if isinstance(w, KBlocked) else w.stride(0)), c
         sg.ksize, sg.stride, sg.ups, sg.H, sg.W, sg.asym = ksize, stride, ups, h, wd, asym
+        sg.kblocked = 1 if isinstance(w, KBlocked) else 0
     a.zeros = zero_page(img0.device).data_ptr()
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, False)
     _fill_split(a, tile, ksplit, ws)
@@ -535,9 +590,9 @@ def weight_spans(a: GemmArgs) -> list[tuple[int, int]]:
         sg = a.seg[s]
         k = int(sg.k) * (int(sg.ksize) ** 2 if a.conv else 1)
         if getattr(a, "weight_is_x", False):
-            out.append((int(sg.x or 0), ((int(a.M) - 1) * int(sg.ldx) + k) * es))
+            out.append((int(sg.x or 0), (int(a.M) * k if sg.kblocked & 2 else (int(a.M) - 1) * int(sg.ldx) + k) * es))
         else:
-            out.append((int(sg.w or 0), ((int(a.N) - 1) * int(sg.ldw) + k) * es))
+            out.append((int(sg.w or 0), (int(a.N) * k if sg.kblocked & 1 else (int(a.N) - 1) * int(sg.ldw) + k) * es))
     return out
 
 

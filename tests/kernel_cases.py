@@ -126,6 +126,33 @@ def gemm_geglu_case(M, K, n_out, dtype, seed=30):
     return _cmp(out, ref, dtype)
 
 
+def gemm_geglu_kblocked_chain_case(M, K, n_out, N2, dtype, seed=31):
+    """FeedForward as the engine runs it: GEGLU epilogue storing its [M, n_out] result K-blocked, consumed as the K-blocked x
+    operand of the second GEMM (K-blocked weights too) -- bit-identical to the row-major chain."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(2 * n_out, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(2 * n_out, dtype=dtype, seed=seed + 2)
+    idx = native.geglu_pack_index(n_out, device=DEV)
+    wp, bp = w[idx].contiguous(), b[idx].contiguous()
+    w2 = _rand(N2, n_out, dtype=dtype, seed=seed + 3, scale=n_out ** -0.5)
+    r = _rand(M, N2, dtype=dtype, seed=seed + 4)
+    mid0 = torch.empty(M, n_out, dtype=dtype, device=DEV)
+    out0 = torch.empty(M, N2, dtype=dtype, device=DEV)
+    native.gemm([(x, wp)], mid0, bias=bp, geglu=True)
+    native.gemm([(mid0, w2)], out0, res=r)
+    mid1 = torch.full((M, n_out), float("nan"), dtype=dtype, device=DEV)
+    out1 = torch.full((M, N2), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, native.KBlocked(wp))], mid1, bias=bp, geglu=True, out_kblocked=True)
+    blocked = native.KBlocked.adopt(mid1.view(-1), M, n_out)
+    assert torch.equal(blocked.dense(), mid0), "K-blocked GEGLU store differs from the row-major one"
+    native.gemm([(blocked, native.KBlocked(w2))], out1, res=r)
+    assert torch.equal(out0, out1), "K-blocked chain changed the result"
+    y = x.float() @ w.float().t() + b.float()
+    a, g = y.chunk(2, dim=-1)
+    ref = (a * F.gelu(g, approximate="none")).to(dtype).float() @ w2.float().t() + r.float()
+    return _cmp(out1, ref, dtype)
+
+
 def gemm_vt_case(L, K, Cc, dtype, B=2, seed=40):
     """V^T projection: out[Cc, B*L] = W_v @ x^T (operands swapped) -- the layout mi355x_attention consumes."""
     x = _rand(B * L, K, dtype=dtype, seed=seed)
@@ -373,6 +400,39 @@ def gemm_prefetch_case(M, K, N, dtype, ksplit=1, seed=37):
     return _cmp(out1, ref, dtype)
 
 
+def gemm_kblocked_case(M, K, N, dtype, which="w", seed=38):
+    """K-blocked operand layout ([K block][row][128 B]): same arithmetic in the same order, so the result must be bit-identical
+    to the row-major launch; `which` = "w" (weights in the w slot), "x" (the transposed projections) or "both"."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2)
+    out0 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    out1 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, w)], out0, bias=b)
+    xa = native.KBlocked(x) if which in ("x", "both") else x
+    wa = native.KBlocked(w) if which in ("w", "both") else w
+    native.gemm([(xa, wa)], out1, bias=b)
+    assert torch.equal(out0, out1), "K-blocked operand changed the result"
+    y = x.float() @ w.float().t() + b.float()
+    return _cmp(out1, y, dtype)
+
+
+def conv_kblocked_case(B, Cin, Cout, H, W, dtype, ksplit=1, seed=39):
+    """3x3 convolution with K-blocked packed weights vs the same launch with row-major packed weights (bit-identical)."""
+    x = _rand(B, H, W, Cin, dtype=dtype, seed=seed)
+    w4 = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=(Cin * 9) ** -0.5)
+    wp = native.pack_conv_weight(w4)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2)
+    ws = torch.empty(ksplit * B * H * W * Cout, dtype=torch.float32, device=DEV) if ksplit > 1 else None
+    out0 = torch.full((B * H * W, Cout), float("nan"), dtype=dtype, device=DEV)
+    out1 = torch.full((B * H * W, Cout), float("nan"), dtype=dtype, device=DEV)
+    native.conv_gemm([(x, wp, 3, 1, 1)], out0, B, H, W, bias=b, ksplit=ksplit, ws=ws, tile=1 if ksplit > 1 else 0)
+    native.conv_gemm([(x, native.KBlocked(wp), 3, 1, 1)], out1, B, H, W, bias=b, ksplit=ksplit, ws=ws, tile=1 if ksplit > 1 else 0)
+    assert torch.equal(out0, out1), "K-blocked conv weights changed the result"
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w4.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    return _cmp(out1, ref, dtype)
+
+
 def gemm_quick_gelu_case(M, K, N, dtype, seed=36):
     """CLIP-L's FeedForward activation, x * sigmoid(1.702 x) (GeLUApproximation.SIGMOID), as the GEMM epilogue."""
     x = _rand(M, K, dtype=dtype, seed=seed)
@@ -484,6 +544,12 @@ def all_cases():
             (f"gemm_{tag}_gelu_res_1000x640x384", lambda dt=dt: gemm_gelu_case(1000, 640, 384, dt)),
             (f"gemm_{tag}_gelu_Nedge", lambda dt=dt: gemm_gelu_case(300, 640, 200, dt)),
             (f"gemm_{tag}_quick_gelu_154x768x3072", lambda dt=dt: gemm_quick_gelu_case(154, 768, 3072, dt)),
+            (f"gemm_{tag}_geglu_kblocked_chain", lambda dt=dt: gemm_geglu_kblocked_chain_case(300, 640, 2560, 640, dt)),
+            (f"gemm_{tag}_kblocked_w_300x5120x200", lambda dt=dt: gemm_kblocked_case(300, 5120, 200, dt)),
+            (f"gemm_{tag}_kblocked_x_1280x640x2048", lambda dt=dt: gemm_kblocked_case(1280, 640, 2048, dt, which="x")),
+            (f"gemm_{tag}_kblocked_both_154x768x320", lambda dt=dt: gemm_kblocked_case(154, 768, 320, dt, which="both")),
+            (f"conv_{tag}_kblocked_3x3_640", lambda dt=dt: conv_kblocked_case(2, 640, 320, 16, 16, dt)),
+            (f"conv_{tag}_kblocked_3x3_splitk3", lambda dt=dt: conv_kblocked_case(1, 640, 640, 16, 16, dt, ksplit=3)),
             (f"gemm_{tag}_prefetch_300x640x200", lambda dt=dt: gemm_prefetch_case(300, 640, 200, dt)),
             (f"gemm_{tag}_prefetch_2048x1280x1280", lambda dt=dt: gemm_prefetch_case(2048, 1280, 1280, dt)),
             (f"gemm_{tag}_prefetch_splitk3", lambda dt=dt: gemm_prefetch_case(512, 1920, 384, dt, ksplit=3)),
