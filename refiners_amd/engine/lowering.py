@@ -434,7 +434,7 @@ class Lowering:
     def linear_T(self, x: Tensor, spec: LinSpec, out_t: Tensor) -> Tensor:
         """out_t[N, M] = W x^T (+ LoRA): the V^T layout mi355x_attention consumes (operands swapped, no bias)."""
         _expect(spec.b is None, "transposed projection with bias is not supported")
-        segs = [(spec.w, x)]
+        segs = [(self.kblocked(spec.w), x)]
         t = None
         if spec.lora is not None:
             t = self.lora_down(x, spec.lora)
@@ -632,7 +632,7 @@ class Lowering:
         if qs.lora is None and ks.lora is None:
             wqk = self.cache.get(("qk",) + PackCache.ident(qs.w, ks.w), lambda: torch.cat([qs.w, ks.w], 0).contiguous())
             qk = self.pool.get(M, 2 * C)
-            native.gemm([(h, wqk)], qk)
+            native.gemm([(h, self.kblocked(wqk))], qk)
             q, k = qk[:, :C], qk[:, C:]
         else:
             qk = None

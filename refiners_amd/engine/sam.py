@@ -128,7 +128,7 @@ class SAMLowering(Lowering):
             native.gather_rows(att, merge, am)
             self.pool.put(att)
             att = am
-        native.gemm([(att, out_spec.w)], tok, bias=out_bias, res=tok)
+        native.gemm([(att, self.kblocked(out_spec.w))], tok, bias=out_bias, res=tok)
         self.pool.put(att)
         _expect(len(r2) == 2 and isa(r2[0], "LayerNorm") and isa(r2[1], "FeedForward"), "unexpected MLP residual")
         ff = kids(r2[1])
@@ -204,16 +204,16 @@ class SAMLowering(Lowering):
         L, Dq, Lp = S1 * S2, packs["Dq"], packs["Lp"]
         Mw = n * L
         qp = self.pool.get(Mw, H * Lp)
-        native.gemm([(h, packs["wqp"])], qp, bias=packs["bqp"])
+        native.gemm([(h, self.kblocked(packs["wqp"]))], qp, bias=packs["bqp"])
         q = self.pool.get(Mw, H * Dq)
         native.relpos_pack(qp, q, H, d, S1, S2, Lp, Dq)
         self.pool.put(qp)
         k = self.pool.get(Mw, H * Dq)
-        native.gemm([(h, packs["wkp"])], k, bias=packs["bkp"], res=self._onehot_rows(n, H, d, S1, S2, Dq))
+        native.gemm([(h, self.kblocked(packs["wkp"]))], k, bias=packs["bkp"], res=self._onehot_rows(n, H, d, S1, S2, Dq))
         lkp = (L + 63) // 64 * 64
         if lkp == L:
             vt = self.pool.get(C, Mw)
-            native.gemm([(packs["wv"], h)], vt, weight_operand="x")
+            native.gemm([(self.kblocked(packs["wv"]), h)], vt, weight_operand="x")
         else:
             # every window's V^T columns start on a 64-key boundary: a second gather of the SAME LayerNorm output with
             # the windows padded to lkp rows (zero rows -> zero V^T columns, which masked keys multiply by exactly 0)
@@ -221,7 +221,7 @@ class SAMLowering(Lowering):
             hv = self.pool.get(n * lkp, C)
             native.gather_rows(h_full, part_v, hv)
             vt = self.pool.get(C, n * lkp)
-            native.gemm([(packs["wv"], hv)], vt, weight_operand="x")
+            native.gemm([(self.kblocked(packs["wv"]), hv)], vt, weight_operand="x")
             self.pool.put(hv)
         att = self.pool.get(Mw, C)
         native.attention_general(q.view(n, L, H * Dq), k.view(n, L, H * Dq), vt.view(C, n, lkp), att.view(n, L, C), H, L, scale=1.0)

@@ -62,16 +62,16 @@ class TextLowering(Lowering):
             z = lambda s: s.b if s.b is not None else torch.zeros(C, device=self.device, dtype=self.dtype)  # noqa: E731
             bqk = self.cache.get(("clip_bqk",) + ident, lambda: torch.cat([z(qs), z(ks)]).contiguous())
         qk = self.pool.get(M, 2 * C)
-        native.gemm([(h, wqk)], qk, bias=bqk)
+        native.gemm([(h, self.kblocked(wqk))], qk, bias=bqk)
         lkp = self._pad_keys(L)
         if lkp == L:
             vt = self.pool.get(C, M)
-            native.gemm([(vs.w, h)], vt, weight_operand="x")
+            native.gemm([(self.kblocked(vs.w), h)], vt, weight_operand="x")
         else:  # every sample's V^T columns start on a 64-key boundary; the padding is zeroed once, here
             vt = torch.zeros(C, B * lkp, device=self.device, dtype=self.dtype)
             self.__dict__.setdefault("_keep", []).append(vt)
             for b in range(B):
-                native.gemm([(vs.w, h[b * L : (b + 1) * L])], vt[:, b * lkp : b * lkp + L], weight_operand="x")
+                native.gemm([(self.kblocked(vs.w), h[b * L : (b + 1) * L])], vt[:, b * lkp : b * lkp + L], weight_operand="x")
         self.pool.put(h)
         o = self.pool.get(M, C)
         q3 = qk.as_strided((B, L, C), (L * qk.stride(0), qk.stride(0), 1))
@@ -90,7 +90,7 @@ class TextLowering(Lowering):
                 return (acc + os_.b.float() if os_.b is not None else acc).to(self.dtype).contiguous()
 
             bo = self.cache.get(("clip_bo",) + PackCache.ident(os_.w, os_.b, vs.b), fold)
-        native.gemm([(o, os_.w)], x, bias=bo, res=x)
+        native.gemm([(o, self.kblocked(os_.w))], x, bias=bo, res=x)
         self.pool.put(o)
         return x
 
