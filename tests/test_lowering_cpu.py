@@ -188,3 +188,23 @@ def test_weight_prefetch_links_every_gemm_to_the_next_ones_weights():
     assert all(32 <= a.prefetch_blocks <= 128 for a in g)
     native.link_weight_prefetch(ops, enable=False)
     assert all(not a.prefetch[0] and a.prefetch_blocks == 0 for a in g)
+
+
+def test_kblocked_wrapper_round_trips_and_is_what_prefetch_sees():
+    """native.KBlocked: [N, K] -> [K / block][N][block] and back; a recorded launch with a K-blocked weight reports N * K bytes."""
+    import ctypes as C
+
+    from refiners_amd import native
+
+    for dtype, blk in ((torch.bfloat16, 64), (torch.float32, 32)):
+        w = torch.randn(37, 5 * blk).to(dtype)
+        kb = native.KBlocked(w)
+        assert kb.shape == (37, 5 * blk) and tuple(kb.t.shape) == (5, 37, blk) and kb.dtype == dtype
+        assert torch.equal(kb.dense(), w)
+        assert torch.equal(kb.t[2, 11], w[11, 2 * blk : 3 * blk])  # K block 2 of row 11
+        adopted = native.KBlocked.adopt(kb.t.reshape(-1), 37, 5 * blk)
+        assert torch.equal(adopted.dense(), w)
+    a = native.GemmArgs()
+    a.dtype, a.M, a.N, a.nseg, a.conv = 1, 2048, 1280, 1, 0
+    a.seg[0].k, a.seg[0].ksize, a.seg[0].w, a.seg[0].ldw, a.seg[0].kblocked = 5120, 1, 0x1000, 5120, 1
+    assert native.weight_spans(a) == [(0x1000, 1280 * 5120 * 2)]
