@@ -293,12 +293,40 @@ def sdxl_unet(sd: SD, x: Tensor, timestep: Tensor, text: Tensor, pooled: Tensor,
 
 
 @torch.no_grad()
-def sd1_unet(sd: SD, x: Tensor, timestep: Tensor, text: Tensor) -> Tensor:
-    """SD1UNet.forward (stable_diffusion_1/unet.py:165-249): 13 residual slots, middle block summed with residuals[-1]."""
+def sd1_controlnet_residuals(cn: SD, x: Tensor, timestep: Tensor, text: Tensor, condition: Tensor, scale: float, scale_decay: float) -> list[Tensor]:
+    """Controlnet (stable_diffusion_1/controlnet.py:66-150): its own TimestepEncoder / DownBlocks / MiddleBlock weights; the
+    ConditionEncoder output is added right after conv_in (BEFORE the first 1x1 conv, unlike ControlLora); every block output goes
+    through a 1x1 conv and is scaled by scale * scale_decay^(12 - n)."""
+    net = _Net(cn, None)
+    t = sinusoidal_embedding(timestep, 320)
+    temb = net.linear("TimestepEncoder.RangeEncoder.Linear_2", F.silu(net.linear("TimestepEncoder.RangeEncoder.Linear_1", t)))
+    x = x[:, :4]
+    enc = {k.removeprefix("DownBlocks.Chain_1.Residual.ConditionEncoder."): v for k, v in cn.items() if "ConditionEncoder." in k}
+    out: list[Tensor] = []
+    shapes: list = []
+    for n, kinds in enumerate(SD1_DOWN):
+        x = _stage(net, f"DownBlocks.Chain_{n + 1}", kinds, "sd1", x, temb, text, None, shapes)
+        if n == 0:
+            x = x + condition_encoder(enc, condition)
+        out.append(net.conv(f"DownBlocks.Chain_{n + 1}.Passthrough.Conv2d", x) * scale * scale_decay ** float(12 - n))
+    x = residual_block(net, "MiddleBlock.ResidualBlock_1", x, temb)
+    x = cross_attention_2d(net, "MiddleBlock.CLIPLCrossAttention", x, text, 8, False, None)
+    x = residual_block(net, "MiddleBlock.ResidualBlock_2", x, temb)
+    out.append(net.conv("MiddleBlock.Passthrough.Conv2d", x) * scale)
+    return out
+
+
+@torch.no_grad()
+def sd1_unet(sd: SD, x: Tensor, timestep: Tensor, text: Tensor, controlnets: list | None = None) -> Tensor:
+    """SD1UNet.forward (stable_diffusion_1/unet.py:165-249): 13 residual slots, middle block summed with residuals[-1].
+    `controlnets`: dicts {weights, condition, scale, scale_decay}; each runs first and pre-populates the slots."""
     net = _Net(sd, None)
     t = sinusoidal_embedding(timestep, 320)
     temb = net.linear("TimestepEncoder.RangeEncoder.Linear_2", F.silu(net.linear("TimestepEncoder.RangeEncoder.Linear_1", t)))
     residuals: list[Any] = [0.0] * 13
+    for c in controlnets or []:
+        extra = sd1_controlnet_residuals(c["weights"], x, timestep, text, c["condition"], c["scale"], c["scale_decay"])
+        residuals = [r + e for r, e in zip(residuals, extra)]
     shapes: list = []
     for n, kinds in enumerate(SD1_DOWN):
         x = _stage(net, f"DownBlocks.Chain_{n + 1}", kinds, "sd1", x, temb, text, None, shapes)

@@ -120,3 +120,4 @@ def kohya_sdxl_lora_keys(rank: int = 8):
 
 # ------------------------------------------------------------------------------------------------ next-4: T2I-Adapter
 T2I_CASE = dict(weight_seed=0, input_seed=31, latent_hw=(32, 32), num_steps=50, step=20, scale=0.8)
+CONTROLNET_CASE = dict(weight_seed=0, input_seed=41, latent_hw=(16, 16), timestep=601, scale=0.8, scale_decay=0.9)
