@@ -60,7 +60,8 @@ struct GemmP {
     int vec_ok;
 };
 
-// ABL (ablation, probing only): 0 = the real kernel; 1 = no MFMA; 2 = no LDS fragment reads; 3 = no global->LDS loads
+// ABL (ablation, probing only): 0 = the real kernel; 1 = no MFMA; 2 = no LDS fragment reads; 3 = no global->LDS loads;
+// 4 = the real kernel with the older loader that recomputes every address from the segment descriptor in every iteration
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int NTHR = WM * WN * 64;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         }
     }
 
-    auto issue = [&](int buf) {
+    auto issue_legacy = [&](int buf) {
         const SegP& sp = p.seg[seg];
         char* xs = smem + buf * STAGE;
         char* ws = xs + XBYTES;
@@ -219,30 +220,117 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
             if (!rotate) ++seg;
         }
     };
+    // ---- fast loader state (ABL != 4): everything that does not change from one K block to the next is hoisted out of the loop.
+    // Per thread: the row base pointers of the current segment (conv: of the current tap) with the swizzled chunk offset folded
+    // in; per workgroup: a running byte offset along K.  The per-iteration cost of a load is one 64-bit add; the segment
+    // descriptor (a dynamically indexed kernel argument, i.e. scalar loads + waits) is touched only when the segment or tap changes.
+    const char* xbase[XI];
+    const char* wbase[WI];
+    int64_t xstep = 128, wstep = 128;  // bytes from one K block to the next (row-major: 128; K-blocked: rows * 128)
+    int64_t xoff = 0, woff = 0;        // running offsets inside the current segment
+    int cur_nkb = 0, cur_cpb = 1, tap = 0, cb = 0;
+    auto set_tap = [&](const SegP& sp) {  // conv: per-thread pixel pointers of tap `tap` (zero page for padding / out-of-tile rows)
+        int dy = tap / sp.ksize, dx = tap - dy * sp.ksize;
+        dy -= sp.pad;
+        dx -= sp.pad;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int iy = xoy[it] * sp.stride + dy, ix = xox[it] * sp.stride + dx;
+            const int HH = sp.H << sp.ups_shift, WW = sp.W << sp.ups_shift;
+            const bool ok = xvalid[it] && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
+            const int sy = iy >> sp.ups_shift, sx = ix >> sp.ups_shift;
+            const int64_t pix = ((int64_t)xb[it] * sp.H + sy) * sp.W + sx;
+            xbase[it] = ok ? sp.x + pix * sp.ldxb + xcoff[it] : nullptr;
+        }
+    };
+    auto enter = [&](int s, int kb0) {  // make segment s current, positioned at its K block kb0
+        const SegP& sp = p.seg[s];
+        cur_nkb = sp.nkb;
+        cur_cpb = sp.cpb;
+        wstep = sp.wkb ? (int64_t)p.N * 128 : 128;
+        woff = (int64_t)kb0 * wstep;
+#pragma unroll
+        for (int it = 0; it < WI; ++it) wbase[it] = sp.w + (sp.wkb ? (int64_t)wnrow[it] * 128 : (int64_t)wnrow[it] * sp.ldwb) + wcoff[it];
+        if constexpr (CONV) {
+            tap = kb0 / sp.cpb;
+            cb = kb0 - tap * sp.cpb;
+            set_tap(sp);
+        } else {
+            xstep = sp.xkb ? (int64_t)p.M * 128 : 128;
+            xoff = (int64_t)kb0 * xstep;
+#pragma unroll
+            for (int it = 0; it < XI; ++it) xbase[it] = sp.x + (sp.xkb ? (int64_t)xm[it] * 128 : (int64_t)xm[it] * sp.ldxb) + xcoff[it];
+        }
+    };
+    if constexpr (ABL != 4) enter(seg, kb);
+
+    auto issue = [&](int buf) {
+        if constexpr (ABL == 4) {
+            issue_legacy(buf);
+        } else {
+            char* xs = smem + buf * STAGE;
+            char* ws = xs + XBYTES;
+#pragma unroll
+            for (int it = 0; it < XI; ++it) {
+                const char* src;
+                if constexpr (CONV) src = xbase[it] ? xbase[it] + (int64_t)cb * 128 : p.zeros + xcoff[it];
+                else src = xbase[it] + xoff;
+                if constexpr (ABL != 3) glds16(src, xs + (it * NTHR + wid * 64) * 16);
+                else asm volatile("" ::"v"(src));
+            }
+#pragma unroll
+            for (int it = 0; it < WI; ++it) {
+                const char* src = wbase[it] + woff;
+                if constexpr (ABL != 3) glds16(src, ws + (it * NTHR + wid * 64) * 16);
+                else asm volatile("" ::"v"(src));
+            }
+            // advance along K; cross into the next tap / segment when this one is exhausted
+            ++kb;
+            woff += wstep;
+            if constexpr (CONV) {
+                if (++cb == cur_cpb) {
+                    cb = 0;
+                    ++tap;
+                    if (kb < cur_nkb) set_tap(p.seg[seg]);
+                }
+            } else {
+                xoff += xstep;
+            }
+            if (kb == cur_nkb) {
+                kb = 0;
+                if (!rotate) ++seg;
+                if (seg < p.nseg) enter(seg, 0);
+            }
+        }
+    };
     auto compute = [&](int buf) {
         const char* xs = smem + buf * STAGE;
         const char* ws = xs + XBYTES;
+        // all 2 x (MT + NT) fragment reads of the K block are issued before the first MFMA, so that the LDS latency of the
+        // second half overlaps the matrix work of the first (the compiler then waits with counted lgkmcnt, not lgkmcnt(0) twice)
+        frag_t xf[2][MT], wf[2][NT];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            frag_t xf[MT], wf[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if constexpr (ABL != 2) xf[i] = lds_read_frag(xs, tile_off<128>(wm * 16 * MT + 16 * i + c16, 4 * kk + g));
-                else xf[i] = frag_t{i + buf, kk, lane, 1};
+                if constexpr (ABL != 2) xf[kk][i] = lds_read_frag(xs, tile_off<128>(wm * 16 * MT + 16 * i + c16, 4 * kk + g));
+                else xf[kk][i] = frag_t{i + buf, kk, lane, 1};
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if constexpr (ABL != 2) wf[j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
-                else wf[j] = frag_t{j, kk + buf, lane, 2};
+                if constexpr (ABL != 2) wf[kk][j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
+                else wf[kk][j] = frag_t{j, kk + buf, lane, 2};
             }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    if constexpr (ABL != 1) mma_step<T>(acc[i][j], wf[j], xf[i]);
-                    else asm volatile("" ::"v"(wf[j]), "v"(xf[i]));
+                    if constexpr (ABL != 1) mma_step<T>(acc[i][j], wf[kk][j], xf[kk][i]);
+                    else asm volatile("" ::"v"(wf[kk][j]), "v"(xf[kk][i]));
                 }
-        }
     };
 
     // ---- software pipeline: NSTAGE LDS buffers, D = NSTAGE - 1 K blocks in flight -------------------------------------
@@ -492,6 +580,7 @@ int g_krot = 0;    // 0 = off, n = workgroup i of an XCD starts its K loop at bl
 // The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
 // how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.
 int g_alt = 0;  // probing: alternative tile / stage heuristics
+int g_legacy = 0;  // probing: 1 = the pre-hoisting loader (per-iteration address arithmetic, ABL = 4) for A/B runs
 inline int pick_stages_default(const GemmP&, int);
 inline int pick_tile(const GemmP& p, bool conv) {
     // measured on MI355X over the UNet's shapes (tools/probe_gemm.py, profiles/r01_b_probe_gemm_tiles.log)
@@ -526,7 +615,7 @@ inline int pick_stages_default(const GemmP&, int) {
 template <typename T, int BM, int BN, bool CONV>
 int launch_stages(const GemmP& p, int stages, hipStream_t stream) {
     switch (stages) {
-        case 2: return launch_cfg<T, BM, BN, 2, 2, CONV, 2>(p, stream);
+        case 2: return g_legacy ? launch_cfg<T, BM, BN, 2, 2, CONV, 2, 4>(p, stream) : launch_cfg<T, BM, BN, 2, 2, CONV, 2>(p, stream);
         case 4: return launch_cfg<T, BM, BN, 2, 2, CONV, 4>(p, stream);
         default: return launch_cfg<T, BM, BN, 2, 2, CONV, 3>(p, stream);
     }
@@ -589,6 +678,10 @@ extern "C" int mi355x_set_option(const char* name, int value) {
     if (name && name[0] == 'p') {  // "pfblocks" / "pfmode"
         if (name[2] == 'b') g_pf_blocks = value < 0 ? 0 : (value + 7) / 8 * 8;
         else g_pf_mode = value;
+        return MI355X_OK;
+    }
+    if (name && name[0] == 'l') {  // "legacy"
+        g_legacy = value;
         return MI355X_OK;
     }
     if (name && name[0] == 'h') {  // "heur"

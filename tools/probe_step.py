@@ -31,20 +31,10 @@ def main():
     native.link_weight_prefetch(ops, enable=False)
     print(f"no prefetch: {t():.2f} ms", flush=True)
     native.link_weight_prefetch(ops)
-    print(f"prefetch on, replay without a graph: {t():.2f} ms  (python glue ops in the program: {sum(1 for e in ops if e[0] is None)})", flush=True)
-    # the number that matters: one HIP-graph launch per step
-    import time
-    for i in range(3):
-        pipe2 = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=True, lora_mode="merged")
-        pipe2.set_inputs(inp["x"].to(dev), clip_text_embedding=inp["text"].to(dev), pooled_text_embedding=inp["pooled"].to(dev), time_ids=inp["time_ids"].to(dev))
-        for k in range(3):
-            pipe2.step(k)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(20):
-            pipe2.step(k)
-        torch.cuda.synchronize()
-        print(f"graph replay: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/step", flush=True)
+    for legacy in (1, 0, 1, 0):
+        native.load().mi355x_set_option(b"legacy", legacy)
+        print(f"{'per-iteration address arithmetic (old loader)' if legacy else 'hoisted row pointers (new loader)       '}: {t():.2f} ms", flush=True)
+    native.load().mi355x_set_option(b"legacy", 0)
 
 
 if __name__ == "__main__":
