@@ -181,7 +181,7 @@ class CompiledUNet:
         sig = []
         for m in self.unet.modules():
             sig.append(id(m))
-            if isa(m, "Multiply"):
+            if isa(m, "Multiply", "T2IFeatures"):  # nodes whose live scale is baked into the program
                 sig.append(float(m.scale))
         return hash(tuple(sig))
 
