@@ -5,16 +5,20 @@
 
 A "step" is one DDIM denoising step of one 1024x1024 image per GPU: SDXL-base UNet forward on the classifier-free-
 guidance pair (batch 2, 4x128x128 latents, 77 text tokens) + CFG combine + DDIM update, bfloat16, replayed as one HIP
-graph (BASELINE.json configs[1]; `--workload lora_ip` runs configs[2]: two rank-16 LoRAs on all 722 transformer
-Linears + IP-Adapter).  Weights are random-init of the real architecture, inputs synthetic, both resident in HBM before
-the timed region.  Multi-GPU: one process per GPU, independent prompts per rank (weak scaling), ONE RCCL broadcast of
-the weights at start-up, no per-step collective.  Rank 0 prints ONE JSON line.
+graph.  The default workload is the north star's TARGET, BASELINE.json configs[2]: two rank-16 LoRAs on all 722
+transformer Linears + IP-Adapter injected through Adapter.inject(); `--workload bare` is configs[1] (also measured by the
+default run and reported under `extra.configs1_bare`), `--workload control --images-per-gpu 4` configs[3]'s per-GPU shape.
+Weights are random-init of the real architecture, inputs synthetic, both resident in HBM before the timed region.
+Multi-GPU: one process per GPU, independent prompts per rank (weak scaling), ONE RCCL broadcast of the weights at
+start-up, no per-step collective; `python bench.py --gpus N` without a torchrun environment re-launches itself through
+torch.distributed.run.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 from pathlib import Path
@@ -68,6 +72,28 @@ def op_flops(entry) -> float:
     return 0.0
 
 
+def respawn_under_torchrun(n: int) -> None:
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: become `python -m torch.distributed.run ...` with
+    the same arguments, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(__file__).resolve()), *sys.argv[1:]]
+    os.execv(sys.executable, cmd)
+
+
+def pmc_mfma_util(family: str):
+    """MFMA utilisation of a kernel family from the latest committed counter pass (tools/profile_round.py: a separate
+    `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...` run of this same command)."""
+    try:
+        f = sorted((ROOT / "profiles").glob("r*_pmc_mfma.json"))[-1]
+        fam = json.loads(f.read_text())["families"][family]
+        return dict(fam, source=f"profiles/{f.name}")
+    except Exception:  # noqa: BLE001 -- no committed pass
+        return None
+
+
 def pmc_traffic(family: str):
     """HBM-side bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are
     separate profiler runs, they cannot be taken inside this process): FETCH_SIZE doubled per MI355X_MICROARCH.md, KiB -> B."""
@@ -95,58 +121,39 @@ def time_ops(ops, iters: int = 5) -> float:
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["bare", "lora_ip", "control"], default="bare",
-                    help="bare = BASELINE configs[1]; lora_ip = configs[2]; control = configs[3] (ControlLora canny; use --images-per-gpu 4 for its 32-prompt / 8-GPU shape)")
-    ap.add_argument("--images-per-gpu", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the informational extras (VAE decode, 4-images-per-GPU point): for profiler passes")
-    ap.add_argument("--lora-mode", choices=["fused", "merged"], default="merged",
-                    help="merged: W' = W + sum s B A formed at lowering time (one launch per adapted layer); fused: run-time LoRA K segments")
-    args = ap.parse_args()
+WORKLOADS = {
+    "bare": ("configs[1]", ""),
+    "lora_ip": ("configs[2]", " + 2 LoRA r16 (722 Linears) + IP-Adapter"),
+    "control": ("configs[3]", " + ControlLora (canny)"),
+}
 
+
+def build_pipeline(workload: str, n_img: int, rank: int, dev: torch.device, dtype: torch.dtype, lora_mode: str, use_graph: bool, broadcast: bool = True):
+    """UNet (random init in HBM) + adapters injected through the Chain API + one CompiledSDXL with its inputs staged."""
     import refiners_amd
-    from refiners_amd import native, parallel, synth
+    from refiners_amd import parallel, synth
     from refiners_amd.engine.compiled import CompiledSDXL
     from refiners_amd.latent_diffusion.sdxl import SDXLUNet
 
-    rank, world, local = parallel.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    native.load()
-    dtype = torch.bfloat16
-
-    # ---- model: rank 0 draws the weights, everyone else receives them over RCCL / xGMI --------------------------------
-    t0 = time.time()
     unet = SDXLUNet(4, device="meta")
-    gpu_weights(unet, seed=0 if rank == 0 else 1000 + rank, dtype=dtype, device=dev)
+    gpu_weights(unet, seed=0 if rank == 0 else 1000 + rank, dtype=dtype, device=dev)  # rank 0 draws; the others receive (below)
+    bare_sd = dict(unet.state_dict())  # references to the bare model's tensors, for the CPU baseline
     specs = {"loras": [], "ip": None, "control": []}
-    if args.workload == "lora_ip":
-        shapes = synth.model_shapes(unet)
+    shapes = synth.model_shapes(unet)
+    if workload == "lora_ip":
         specs = {"loras": [synth.lora_spec(shapes, "l1", 1.0, seed=5), synth.lora_spec(shapes, "l2", 0.8, seed=5)],
-                 "ip": synth.ip_spec(shapes, 0.6, batch=2 * args.images_per_gpu, seed=5), "control": []}
-        synth.apply_adapters(unet, refiners_amd.namespace(), device=dev, dtype=dtype, **specs)
-    if args.workload == "control":
-        specs = {"loras": [], "ip": None, "control": [synth.control_spec("canny", 1.0, 2 * args.images_per_gpu, LATENT, seed=5)]}
+                 "ip": synth.ip_spec(shapes, 0.6, batch=2 * n_img, seed=5), "control": []}
+    if workload == "control":
+        specs = {"loras": [], "ip": None, "control": [synth.control_spec("canny", 1.0, 2 * n_img, LATENT, seed=5)]}
+    if workload != "bare":
         synth.apply_adapters(unet, refiners_amd.namespace(), device=dev, dtype=dtype, **specs)
     torch.cuda.synchronize()
     tb = time.time()
-    n_bcast = parallel.broadcast_module(unet, src=0)
+    n_bcast = parallel.broadcast_module(unet, src=0) if broadcast else 0
     torch.cuda.synchronize()
     bcast_s = time.time() - tb
-    n_params = sum(p.numel() for p in unet.parameters())
-
-    # ---- inputs: independent prompts per rank, resident in HBM -------------------------------------------------------
-    n_img = args.images_per_gpu
     inp = synth.sdxl_inputs(n_img, LATENT, seed=100 + rank)
-    pipe = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=not args.no_graph, lora_mode=args.lora_mode)
+    pipe = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=use_graph, lora_mode=lora_mode)
     kw = {}
     if specs["ip"] is not None:
         kw["clip_image_embedding"] = specs["ip"]["tokens"].to(dev)
@@ -154,33 +161,31 @@ def main() -> None:
         kw["conditions"] = {c["name"]: c["condition"].to(dev) for c in specs["control"]}
     pipe.set_inputs(inp["x"].to(dev), clip_text_embedding=inp["text"].to(dev), pooled_text_embedding=inp["pooled"].to(dev),
                     time_ids=inp["time_ids"].to(dev), **kw)
-    for i in range(args.warmup):
+    return unet, specs, bare_sd, pipe, {"weights_broadcast_s": round(bcast_s, 3), "broadcast_launches": n_bcast}
+
+
+def timed_steps(pipe, steps: int, warmup: int, world: int, dev: torch.device) -> float:
+    """W untimed steps, then exactly K steps between barrier + synchronize pairs; seconds, max over ranks."""
+    from refiners_amd import parallel
+
+    for i in range(warmup):
         pipe.step(i % 50)
     torch.cuda.synchronize()
-    setup_s = time.time() - t0
-
-    # ---- timed region: exactly K steps between barrier + synchronize on both sides --------------------------------
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         pipe.step(i % 50)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t1, device=dev)
-    finite = bool(torch.isfinite(pipe.x.float()).all())
+    return parallel.max_over_ranks(time.perf_counter() - t1, device=dev)
 
-    if rank != 0:
-        if world > 1:
-            torch.distributed.barrier()
-        return
 
-    ms_per_step = elapsed / args.steps * 1e3
-    images_per_s = world * n_img / (ms_per_step * 1e-3 * 50)
+def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict:
+    """Per-entry-point replay of the recorded step (HIP events on the launch stream, outside the timed region)."""
     low = pipe.engine.low
-    # ---- roofline of the dominant kernel family, measured live (outside the timed region) ---------------------------
     groups: dict[str, list] = {}
     for e in low.step:
         if e[0] is not None:
@@ -193,100 +198,189 @@ def main() -> None:
                      "tflops": round(fl / sec / 1e12, 1) if fl else None}
     dom = max((n for n in fam if fam[n]["tflop"]), key=lambda n: fam[n]["ms"])
     executed_tflop = sum(f["tflop"] for f in fam.values())
-    roofline = {
+    algo = STEP_TFLOP[workload] * n_img
+    return {
         "bound": "mfma", "kernel": dom, "launches_per_step": fam[dom]["launches"], "avg_launch_us": fam[dom]["avg_us"],
         "achieved": fam[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam[dom]["tflops"] / PEAK_BF16_TFLOPS, 4),
-        "traffic": pmc_traffic(dom),
-        "step": {"algorithmic_tflop": STEP_TFLOP[args.workload] * n_img, "executed_tflop": round(executed_tflop, 3),
-                 "achieved": round(STEP_TFLOP[args.workload] * n_img / (ms_per_step * 1e-3), 1),
-                 "frac": round(STEP_TFLOP[args.workload] * n_img / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)},
+        "traffic": pmc_traffic(dom), "mfma_util": pmc_mfma_util(dom),
+        "step": {"algorithmic_tflop": algo, "executed_tflop": round(executed_tflop, 3), "achieved": round(algo / (ms_per_step * 1e-3), 1),
+                 "frac": round(algo / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)},
         "families": fam,
     }
 
-    # ---- CPU baseline: the oracle (float32 port of the reference's algorithm) on this host's cores, one step -------
+
+def cpu_baseline_step(bare_sd: dict, specs: dict, workload: str, threads: int) -> dict:
+    """The reference's own path for ONE denoising step on this host's cores: the mirror's UNFUSED Chain forward issues the
+    same ATen calls, module by module, as refiners' `LatentDiffusionModel.forward` (CFG cat, SDXLUNet Chain with the same
+    adapters injected through the same API, CFG combine, DDIM) -- float32, CPU, `threads` intra-op threads."""
+    import refiners_amd
+    from refiners_amd import synth
+    from refiners_amd.latent_diffusion.sampling import DDIM, SDXLDenoiser
+    from refiners_amd.latent_diffusion.sdxl import SDXLUNet
+
+    torch.set_num_threads(threads)
+    cpu = torch.device("cpu")
+    unet = SDXLUNet(4, device="meta")
+    unet.load_state_dict({k: v.detach().to(device=cpu, dtype=torch.float32) for k, v in bare_sd.items()}, assign=True)
+    if workload != "bare":
+        synth.apply_adapters(unet, refiners_amd.namespace(), device=cpu, dtype=torch.float32, **specs)
+    sd = SDXLDenoiser(unet, DDIM(50, device=cpu, dtype=torch.float32))
+    cin = synth.sdxl_inputs(1, LATENT, seed=100)
+    kw = dict(clip_text_embedding=cin["text"], pooled_text_embedding=cin["pooled"], time_ids=cin["time_ids"], condition_scale=5.0)
+    with torch.no_grad():
+        sd(cin["x"][:, :, :16, :16], 0, **kw)  # page-in / thread-pool warm-up on a 16x16 latent
+        tc = time.perf_counter()
+        out = sd(cin["x"], 0, **kw)
+        cpu_s = time.perf_counter() - tc
+    assert bool(torch.isfinite(out).all())
+    return {"value": round(1.0 / (cpu_s * 50), 6), "unit": "images/s", "cores": threads, "kind": "port",
+            "path": "mirror-of-reference ATen path: refiners_amd.fluxion Chain forward, unfused, the same adapters injected (no oracle, no native kernels)",
+            "dtype": "f32", "ms_per_step": round(cpu_s * 1e3, 1), "host_cpus": os.cpu_count(),
+            "sample": "1 of the 50 DDIM steps of one 1024x1024 image (CFG pair) of this workload; images/s extrapolated x50"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="lora_ip",
+                    help="lora_ip = BASELINE configs[2] (the north star's target, default); bare = configs[1]; control = configs[3] (use --images-per-gpu 4 for its 32-prompt / 8-GPU shape)")
+    ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="intra-op threads of the CPU baseline (0 = min(64, host cpus))")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informational extras (configs[1] line, fused-LoRA line, VAE decode, 4-images-per-GPU point)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-family replay (profiler passes: the kernel table then holds the timed steps only)")
+    ap.add_argument("--lora-mode", choices=["fused", "merged"], default="merged",
+                    help="merged: W' = W + sum s B A formed at lowering time (one launch per adapted layer); fused: run-time LoRA inside the parent launch")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)
+
+    from refiners_amd import native, parallel
+
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    native.load()
+    dtype = torch.bfloat16
+    n_img = args.images_per_gpu
+    use_graph = not args.no_graph
+
+    t0 = time.time()
+    unet, specs, bare_sd, pipe, bc = build_pipeline(args.workload, n_img, rank, dev, dtype, args.lora_mode, use_graph)
+    n_params = sum(p.numel() for p in unet.parameters())
+    elapsed = timed_steps(pipe, args.steps, args.warmup, world, dev)
+    setup_s = time.time() - t0 - elapsed
+    finite = bool(torch.isfinite(pipe.x.float()).all())
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    images_per_s = world * n_img / (ms_per_step * 1e-3 * 50)
+    roofline = None if args.no_roofline else family_roofline(pipe, args.workload, n_img, ms_per_step)
+    stats = dict(pipe.engine.stats)
+
+    extra: dict = {"params": n_params, "launches_per_step": stats["step_ops"], "prologue_launches": stats["prologue_ops"], "fallback_nodes": stats["fallback_nodes"],
+                   "arena_bytes": stats["pool_bytes"], "weight_prefetch": stats.get("weight_prefetch"), **bc, "setup_s": round(setup_s, 1),
+                   "output_finite": finite, "device": native.device_info(), "gemm_tuning": stats.get("gemm_tuning")}
+
+    # ---- CPU baseline: the reference's path (mirror Chain forward, same adapters) on this host's cores, one step -----------
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import unet_oracle as O
-
-        if specs["loras"] or specs["ip"]:
-            bare = {}  # the oracle wants bare-model keys: adapters are passed as specs
-            raise_keys = None
-        sd_cpu = None
-        if args.workload == "bare":
-            sd_cpu = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
-        if sd_cpu is not None:
-            cin = synth.sdxl_inputs(1, LATENT, seed=100)
-            O.sdxl_cfg_step(sd_cpu, cin["x"][:, :, :32, :32], 0, 50, cin["text"], cin["pooled"], cin["time_ids"])  # page-in / warm-up at 32x32
-            tc = time.perf_counter()
-            O.sdxl_cfg_step(sd_cpu, cin["x"], 0, 50, cin["text"], cin["pooled"], cin["time_ids"])
-            cpu_s = time.perf_counter() - tc
-            cpu = {"value": round(1.0 / (cpu_s * 50), 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                   "ms_per_step": round(cpu_s * 1e3, 1),
-                   "sample": "1 of the 50 DDIM steps of one 1024x1024 image (CFG pair), float32, oracle/unet_oracle.py; images/s extrapolated x50"}
-            del sd_cpu
-
-    # ---- next-1 (outside the metric): VAE decode of the finished latents, for an end-to-end images/s figure ---------
-    vae_ms = None
-    try:
-        if args.no_extra:
-            raise RuntimeError("skipped (--no-extra)")
-        from refiners_amd.engine.vae import CompiledVAEDecoder
-        from refiners_amd.latent_diffusion.vae import SDXLAutoencoder
-
-        vae = SDXLAutoencoder(device="meta")
-        gpu_weights(vae, seed=7, dtype=dtype, device=dev)
-        dec = CompiledVAEDecoder(vae)
-        z = pipe.x[:1] * 0.13
-        dec(z)
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for _ in range(3):
-            dec(z)
-        torch.cuda.synchronize()
-        vae_ms = (time.perf_counter() - tv) / 3 * 1e3
-    except Exception as exc:  # noqa: BLE001 -- the VAE is outside the benchmarked path; report, do not fail the bench
-        vae_ms = f"failed: {type(exc).__name__}: {exc}"
-
-    # ---- throughput-oriented operating point (outside the metric): 4 images per GPU through the same engine -------------
-    batched = None
-    if world == 1 and n_img == 1 and args.workload == "bare" and not args.no_extra:
+        threads = args.cpu_threads or min(64, os.cpu_count() or 1)
         try:
-            inp4 = synth.sdxl_inputs(4, LATENT, seed=300)
-            pipe4 = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=not args.no_graph, lora_mode=args.lora_mode)
-            pipe4.set_inputs(inp4["x"].to(dev), clip_text_embedding=inp4["text"].to(dev), pooled_text_embedding=inp4["pooled"].to(dev), time_ids=inp4["time_ids"].to(dev))
-            for i in range(2):
-                pipe4.step(i)
+            cpu = cpu_baseline_step(bare_sd, specs, args.workload, threads)
+        except Exception as exc:  # noqa: BLE001 -- a baseline failure must not lose the measured line
+            cpu = {"value": None, "unit": "images/s", "cores": threads, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"}
+
+    if world == 1 and n_img == 1 and not args.no_extra:
+        # ---- the same target workload with run-time (exact-order) LoRA instead of merged weights ------------------------
+        if args.workload == "lora_ip":
+            try:
+                other = "fused" if args.lora_mode == "merged" else "merged"
+                from refiners_amd.engine.compiled import CompiledSDXL
+
+                p2 = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=use_graph, lora_mode=other)
+                p2.inputs, p2.x = pipe.inputs, pipe.x.clone()
+                p2._tables(dev)
+                s2 = timed_steps(p2, 10, 2, 1, dev)
+                extra[f"lora_mode_{other}"] = {"ms_per_step": round(s2 / 10 * 1e3, 3), "launches_per_step": p2.engine.stats["step_ops"]}
+                del p2
+            except Exception as exc:  # noqa: BLE001
+                extra["lora_mode_other"] = f"failed: {type(exc).__name__}: {exc}"
+        # ---- next-1 (outside the metric): VAE decode of the finished latents, for an end-to-end images/s figure ---------
+        try:
+            from refiners_amd.engine.vae import CompiledVAEDecoder
+            from refiners_amd.latent_diffusion.vae import SDXLAutoencoder
+
+            vae = SDXLAutoencoder(device="meta")
+            gpu_weights(vae, seed=7, dtype=dtype, device=dev)
+            dec = CompiledVAEDecoder(vae)
+            z = pipe.x[:1] * 0.13
+            dec(z)
             torch.cuda.synchronize()
-            t4 = time.perf_counter()
-            for i in range(10):
-                pipe4.step(i)
+            tv = time.perf_counter()
+            for _ in range(3):
+                dec(z)
             torch.cuda.synchronize()
-            ms4 = (time.perf_counter() - t4) / 10 * 1e3
-            batched = {"images_per_gpu": 4, "ms_per_step": round(ms4, 3), "images_per_s": round(4 / (ms4 * 1e-3 * 50), 4),
-                       "step_tflops": round(4 * STEP_TFLOP["bare"] / (ms4 * 1e-3), 1), "frac_of_peak": round(4 * STEP_TFLOP["bare"] / (ms4 * 1e-3) / PEAK_BF16_TFLOPS, 4)}
-            del pipe4
-        except Exception as exc:  # noqa: BLE001
-            batched = f"failed: {type(exc).__name__}: {exc}"
+            vae_ms = (time.perf_counter() - tv) / 3 * 1e3
+            extra["vae_decode_ms_per_image"] = round(vae_ms, 2)
+            extra["vae_fallback_nodes"] = dec.stats.get("fallback_nodes") if hasattr(dec, "stats") else None
+            extra["end_to_end_images_per_s_incl_vae"] = round(world * n_img / (ms_per_step * 1e-3 * 50 + n_img * vae_ms * 1e-3), 4)
+            del dec, vae
+        except Exception as exc:  # noqa: BLE001 -- the VAE is outside the benchmarked path; report, do not fail the bench
+            extra["vae_decode_ms_per_image"] = f"failed: {type(exc).__name__}: {exc}"
+        # ---- BASELINE configs[1] (no adapters) and the 4-images-per-GPU operating point, through the same engine ----------
+        del pipe
+        if args.workload != "bare":
+            del unet, bare_sd
+            try:
+                torch.cuda.empty_cache()
+                unet_b, _, _, pipe_b, _ = build_pipeline("bare", 1, rank, dev, dtype, args.lora_mode, use_graph, broadcast=False)
+                sb = timed_steps(pipe_b, 20, 3, 1, dev)
+                msb = sb / 20 * 1e3
+                extra["configs1_bare"] = {"ms_per_step": round(msb, 3), "images_per_s": round(1 / (msb * 1e-3 * 50), 4), "launches_per_step": pipe_b.engine.stats["step_ops"],
+                                          "step_tflops": round(STEP_TFLOP["bare"] / (msb * 1e-3), 1)}
+                del pipe_b
+                unet = unet_b
+            except Exception as exc:  # noqa: BLE001
+                extra["configs1_bare"] = f"failed: {type(exc).__name__}: {exc}"
+                unet = None
+        if unet is not None and args.workload in ("bare", "lora_ip"):  # `unet` is a bare SDXL UNet here
+            try:
+                from refiners_amd import synth
+                from refiners_amd.engine.compiled import CompiledSDXL
+
+                inp4 = synth.sdxl_inputs(4, LATENT, seed=300)
+                pipe4 = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=use_graph, lora_mode=args.lora_mode)
+                pipe4.set_inputs(inp4["x"].to(dev), clip_text_embedding=inp4["text"].to(dev), pooled_text_embedding=inp4["pooled"].to(dev), time_ids=inp4["time_ids"].to(dev))
+                s4 = timed_steps(pipe4, 10, 2, 1, dev)
+                ms4 = s4 / 10 * 1e3
+                extra["throughput_operating_point"] = {"workload": "configs[1] (bare)", "images_per_gpu": 4, "ms_per_step": round(ms4, 3), "images_per_s": round(4 / (ms4 * 1e-3 * 50), 4),
+                                                       "step_tflops": round(4 * STEP_TFLOP["bare"] / (ms4 * 1e-3), 1),
+                                                       "frac_of_peak": round(4 * STEP_TFLOP["bare"] / (ms4 * 1e-3) / PEAK_BF16_TFLOPS, 4)}
+                del pipe4
+            except Exception as exc:  # noqa: BLE001
+                extra["throughput_operating_point"] = f"failed: {type(exc).__name__}: {exc}"
 
     line = {
         "metric": "sdxl_base_1024px_images_per_sec_50_ddim_steps", "value": round(images_per_s, 4), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "SDXL-base UNet CFG step, 1024x1024 (latent 2x4x128x128, 77 text tokens), DDIM-50" +
-                   {"bare": "", "lora_ip": " + 2 LoRA r16 (722 Linears) + IP-Adapter", "control": " + ControlLora (canny)"}[args.workload],
-                   "baseline_config": {"bare": "configs[1]", "lora_ip": "configs[2]", "control": "configs[3]"}[args.workload], "images_per_gpu": n_img,
-                   "parallelism": f"replica x{world} (independent prompts, weights broadcast once)", "hip_graph": not args.no_graph,
+        "config": {"workload": "SDXL-base UNet CFG step, 1024x1024 (latent 2x4x128x128, 77 text tokens), DDIM-50" + WORKLOADS[args.workload][1],
+                   "baseline_config": WORKLOADS[args.workload][0], "images_per_gpu": n_img,
+                   "parallelism": f"replica x{world} (independent prompts, weights broadcast once)", "hip_graph": use_graph,
                    "lora_mode": args.lora_mode if args.workload != "bare" else None},
         "step_latency_ms": round(ms_per_step, 3),
-        "roofline": roofline, "cpu_baseline": cpu,
-        "extra": {"params": n_params, "launches_per_step": pipe.engine.stats["step_ops"], "prologue_launches": pipe.engine.stats["prologue_ops"],
-                  "fallback_nodes": pipe.engine.stats["fallback_nodes"], "arena_bytes": pipe.engine.stats["pool_bytes"],
-                  "weight_prefetch": pipe.engine.stats.get("weight_prefetch"),
-                  "weights_broadcast_s": round(bcast_s, 3), "broadcast_launches": n_bcast, "setup_s": round(setup_s, 1),
-                  "output_finite": finite, "device": native.device_info(),
-                  "throughput_operating_point": batched,
-                  "vae_decode_ms_per_image": round(vae_ms, 2) if isinstance(vae_ms, float) else vae_ms,
-                  "end_to_end_images_per_s_incl_vae": round(world * n_img / (ms_per_step * 1e-3 * 50 + n_img * vae_ms * 1e-3), 4) if isinstance(vae_ms, float) else None},
+        "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
     }
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 2
+#define MI355X_ABI_VERSION 3
 
 enum { MI355X_F32 = 0, MI355X_BF16 = 1 };
 
@@ -110,7 +110,9 @@ typedef struct {
     const void* res;        /* [M][ldres] or NULL */
     int64_t ldres;
     const void* zeros;      /* >= 256 zero bytes in device memory; required when conv == 1 */
-    int32_t tile;           /* 0 = let the library choose; 1: 128x128  2: 128x64  3: 64x128  4: 64x64  5: 256x128 (M x N) */
+    int32_t tile;           /* 0 = let the library choose; 1: 128x128  2: 128x64  3: 64x128  4: 64x64  5: 256x128 (M x N);
+                               6: 128x128 computed by 8 waves in two K groups (even / odd K blocks, summed through LDS in a fixed order):
+                               for launches with fewer output tiles than CUs */
     int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
                                partial sums into `ws`, a second launch adds them in a fixed order (deterministic) and
                                applies the epilogue.  Not combinable with geglu. */
@@ -125,6 +127,30 @@ typedef struct {
     int32_t prefetch_blocks;
     int32_t out_kblocked;   /* geglu == 1 only: store the [M][N/2] result K-blocked, [(N/2)*sizeof/128][M][128 bytes] (ldo ignored), ready to be
                                the x operand (kblocked bit 1) of the next GEMM -- FeedForward's second Linear reads 10 KB rows otherwise */
+    int32_t stages;         /* LDS pipeline depth: 0 = let the library choose, 2..4 (tiles 5 and 6: 2 or 3 / 2 only) */
+    /* Transposed column group (conv == 0): when out_t != NULL, output columns n >= nt_begin (a multiple of 128) are written as
+       out_t[(n - nt_begin) * ldt + m] (the V^T [C][B*L] layout mi355x_attention wants) and only columns < nt_begin go to `out`.
+       One launch over the stacked weights [Wq; Wk; Wv] then yields Q | K row-major and V transposed: the three projections of
+       Distribute(Linear, Linear, Linear) in src/refiners/fluxion/layers/attentions.py:205-316.  bias is applied to both groups;
+       rowbias / res / geglu / ksplit are not available with out_t.  `out` may be NULL when nt_begin == 0. */
+    int32_t nt_begin;
+    void* out_t;
+    int64_t ldt;
+    /* LayerNorm folded into the GEMM that consumes its output (fl.LayerNorm, src/refiners/fluxion/layers/norm.py:13-60, followed by
+       fl.Linear: the three Residual bodies of CrossAttentionBlock, latent_diffusion/cross_attention.py:25-73).  x is the tensor the
+       LayerNorm would have read; the caller passes weights already scaled by gamma (W' = W . diag(gamma)) and
+         ln_s[n] = sum_k W'[n][k],   ln_c[n] = sum_k beta[k] W[n][k] + bias[n]          (float32, packed like the weight rows)
+       and the kernel computes out = rstd[m] * (x W'^T - mean[m] * ln_s) + ln_c, mean / rstd of row m over the LayerNorm width taken
+       from `ln_stats`: ln_parts x M pairs (mean, M2 = sum of squared deviations) of consecutive 32-column chunks, float32, laid out
+       [part][m][2] -- exactly what `stats_out` of the launch that PRODUCED x wrote.  bias must be NULL (it is inside ln_c). */
+    const void* ln_stats;
+    int32_t ln_parts;
+    float ln_eps;
+    const void* ln_s;
+    const void* ln_c;
+    /* Producer side: besides `out`, write per-row (mean, M2) of every 32-column chunk of the STORED (rounded) output row into
+       stats_out[(n / 32) * M + m] (float32 pairs; N a multiple of 64, vectorisable epilogue, no geglu / ksplit / out_t). */
+    void* stats_out;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

@@ -13,8 +13,8 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libmi355x_refiners.so"
-SOURCES = ["gemm.hip", "attention.hip", "attention_general.hip", "norm.hip", "elementwise.hip"]
-HEADERS = ["common.cuh", "../../include/mi355x_refiners.h"]
+SOURCES = ["gemm.hip", "gemm_conv.hip", "attention.hip", "attention_general.hip", "norm.hip", "elementwise.hip"]
+HEADERS = ["common.cuh", "gemm_kernel.cuh", "../../include/mi355x_refiners.h"]
 ARCH = "gfx950"
 
 

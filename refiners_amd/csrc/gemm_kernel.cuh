@@ -1,0 +1,820 @@
+// gemm_kernel.cuh: the LDS-tiled MFMA GEMM / implicit-GEMM convolution kernel of mi355x_gemm (gfx950), shared by the two
+// translation units that instantiate it (gemm.hip: plain GEMMs + the C entry point, gemm_conv.hip: convolutions).
+//
+//   out[M,N] = epi( sum_s X_s[M,K_s] . W_s[N,K_s]^T )        (see include/mi355x_refiners.h for the contract)
+//
+// Structure (one workgroup = KG x WM x WN waves, BM x BN output tile, K consumed in 128-byte blocks per row):
+//   * both operands are K-contiguous, so an LDS tile is `rows x 128 B`; the global->LDS copy is
+//     global_load_lds_dwordx4 (16 B per lane, lane-linear LDS image) with the bank-conflict XOR swizzle applied to
+//     the per-lane SOURCE chunk; NSTAGE LDS stages, one barrier per K block (loads of later blocks overlap MFMA on block k);
+//   * MFMA orientation: A operand = weight rows, B operand = activation rows, so a lane ends up holding, for each of
+//     its activation rows, 4 consecutive N per 16x16 tile.  The weight tile is loaded with the row permutation
+//     R = 16j + 4a + b  <->  n = 4*NT*a + 4j + b, which makes every lane own 4*NT CONSECUTIVE output columns:
+//     the epilogue (bias, time-embedding row bias, GEGLU, residual, LayerNorm statistics) is fully 16-byte vectorised;
+//   * TRANSPOSED column groups (tiles at n0 >= nt_begin): the operand roles are swapped (A = activation rows, with the
+//     same permutation applied to THEM), so a lane owns 4*MT consecutive output ROWS of one column and stores them as
+//     16-byte vectors into out_t[n][m]: a self-attention's Q | K | V^T come out of ONE launch;
+//   * KG = 2 ("K groups"): 8 waves share one output tile, waves 0-3 take the even K blocks, waves 4-7 the odd ones, each
+//     group with its own LDS ring; the two partial tiles are added through LDS in a fixed order.  For launches with fewer
+//     tiles than CUs this puts two waves on every SIMD (twice the bytes in flight, each wave's LDS / barrier stalls
+//     covered by the other) without the HBM round trip of a split-K across workgroups;
+//   * conv mode gathers the activation rows straight from the NHWC image (zero padding comes from a zero page, nearest
+//     2x upsampling and stride 2 are address arithmetic), so no im2col buffer, no materialised upsample / concat;
+//   * LayerNorm folded in: a launch whose x is LN(r) reads r itself; the weights carry gamma (W' = W . diag(gamma)) and the
+//     epilogue applies y = rstd[m] * (acc - mean[m] * s[n]) + c[n] with s = W' 1, c = W beta + bias.  mean / rstd come from
+//     per-row (mean, M2) partials over 32-column chunks that the launch PRODUCING r wrote from its epilogue (Chan-merged
+//     in a fixed order: deterministic, no atomics);
+//   * bf16 -> v_mfma_f32_16x16x32_bf16, f32 (parity mode) -> v_mfma_f32_16x16x4_f32; identical LDS image.
+#pragma once
+#include <type_traits>
+
+#include "../../include/mi355x_refiners.h"
+#include "common.cuh"
+
+namespace mi355x {
+
+struct SegP {
+    const char* x;
+    const char* w;
+    int64_t ldxb;  // bytes
+    int64_t ldwb;  // bytes
+    int nkb;       // number of 128-byte K blocks in this segment
+    int cpb;       // conv: K blocks per tap (= channels*sizeof(T)/128)
+    int ksize, stride, ups_shift, H, W;
+    int wkb, xkb;  // operand stored K-blocked: [K block][row][128 B]
+    int pad;  // zero rows / columns before the image (ksize / 2, or 0 for the bottom/right-only padding of Downsample(padding=0))
+};
+
+struct GemmP {
+    int M, N, nseg;
+    int OH, OW;
+    SegP seg[MI355X_MAX_SEG];
+    char* out;
+    int64_t ldo;  // elements
+    const char* bias;
+    const char* rowbias;
+    int64_t ld_rowbias;  // elements
+    int rows_per_group;
+    int geglu;
+    int gelu;  // activation on every output column (after bias / row bias, before the residual): 1 = erf-GELU, 2 = x * sigmoid(1.702 x)
+    const char* res;
+    int64_t ldres;  // elements
+    const char* zeros;
+    int tiles_m, tiles_n;
+    int ksplit, kb_per_split, grid0;  // split-K: ksplit workgroups per tile, each accumulating kb_per_split K blocks
+    float* partial;                   // [ksplit][M][N] float32 partial sums (split-K only)
+    int tile_hint;                    // 0 = heuristic, 1..6 = caller's choice
+    int stage_hint;                   // 0 = heuristic, 2..4 = caller's choice
+    int out_kb;                       // GEGLU output stored K-blocked ([column block][M rows][128 B]) for the GEMM that consumes it as x
+    // transposed column group: columns n >= nt_begin are stored as out_t[(n - nt_begin) * ldt + m]
+    int nt_begin;
+    char* out_t;
+    int64_t ldt;  // elements
+    // LayerNorm folded into this launch (consumer side) / row statistics written by this launch (producer side)
+    const float* ln_stats;  // [ln_parts][M][2] (mean, M2) per 32-column chunk of the normalised tensor, or NULL
+    int ln_parts;
+    float ln_eps;
+    const float* ln_s;  // [N]: sum_k W'[n][k]
+    const float* ln_c;  // [N]: sum_k beta[k] W[n][k] (+ bias[n])
+    float* stats_out;   // [N / 32][M][2], or NULL
+    // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
+    // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
+    const char* pf_ptr[MI355X_MAX_PREFETCH];
+    int64_t pf_bytes[MI355X_MAX_PREFETCH];
+    int pf_blocks, pf_mode;  // pf_mode: 1 = plain loads, 2 = non-temporal loads (L2 evict-first)
+    int pn, hm, hn;          // XCD rasterisation: the 8 XCDs own a pm x pn grid of hm x hn-tile regions
+    int vec_ok;
+};
+
+// Chan's pairwise update of (count, mean, M2); exact for empty operands.
+MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    const float nt = n + nb;
+    if (nt > 0.f) {
+        const float d = mb - mean, f = nb / nt;
+        mean += d * f;
+        m2 += m2b + d * d * n * f;
+        n = nt;
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1>
+__global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
+    constexpr int NW = WM * WN;           // waves per K group
+    constexpr int NTHR = NW * 64;         // threads per K group: the loader geometry
+    constexpr int NTHR_ALL = NTHR * KG;   // threads per workgroup
+    constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+    constexpr int XI = BM * 8 / NTHR, WI = BN * 8 / NTHR;
+    constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
+    static_assert(KG == 1 || KG == 2, "one or two K groups");
+    constexpr int WNE = 16 * NT;  // columns per wave
+    constexpr int WME = 16 * MT;  // rows per wave
+    static_assert(BM * 8 % NTHR == 0 && BN * 8 % NTHR == 0, "tile/thread mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rowstat = reinterpret_cast<float*>(smem + KG * NSTAGE * STAGE);  // [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer)
+
+    const int tid_all = threadIdx.x, wid_all = wave_id();
+    const int kg = KG > 1 ? wid_all / NW : 0;
+    const int tid = tid_all - kg * NTHR, lane = tid & 63, wid = wid_all - kg * NW;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int wm = wid / WN, wn = wid % WN;
+    char* const smem_g = smem + kg * (NSTAGE * STAGE);
+    // XCD-aware rasterisation: workgroup b runs on XCD b % 8 (observed dispatch rule, a speed assumption only); each XCD
+    // owns one rectangular region of the tile grid so that its private L2 sees as few distinct operand rows as possible.
+    if ((int)blockIdx.x < p.pf_blocks) {  // prefetch role (see GemmP::pf_ptr): one 4-byte read per 64 bytes, 8 independent loads in flight
+        int acc = 0;
+        const int64_t stride = (int64_t)p.pf_blocks * NTHR_ALL * 64;
+        constexpr int U = 8;
+#pragma unroll
+        for (int sp = 0; sp < MI355X_MAX_PREFETCH; ++sp) {
+            const char* base = p.pf_ptr[sp];
+            const int64_t bytes = base ? p.pf_bytes[sp] : 0;
+            for (int64_t off = ((int64_t)blockIdx.x * NTHR_ALL + tid_all) * 64; off < bytes; off += stride * U) {
+                int v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t o = off + u * stride;
+                    const int* src = reinterpret_cast<const int*>(base + (o < bytes ? o : off));
+                    v[u] = p.pf_mode == 2 ? __builtin_nontemporal_load(src) : *src;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc ^= v[u];
+            }
+        }
+        if (acc == 0x5a5a1234 && p.pf_bytes[0] < 0) *reinterpret_cast<int*>(p.out) = acc;  // never taken: keeps the loads alive
+        return;
+    }
+    const int bid = (int)blockIdx.x - p.pf_blocks;
+    const int split = p.ksplit > 1 ? bid / p.grid0 : 0;
+    const int bx = bid - split * p.grid0;
+    int tm, tn;
+    if (p.pn > 0) {  // rectangular regions (exact split of the tile grid, grid0 = 8 * hm * hn)
+        const int xcd = bx & 7, idx = bx >> 3;
+        const int rm = xcd / p.pn, rn = xcd - rm * p.pn;
+        const int lm = idx / p.hn, ln = idx - lm * p.hn;
+        tm = rm * p.hm + lm;
+        tn = rn * p.hn + ln;
+    } else {  // contiguous chunk of the row-major (pn == 0) or column-major (pn == -1) tile order per XCD, balanced to +-1 tile
+        const int id = xcd_remap(bx, p.grid0);
+        if (p.pn == 0) {
+            tm = id / p.tiles_n;
+            tn = id - tm * p.tiles_n;
+        } else {
+            tn = id / p.tiles_m;
+            tm = id - tn * p.tiles_m;
+        }
+    }
+    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bool tr = !CONV && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
+
+    // ---- per-thread loader coordinates (fixed for the whole K loop) ----
+    // Exactly one operand's rows are permuted inside each wave's 16*T-row span (see the header): the weights' normally, the
+    // activations' for a transposed tile.
+    int xm[XI];      // clamped global row (plain) / global row (conv)
+    int xcoff[XI];   // logical chunk * 16
+    int xb[XI], xoy[XI], xox[XI];
+    bool xvalid[XI];
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+        const int q = it * NTHR + tid, row = q >> 3, pch = q & 7;
+        xcoff[it] = (pch ^ swz<128>(row)) << 4;
+        int mr = row;
+        if (!CONV && tr) {
+            const int rl = row % WME;
+            mr = (row - rl) + 4 * MT * ((rl >> 2) & 3) + 4 * (rl >> 4) + (rl & 3);
+        }
+        const int m = m0 + mr;
+        xvalid[it] = m < p.M;
+        xm[it] = m < p.M ? m : p.M - 1;
+        if constexpr (CONV) {
+            const int ohw = p.OH * p.OW;
+            const int b = xm[it] / ohw, rem = xm[it] - b * ohw;
+            xb[it] = b;
+            xoy[it] = rem / p.OW;
+            xox[it] = rem - xoy[it] * p.OW;
+        }
+    }
+    int wnrow[WI], wcoff[WI];
+#pragma unroll
+    for (int it = 0; it < WI; ++it) {
+        const int q = it * NTHR + tid, row = q >> 3, pch = q & 7;
+        wcoff[it] = (pch ^ swz<128>(row)) << 4;
+        const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
+        const int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
+        wnrow[it] = n < p.N ? n : p.N - 1;
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- K-block iteration state ----
+    int seg = 0, kb = 0;  // kb = block index inside the current segment
+    int total_kb = 0;
+    for (int s = 0; s < p.nseg; ++s) total_kb += p.seg[s].nkb;
+    if (p.ksplit > 1) {  // this workgroup's share of the K blocks: [first, first + total_kb)
+        const int first = split * p.kb_per_split;
+        total_kb = min(p.kb_per_split, total_kb - first);
+        kb = first;
+        while (seg < p.nseg - 1 && kb >= p.seg[seg].nkb) {
+            kb -= p.seg[seg].nkb;
+            ++seg;
+        }
+    }
+    // K groups interleave: group kg takes blocks kg, kg + KG, ... of the workgroup's range
+    const int my_kb = (total_kb - kg + KG - 1) / KG;   // blocks of this group
+    const int max_kb = (total_kb + KG - 1) / KG;       // loop trips of the workgroup (= group 0's blocks)
+
+    // ---- loader state: everything that does not change from one K block to the next is hoisted out of the loop.
+    // Per thread: the row base pointers of the current segment (conv: of the current tap) with the swizzled chunk offset folded
+    // in; per workgroup: a running byte offset along K.  The per-iteration cost of a load is one 64-bit add; the segment
+    // descriptor (a dynamically indexed kernel argument, i.e. scalar loads + waits) is touched only when the segment or tap changes.
+    const char* xbase[XI];
+    const char* wbase[WI];
+    int64_t xstep = 128, wstep = 128;  // bytes from one K block to the next (row-major: 128; K-blocked: rows * 128)
+    int64_t xoff = 0, woff = 0;        // running offsets inside the current segment
+    int cur_nkb = 0, cur_cpb = 1, tap = 0, cb = 0;
+    auto set_tap = [&](const SegP& sp) __attribute__((always_inline)) {  // conv: per-thread pixel pointers of tap `tap` (zero page for padding / out-of-tile rows)
+        int dy = tap / sp.ksize, dx = tap - dy * sp.ksize;
+        dy -= sp.pad;
+        dx -= sp.pad;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int iy = xoy[it] * sp.stride + dy, ix = xox[it] * sp.stride + dx;
+            const int HH = sp.H << sp.ups_shift, WW = sp.W << sp.ups_shift;
+            const bool ok = xvalid[it] && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
+            const int sy = iy >> sp.ups_shift, sx = ix >> sp.ups_shift;
+            const int64_t pix = ((int64_t)xb[it] * sp.H + sy) * sp.W + sx;
+            xbase[it] = ok ? sp.x + pix * sp.ldxb + xcoff[it] : nullptr;
+        }
+    };
+    auto enter = [&](int s, int kb0) __attribute__((always_inline)) {  // make segment s current, positioned at its K block kb0
+        const SegP& sp = p.seg[s];
+        cur_nkb = sp.nkb;
+        cur_cpb = sp.cpb;
+        wstep = sp.wkb ? (int64_t)p.N * 128 : 128;
+        woff = (int64_t)kb0 * wstep;
+#pragma unroll
+        for (int it = 0; it < WI; ++it) wbase[it] = sp.w + (sp.wkb ? (int64_t)wnrow[it] * 128 : (int64_t)wnrow[it] * sp.ldwb) + wcoff[it];
+        if constexpr (CONV) {
+            tap = kb0 / sp.cpb;
+            cb = kb0 - tap * sp.cpb;
+            set_tap(sp);
+        } else {
+            xstep = sp.xkb ? (int64_t)p.M * 128 : 128;
+            xoff = (int64_t)kb0 * xstep;
+#pragma unroll
+            for (int it = 0; it < XI; ++it) xbase[it] = sp.x + (sp.xkb ? (int64_t)xm[it] * 128 : (int64_t)xm[it] * sp.ldxb) + xcoff[it];
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {  // one K block forward; cross into the next tap / segment when this one is exhausted
+        if (seg >= p.nseg) return;
+        ++kb;
+        woff += wstep;
+        if constexpr (CONV) {
+            if (++cb == cur_cpb) {
+                cb = 0;
+                ++tap;
+                if (kb < cur_nkb) set_tap(p.seg[seg]);
+            }
+        } else {
+            xoff += xstep;
+        }
+        if (kb == cur_nkb) {
+            kb = 0;
+            ++seg;
+            if (seg < p.nseg) enter(seg, 0);
+        }
+    };
+    enter(seg, kb);
+    if constexpr (KG > 1) {
+        if (kg == 1) advance();
+    }
+
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        char* xs = smem_g + buf * STAGE;
+        char* ws = xs + XBYTES;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const char* src;
+            if constexpr (CONV) src = xbase[it] ? xbase[it] + (int64_t)cb * 128 : p.zeros + xcoff[it];
+            else src = xbase[it] + xoff;
+            glds16(src, xs + (it * NTHR + wid * 64) * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < WI; ++it) glds16(wbase[it] + woff, ws + (it * NTHR + wid * 64) * 16);
+#pragma unroll
+        for (int a = 0; a < KG; ++a) advance();
+    };
+
+    // ---- software pipeline: NSTAGE LDS buffers, D = NSTAGE - 1 K blocks in flight -------------------------------------
+    // per iteration: counted vmcnt (block t has landed, the D-1 younger ones stay in flight) -> raw barrier (no vmcnt(0)
+    // drain, guide section 5 "pipelining across barriers") -> issue block t+D into the buffer block t-1 was computed from
+    // -> MFMA on block t.  One barrier per K block.
+    constexpr int D = NSTAGE - 1;
+    constexpr int LPS = XI + WI;  // global_load_lds instructions per thread per stage
+#pragma unroll
+    for (int s0 = 0; s0 < D; ++s0)
+        if (s0 < my_kb) issue(s0);
+
+    if (p.ln_stats) {
+        // LayerNorm consumer: (mean, rstd) of the tile's BM rows from the producer's 32-column partials, TPR threads per row,
+        // merged in a fixed order.  Placed behind the prologue's LDS-DMA issue so that its latency overlaps theirs (the compiler
+        // drains vmcnt before the first use of an ordinary load anyway; the first loop iteration then finds its stage landed).
+        constexpr int TPR = NTHR_ALL / BM;
+        static_assert(TPR >= 1 && (TPR & (TPR - 1)) == 0 && TPR <= 8, "threads per row");
+        const int row = tid_all / TPR, sub = tid_all % TPR;
+        const int m = min(m0 + row, p.M - 1);
+        float cn = 0.f, mean = 0.f, m2 = 0.f;
+        for (int part = sub; part < p.ln_parts; part += TPR) {
+            const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + ((int64_t)part * p.M + m) * 2);
+            stat_merge(cn, mean, m2, 32.f, st[0], st[1]);
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {
+            const float nb = __shfl_xor(cn, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
+            // both partners must combine in the SAME order to end up with identical bits: lower sub-index first
+            if (sub & o) {
+                float n2 = nb, me2 = mb, q2 = qb;
+                stat_merge(n2, me2, q2, cn, mean, m2);
+                cn = n2, mean = me2, m2 = q2;
+            } else {
+                stat_merge(cn, mean, m2, nb, mb, qb);
+            }
+        }
+        if (sub == 0) {
+            rowstat[2 * row] = mean;
+            rowstat[2 * row + 1] = rsqrtf(m2 / cn + p.ln_eps);
+        }
+    }
+
+    // ---- main loop, software-pipelined through REGISTERS as well: the MFMAs of one half K block (32 bf16 / 16 f32 deep) run
+    // while the fragments of the next half are being read from LDS, so no LDS latency is exposed to the matrix pipe:
+    //   phase A(t): MFMA on F0(t) [first half of block t]   || ds_read F1(t)
+    //   -- counted vmcnt: block t+1 has landed; lgkmcnt(0): this wave is done reading block t; barrier; issue block t+1+D --
+    //   phase B(t): MFMA on F1(t)                            || ds_read F0(t+1)
+    // One barrier per K block, between the phases.  The interleave inside a phase is pinned with sched_group_barrier (the
+    // machine scheduler otherwise sinks every ds_read to just before its first use and waits lgkmcnt(0) eight times per block).
+    auto mainloop = [&](auto trc) {
+        constexpr bool TR = decltype(trc)::value;
+        constexpr int RR = MT + NT;                                    // ds_read_b128 per phase
+        constexpr int MM = MT * NT * (sizeof(T) == 4 ? 4 : 1);         // MFMA instructions per phase
+        frag_t xf0[MT], wf0[NT], xf1[MT], wf1[NT];
+        auto read_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT], int blk, int kk) {
+            const char* xs = smem_g + (blk % NSTAGE) * STAGE;
+            const char* ws = xs + XBYTES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
+        };
+        auto mma_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT]) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (TR) mma_step<T>(acc[i][j], xf[i], wf[j]);
+                    else mma_step<T>(acc[i][j], wf[j], xf[i]);
+                }
+        };
+        auto pin = [&]() {  // the phase's LDS reads go out early, one per MFMA, so that the last one is >= MM - RR MFMAs old at the phase end
+            constexpr int HEAD = RR < MM ? RR : MM;
+#pragma unroll
+            for (int r = 0; r < HEAD; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA first: the wait in front of it covers only the previous
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // phase's reads, which are at least MM - RR MFMAs old
+            }
+            if constexpr (RR > HEAD) __builtin_amdgcn_sched_group_barrier(0x100, RR - HEAD, 0);
+            if constexpr (MM > HEAD) __builtin_amdgcn_sched_group_barrier(0x008, MM - HEAD, 0);
+        };
+        // block 0 lands
+        if (D <= my_kb) wait_vm<(D - 1) * LPS>();
+        else wait_vm0();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (D < my_kb) issue(D % NSTAGE);
+        if (my_kb > 0) read_half(xf0, wf0, 0, 0);
+        for (int t = 0; t < max_kb; ++t) {
+            const bool active = KG == 1 || t < my_kb;  // the odd group of an odd block count idles through the last trip
+            if (active) {  // phase A
+                read_half(xf1, wf1, t, 1);
+                mma_half(xf0, wf0);
+                pin();
+            }
+            if (t + 1 < max_kb) {
+                if (t + 1 + D <= my_kb) wait_vm<(D - 1) * LPS>();
+                else wait_vm0();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 1 + D < my_kb) issue((t + 1 + D) % NSTAGE);
+            }
+            if (active) {  // phase B
+                read_half(xf0, wf0, t + 1, 0);  // (past the last block: a harmless read of a stale stage; keeps the phase one basic block)
+                mma_half(xf1, wf1);
+                pin();
+            }
+        }
+    };
+    if constexpr (CONV) {
+        mainloop(std::false_type{});
+    } else {
+        if (tr) mainloop(std::true_type{});
+        else mainloop(std::false_type{});
+    }
+
+    if constexpr (KG > 1) {
+        // fixed-order sum of the two groups' partial tiles through LDS (the stage buffers are free once every wave is past
+        // its last MFMA): group 1 deposits [wave][i][j][lane] float4s, group 0 adds them to its own and runs the epilogue
+        __syncthreads();
+        f32x4* ex = reinterpret_cast<f32x4*>(smem) + (wid * MT * NT) * 64 + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ex[(i * NT + j) * 64] = acc[i][j];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 o = ex[(i * NT + j) * 64];
+                acc[i][j][0] += o[0], acc[i][j][1] += o[1], acc[i][j][2] += o[2], acc[i][j][3] += o[3];
+            }
+    } else if (p.ln_stats) {
+        __syncthreads();  // rowstat was written before the main loop by other waves; with max_kb >= 1 a barrier has passed, this covers total_kb == 0
+    }
+
+    // ---- epilogue ----
+    constexpr int EPC = DT<T>::EPC;
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const T* rowbias = reinterpret_cast<const T*>(p.rowbias);
+    const T* res = reinterpret_cast<const T*>(p.res);
+
+    if constexpr (!CONV) {
+        if (tr) {
+            // transposed tile: every lane owns RUN_T = 4*MT consecutive ROWS m of NT columns n = n0 + wn*WNE + 16 j + c16
+            constexpr int RUN_T = 4 * MT;
+            T* out_t = reinterpret_cast<T*>(p.out_t);
+            const int mb = m0 + wm * WME + RUN_T * g;
+            const bool fullm = p.vec_ok && mb + RUN_T <= p.M;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * WNE + 16 * j + c16;
+                if (n >= p.N) continue;
+                float v[RUN_T];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];
+                if (p.ln_stats) {
+                    const float s = p.ln_s[n], c = p.ln_c[n];
+#pragma unroll
+                    for (int e = 0; e < RUN_T; ++e) {
+                        const int row = min(wm * WME + RUN_T * g + e, BM - 1);
+                        v[e] = rowstat[2 * row + 1] * (v[e] - rowstat[2 * row] * s) + c;
+                    }
+                } else if (bias) {
+                    const float b = to_f32(bias[n]);
+#pragma unroll
+                    for (int e = 0; e < RUN_T; ++e) v[e] += b;
+                }
+                T* op = out_t + (int64_t)(n - p.nt_begin) * p.ldt + mb;
+                if (fullm) {
+#pragma unroll
+                    for (int c = 0; c < RUN_T / EPC; ++c) {
+                        Vec16<T> ov;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
+                        store16<T>(op + c * EPC, ov);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < RUN_T; ++e)
+                        if (mb + e < p.M) op[e] = from_f32<T>(v[e]);
+                }
+            }
+            return;
+        }
+    }
+
+    // every lane owns RUN = 4*NT consecutive columns of MT rows
+    constexpr int RUN = 4 * NT;
+    const int nl = wn * WNE + RUN * g;
+    const int n = n0 + nl;
+    const bool full = p.vec_ok && (n + RUN <= p.N);
+    if (p.ksplit > 1) {  // split-K: raw float32 partial sums; bias / residual / conversion happen in splitk_reduce_kernel
+        float* part = p.partial + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * WME + 16 * i + c16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int nn = n + 4 * j;
+                if (nn + 4 <= p.N) *reinterpret_cast<f32x4*>(part + (int64_t)m * p.N + nn) = acc[i][j];
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nn + r < p.N) part[(int64_t)m * p.N + nn + r] = acc[i][j][r];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int mrow = wm * WME + 16 * i + c16;
+        const int m = m0 + mrow;
+        // rows beyond M keep going through the arithmetic when statistics are produced (the shuffles below need all lanes);
+        // their stores are suppressed
+        const bool mok = m < p.M;
+        if (!mok && !p.stats_out) continue;
+        float v[RUN];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
+        if (full) {
+            if (p.ln_stats) {  // y = rstd * (acc - mean * s[n]) + c[n]   (c carries the Linear's bias)
+                const float mean = rowstat[2 * mrow], rstd = rowstat[2 * mrow + 1];
+#pragma unroll
+                for (int c = 0; c < RUN / 4; ++c) {
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4 * c), cv = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * c + e] = rstd * (v[4 * c + e] - mean * sv[e]) + cv[e];
+                }
+            } else if (bias) {
+#pragma unroll
+                for (int c = 0; c < RUN / EPC; ++c) {
+                    Vec16<T> bv = load16<T>(bias + n + c * EPC);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
+                }
+            }
+            if (rowbias && mok) {
+                const T* rb = rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n;
+#pragma unroll
+                for (int c = 0; c < RUN / EPC; ++c) {
+                    Vec16<T> bv = load16<T>(rb + c * EPC);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
+                }
+            }
+            if (p.gelu) {
+#pragma unroll
+                for (int e = 0; e < RUN; ++e) v[e] = p.gelu == 1 ? gelu_exact(v[e]) : quick_gelu(v[e]);
+            }
+            if (p.geglu) {
+                if constexpr (NT == 4) {
+                    constexpr int HR = RUN / 2;
+                    const int no = (n0 + wn * WNE) / 2 + HR * g;
+                    float o[HR];
+#pragma unroll
+                    for (int e = 0; e < HR; ++e) o[e] = v[e] * gelu_exact(v[HR + e]);
+                    if (res) {
+                        const T* rp = res + (int64_t)m * p.ldres + no;
+#pragma unroll
+                        for (int c = 0; c < HR / EPC; ++c) {
+                            Vec16<T> rv = load16<T>(rp + c * EPC);
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) o[c * EPC + e] += rv.get(e);
+                        }
+                    }
+                    constexpr int BKE = 128 / (int)sizeof(T);  // elements per 128-byte K block of the consumer
+                    T* op = p.out_kb ? out + ((int64_t)(no / BKE) * p.M + m) * BKE + no % BKE : out + (int64_t)m * p.ldo + no;
+#pragma unroll
+                    for (int c = 0; c < HR / EPC; ++c) {
+                        Vec16<T> ov;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) ov.set(e, o[c * EPC + e]);
+                        store16<T>(op + c * EPC, ov);
+                    }
+                }
+            } else {
+                if (res && mok) {
+                    const T* rp = res + (int64_t)m * p.ldres + n;
+#pragma unroll
+                    for (int c = 0; c < RUN / EPC; ++c) {
+                        Vec16<T> rv = load16<T>(rp + c * EPC);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) v[c * EPC + e] += rv.get(e);
+                    }
+                }
+                T* op = out + (int64_t)m * p.ldo + n;
+                float rs = 0.f;  // sum of the values AS STORED (rounded to T): the next LayerNorm normalises the stored tensor
+#pragma unroll
+                for (int c = 0; c < RUN / EPC; ++c) {
+                    Vec16<T> ov;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
+                    if (mok) store16<T>(op + c * EPC, ov);
+                    if (p.stats_out) {
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            v[c * EPC + e] = ov.get(e);
+                            rs += ov.get(e);
+                        }
+                    }
+                }
+                if (p.stats_out) {
+                    // (mean, M2) of this lane's RUN columns, Chan-merged over the lane groups that share a 32-column chunk:
+                    // RUN = 16 -> groups (g, g^1); RUN = 8 -> all four groups.  Lower group first on both sides: identical bits.
+                    float mean = rs * (1.0f / RUN), m2 = 0.f, cn = (float)RUN;
+#pragma unroll
+                    for (int e = 0; e < RUN; ++e) m2 += (v[e] - mean) * (v[e] - mean);
+                    constexpr int GPC = 32 / RUN;  // lane groups per 32-column chunk
+#pragma unroll
+                    for (int o = 16; o < 16 * GPC; o <<= 1) {
+                        const float nb = __shfl_xor(cn, o), mb2 = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
+                        if (lane & o) {
+                            float n2 = nb, me2 = mb2, q2 = qb;
+                            stat_merge(n2, me2, q2, cn, mean, m2);
+                            cn = n2, mean = me2, m2 = q2;
+                        } else {
+                            stat_merge(cn, mean, m2, nb, mb2, qb);
+                        }
+                    }
+                    if (mok && (g % GPC) == 0) {
+                        const int chunk = n / 32;
+                        f32x2 st = {mean, m2};
+                        *reinterpret_cast<f32x2*>(p.stats_out + ((int64_t)chunk * p.M + m) * 2) = st;
+                    }
+                }
+            }
+        } else if (mok) {
+            // guarded scalar path (N edge tiles, unaligned outputs); geglu / LayerNorm fusion are never routed here (host checks)
+#pragma unroll
+            for (int e = 0; e < RUN; ++e) {
+                const int nn = n + e;
+                if (nn < p.N) {
+                    float val = v[e];
+                    if (bias) val += to_f32(bias[nn]);
+                    if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
+                    if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
+                    if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
+                    out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
+                }
+            }
+        }
+    }
+}
+
+// out[m][n] = dtype( sum_s partial[s][m][n] (fixed order) + bias[n] + rowbias[m / rpg][n] + res[m][n] ): 4 columns per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
+    const int nq = (p.N + 3) / 4;
+    const int64_t total = (int64_t)p.M * nq;
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const T* rowbias = reinterpret_cast<const T*>(p.rowbias);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int m = (int)(q / nq);
+        const int n = (int)(q - (int64_t)m * nq) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full4 = n + 4 <= p.N;
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float* pp = p.partial + ((int64_t)s * p.M + m) * p.N + n;
+            if (full4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(pp);
+                v[0] += t[0], v[1] += t[1], v[2] += t[2], v[3] += t[3];
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) v[r] += pp[r];
+            }
+        }
+        for (int r = 0; r < 4; ++r) {
+            const int nn = n + r;
+            if (nn >= p.N) break;
+            float val = v[r];
+            if (bias) val += to_f32(bias[nn]);
+            if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
+            if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
+            if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
+            out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
+        }
+    }
+}
+
+extern int g_pf_blocks;  // default number of prefetch workgroups when the caller gives spans but no count (0 = prefetch off)
+extern int g_pf_mode;    // 1 = plain loads, 2 = non-temporal
+extern int g_tile;       // 0 = heuristic / caller's hint, 1..6 = force a tile configuration (probing / A-B runs)
+extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS pipeline depth
+
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1>
+int launch_cfg(const GemmP& p, hipStream_t stream) {
+    constexpr int LDS = KG * NSTAGE * (BM + BN) * 128 + BM * 8;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static_assert(KG == 1 || (BM / WM / 16) * (BN / WN / 16) * WM * WN * 1024 <= KG * NSTAGE * (BM + BN) * 128, "partial-tile exchange must fit the stage buffers");
+    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    GemmP q = p;
+    q.tiles_n = (p.N + BN - 1) / BN;
+    q.tiles_m = (p.M + BM - 1) / BM;
+    // How the 8 XCDs (private L2 each) share the tile grid.  Bytes pulled into the L2s ~ nx * |X| + nw * |W| where nx / nw =
+    // number of XCDs that touch each activation row / weight row; |X|, |W| in K-elements per row (a 3x3 conv reads every
+    // activation row through 9 taps but it is ONE row in L2).  Candidates: exact pm x pn rectangles, or balanced contiguous
+    // chunks of the row-major (nx = 1, nw = 8) / column-major (nx = 8, nw = 1) order.
+    double kx = 0, kw = 0;
+    for (int sgi = 0; sgi < p.nseg; ++sgi) {
+        const SegP& sg = p.seg[sgi];
+        kw += sg.nkb;
+        kx += CONV ? (double)sg.nkb / (sg.ksize * sg.ksize) : (double)sg.nkb;
+    }
+    const double bx_ = (double)p.M * kx, bw_ = (double)p.N * kw;
+    double best = bx_ + 8.0 * bw_;  // row-major chunks
+    q.pn = 0;
+    q.hm = q.hn = 0;
+    if (8.0 * bx_ + bw_ < best) {
+        best = 8.0 * bx_ + bw_;
+        q.pn = -1;
+    }
+    for (int pm = 2; pm <= 4; pm *= 2) {
+        const int pn = 8 / pm;
+        if (q.tiles_m % pm || q.tiles_n % pn) continue;
+        const double cost = pn * bx_ + pm * bw_;
+        if (cost < best) {
+            best = cost;
+            q.pn = pn;
+            q.hm = q.tiles_m / pm;
+            q.hn = q.tiles_n / pn;
+        }
+    }
+    q.grid0 = q.tiles_m * q.tiles_n;
+    bool any_pf = false;
+    for (int i = 0; i < MI355X_MAX_PREFETCH; ++i) any_pf = any_pf || (q.pf_ptr[i] && q.pf_bytes[i] > 0);
+    if (!any_pf || g_pf_blocks == 0) q.pf_blocks = 0;
+    else if (q.pf_blocks <= 0) q.pf_blocks = g_pf_blocks;
+    q.pf_blocks = (q.pf_blocks + 7) / 8 * 8;  // a multiple of 8: compute block b still lands on XCD b % 8
+    if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
+    q.pf_mode = g_pf_mode;
+    const int grid = q.pf_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
+    // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), q.ln_stats ? LDS : LDS - BM * 8, stream, q);
+    if (q.ksplit > 1) {
+        const int64_t work = (int64_t)q.M * ((q.N + 3) / 4);
+        int64_t rb = (work + 255) / 256;
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((int)rb), dim3(256), 0, stream, q);
+    }
+    return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
+}
+
+// Tile configurations:  1: 128x128   2: 128x64   3: 64x128   4: 64x64   (4 waves, 2 x 2)
+//                       5: 256x128 (8 waves, 4 x 2)          6: 128x128 with two K groups (8 waves, intra-workgroup split-K)
+// The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
+// how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.  The engine
+// passes measured choices per shape (refiners_amd/engine/tuning.py); this heuristic is the fallback.
+inline int pick_tile(const GemmP& p, bool conv) {
+    if (g_tile >= 1 && g_tile <= 6) return g_tile;
+    if (p.tile_hint >= 1 && p.tile_hint <= 6) return p.tile_hint;
+    const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (conv) return 3;  // 64 x 128 wins for every conv shape of the UNet (r01_b probe: 339 / 540 / 570 TF at 32^2 / 64^2 / 128^2)
+    if (p.geglu) return 1;
+    if (b128 <= 256) return 4;
+    if (b128 < 1000) return 2;
+    return 1;
+}
+inline int pick_stages(const GemmP& p) {
+    if (g_stages >= 2 && g_stages <= 4) return g_stages;
+    if (p.stage_hint >= 2 && p.stage_hint <= 4) return p.stage_hint;
+    return 2;  // two LDS stages by default: deeper pipelines cost a resident workgroup per CU
+}
+
+template <typename T, int BM, int BN, bool CONV>
+int launch_stages(const GemmP& p, int stages, hipStream_t stream) {
+    switch (stages) {
+        case 2: return launch_cfg<T, BM, BN, 2, 2, CONV, 2>(p, stream);
+        case 4: return launch_cfg<T, BM, BN, 2, 2, CONV, 4>(p, stream);
+        default: return launch_cfg<T, BM, BN, 2, 2, CONV, 3>(p, stream);
+    }
+}
+
+template <typename T, bool CONV>
+int launch_tile(const GemmP& p, hipStream_t stream) {
+    int tile = pick_tile(p, CONV);
+    if (p.geglu && (tile == 2 || tile == 4)) tile = 3;  // the GEGLU epilogue needs 64 packed columns per wave
+    const int st = pick_stages(p);
+    switch (tile) {
+        case 1: return launch_stages<T, 128, 128, CONV>(p, st, stream);
+        case 2: return launch_stages<T, 128, 64, CONV>(p, st, stream);
+        case 3: return launch_stages<T, 64, 128, CONV>(p, st, stream);
+        case 5: return st == 3 ? launch_cfg<T, 256, 128, 4, 2, CONV, 3>(p, stream) : launch_cfg<T, 256, 128, 4, 2, CONV, 2>(p, stream);
+        case 6: return launch_cfg<T, 128, 128, 2, 2, CONV, 2, 2>(p, stream);
+        default: return launch_stages<T, 64, 64, CONV>(p, st, stream);
+    }
+}
+
+int launch_conv_f32(const GemmP& p, hipStream_t stream);
+int launch_conv_bf16(const GemmP& p, hipStream_t stream);
+
+}  // namespace mi355x

@@ -33,7 +33,26 @@ TOKEN_CONTEXTS = (("cross_attention_block", "clip_text_embedding"), ("ip_adapter
 
 
 def _ident(t: Optional[Tensor]) -> Any:
-    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+    """Identity of a prompt-side input.  The key alone is not enough: once the caller drops the tensor the allocator may hand
+    the same block (same data_ptr, same _version) to the NEXT prompt's embedding, so whoever stores this key also stores the
+    tensor itself (CompiledUNet.prologue_refs) -- a live tensor's address cannot be recycled."""
+    return None if t is None else (id(t), t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+
+
+_param_lists: dict[int, tuple[Any, list]] = {}
+
+
+def _weights_version(unet: Any, epoch: Any = None) -> int:
+    """Changes whenever a parameter is updated IN PLACE (load_state_dict / load_from_safetensors without assign,
+    parallel.broadcast_module, optimizer steps): converted, merged and K-blocked copies must then be rebuilt.  The
+    parameter list of a mirror tree is cached per tree epoch (the walk over ~2 900 modules costs more than the sum)."""
+    if epoch is None:
+        return sum(p._version for p in unet.parameters())
+    got = _param_lists.get(id(unet))
+    if got is None or got[0] != epoch:
+        got = (epoch, list(unet.parameters()))
+        _param_lists[id(unet)] = got
+    return sum(p._version for p in got[1])
 
 
 class Program:
@@ -72,6 +91,7 @@ class CompiledUNet:
         self.key: Any = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.prologue_key: Any = None
+        self.prologue_refs: Any = None  # the staged source tensors themselves (see _ident)
         self.stats: dict[str, Any] = {}
 
     # -- context plumbing ----------------------------------------------------------------------------------
@@ -128,9 +148,11 @@ class CompiledUNet:
         # the step program is replayed step after step: let every GEMM / conv pull the weights of the launches behind it into
         # the Infinity Cache (weights are read exactly once per step, so otherwise every kernel starts on DRAM misses)
         pf = native.link_weight_prefetch(low.step, enable=self.weight_prefetch)
-        self.low, self.io, self.graph, self.prologue_key = low, io, None, None
+        self.low, self.io, self.graph, self.prologue_key, self.prologue_refs = low, io, None, None, None
+        from . import tuning
+
         self.stats = dict(low.stats, step_ops=launches(low.step), prologue_ops=launches(low.prologue), pool_bytes=low.step_pool.bytes() + low.prologue_pool.bytes(),
-                          weight_prefetch=pf)
+                          weight_prefetch=pf, gemm_tuning=tuning.summary(), ln_fuse=low.ln_fuse, qkv_merge=low.qkv_merge)
 
     def _out_channels(self) -> int:
         last = [m for m in self.unet.modules() if isa(m, "Conv2d")][-1]
@@ -159,6 +181,8 @@ class CompiledUNet:
             for buf, f in zip(io.t2i[name], feats):
                 buf.copy_(f)
         self.prologue_key = pk
+        self.prologue_refs = (got["pooled"], got["time_ids"], tuple(got["tokens"].values()), tuple(got["conditions"].values()),
+                              tuple(f for feats in got.get("t2i", {}).values() for f in feats))
         return True
 
     # -- execution ---------------------------------------------------------------------------------------------
@@ -177,8 +201,9 @@ class CompiledUNet:
         from ..fluxion.tree import Chain as MirrorChain
 
         if isinstance(self.unet, MirrorChain):
-            return tree_epoch()
-        sig = []
+            ep = tree_epoch()
+            return (ep, _weights_version(self.unet, ep))
+        sig: list[Any] = [_weights_version(self.unet)]
         for m in self.unet.modules():
             sig.append(id(m))
             if isa(m, "Multiply", "T2IFeatures"):  # nodes whose live scale is baked into the program
@@ -245,16 +270,34 @@ class CompiledSDXL:
         self.unet = unet
         self.engine = CompiledUNet(unet, use_graph=False, lora_mode=lora_mode)
         self.use_graph = use_graph
+        self.coef_table: Optional[Tensor] = None
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.solver = solver if solver is not None else DDIM(num_inference_steps)
-        self.linear = hasattr(self.solver, "linear_step")
         self.hist: Optional[Tensor] = None
         self.primed, self.primed_key = False, None
-        self.condition_scale = condition_scale
+        self._condition_scale = condition_scale
         self.x: Optional[Tensor] = None
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graph_key: Any = None
         self.inputs: dict[str, Any] = {}
-        self.coef_table: Optional[Tensor] = None
+
+    @property
+    def condition_scale(self) -> float:
+        return self._condition_scale
+
+    @condition_scale.setter
+    def condition_scale(self, value: float) -> None:  # baked into the device coefficient table: rebuild it on the next set_inputs / step
+        self._condition_scale = value
+        self.coef_table = None
+
+    @property
+    def solver(self) -> Any:
+        return self._solver
+
+    @solver.setter
+    def solver(self, value: Any) -> None:
+        self._solver = value
+        self.linear = hasattr(value, "linear_step")
+        self.coef_table, self.graph = None, None  # other coefficients, possibly another update kernel
 
     def _tables(self, device: torch.device) -> None:
         rows = []
@@ -280,12 +323,16 @@ class CompiledSDXL:
         self.inputs = {"pooled": pooled_text_embedding, "time_ids": time_ids, "tokens": tokens,
                        "conditions": {f"control_lora_{k}": v for k, v in (conditions or {}).items()},
                        "t2i": {k: tuple(v) for k, v in (t2i_features or {}).items()}}
-        if self.x is None or self.x.shape != x.shape or self.x.device != x.device:
+        if self.x is None or self.x.shape != x.shape or self.x.device != x.device or self.x.dtype != self.unet.dtype:
             self.x = torch.empty(tuple(x.shape), device=x.device, dtype=self.unet.dtype)
+            # the solver history lives as long as x does: a captured graph holds both addresses, so neither may be
+            # re-allocated per trajectory (a fresh zeros_like() here left the graph reading / writing a freed block)
+            self.hist = torch.zeros_like(self.x)
             self.graph = None
         self.x.copy_(x)
         if self.linear:
-            self.hist = torch.zeros_like(self.x)
+            assert self.hist is not None
+            self.hist.zero_()
             self.primed = False  # the model-input buffer must be (re)filled with s_0 * x before the next step
         if self.coef_table is None or self.coef_table.device != x.device:
             self._tables(x.device)
@@ -298,7 +345,9 @@ class CompiledSDXL:
 
     @torch.no_grad()
     def step(self, step: int) -> Tensor:
-        assert self.x is not None and self.coef_table is not None, "call set_inputs first"
+        assert self.x is not None, "call set_inputs first"
+        if self.coef_table is None or self.coef_table.device != self.x.device:
+            self._tables(self.x.device)  # condition_scale / solver changed since the last call
         eng = self.engine
         got = dict(self.inputs, timestep=self.ts_table[step : step + 1])
         n = self.x.shape[0]
@@ -355,7 +404,15 @@ class CompiledSDXL:
         return self.x
 
     @torch.no_grad()
-    def sample(self, first_step: int = 0) -> Tensor:
+    def sample(self, first_step: Optional[int] = None) -> Tensor:
+        """Run the trajectory from the solver's `first_inference_step` (img2img starts later than 0).  A multistep solver
+        decides between its first- and second-order update by comparing the step with ITS first_inference_step
+        (solvers/dpm.py:136-152), so starting anywhere else would run a second-order update on an all-zero history."""
+        first = int(getattr(self.solver, "first_inference_step", 0))
+        if first_step is None:
+            first_step = first
+        assert first_step == first or not self.linear, (
+            f"sample(first_step={first_step}) but solver.first_inference_step={first}: build the solver with first_inference_step={first_step}")
         for s in range(first_step, self.solver.num_inference_steps):
             self.step(s)
         return self.x  # type: ignore[return-value]

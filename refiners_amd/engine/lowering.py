@@ -166,9 +166,30 @@ class Pool:
         return sum(t.numel() * t.element_size() for t in self.all)
 
 
+class _Src:
+    """Key element for one source tensor: compares by (id, _version, data_ptr) and HOLDS the tensor, so that for as long as
+    a cache entry exists its sources stay alive and neither their id() nor their storage address can be handed to another
+    tensor (a same-shaped LoRA loaded after an eject would otherwise hit the stale merged / packed copy)."""
+
+    __slots__ = ("t", "sig")
+
+    def __init__(self, t: Tensor) -> None:
+        self.t = t
+        self.sig = (id(t), t._version, t.data_ptr())
+
+    def __hash__(self) -> int:
+        return hash(self.sig)
+
+    def __eq__(self, other: object) -> bool:
+        return isinstance(other, _Src) and self.sig == other.sig
+
+    def __repr__(self) -> str:
+        return f"_Src{self.sig}"
+
+
 class PackCache:
-    """Packed / converted copies of leaf weights, keyed on the identity and version of the source tensors, so that a
-    re-lowering after inject / eject / scale change only re-packs what actually changed."""
+    """Packed / converted copies of leaf weights, keyed on the identity and version of the source tensors (which the key
+    keeps alive, see _Src), so that a re-lowering after inject / eject / scale change only re-packs what actually changed."""
 
     def __init__(self) -> None:
         self.store: dict[tuple, Any] = {}
@@ -177,7 +198,7 @@ class PackCache:
 
     @staticmethod
     def ident(*tensors: Optional[Tensor]) -> tuple:
-        return tuple((id(t), t._version, t.data_ptr()) if t is not None else None for t in tensors)
+        return tuple(_Src(t) if t is not None else None for t in tensors)
 
     def get(self, key: tuple, make: Callable[[], Any]) -> Any:
         self.used.add(key)
@@ -210,6 +231,11 @@ class Lowering:
         # MI355X the forked Q|K / V^T pair makes the SDXL step 2 % SLOWER (29.7 vs 29.0 ms; the join edges cost more than the
         # overlap gains, both GEMMs pull from the same L2s).  Kept as a switch for larger batches / other trees.
         self.side_branches = device.type == "cuda" and os.environ.get("REFINERS_AMD_SIDE_BRANCHES", "0") == "1"
+        # LayerNorm folded into the GEMM that consumes it (row statistics from the producing GEMM's epilogue) and the three
+        # projections of a self-attention as ONE launch (V stored transposed): REFINERS_AMD_LN_FUSE / REFINERS_AMD_QKV_MERGE = 0 switch
+        # them off (A/B runs; the unfused kernels stay in the library)
+        self.ln_fuse = os.environ.get("REFINERS_AMD_LN_FUSE", "1") != "0"
+        self.qkv_merge = os.environ.get("REFINERS_AMD_QKV_MERGE", "1") != "0"
         self.device, self.dtype = device, dtype
         self.es = 4 if dtype == torch.float32 else 2
         self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
@@ -357,7 +383,18 @@ class Lowering:
         _expect((i * self.es) % 128 == 0, f"conv in_channels {i} not 128-byte aligned")
         wp = self.cache.get(("convw",) + PackCache.ident(w), lambda: native.pack_conv_weight(self.cvt(w)))
         lora = None
-        if loras and self.lora_mode == "merged" and all(kids(lr)[1].kernel_size == (1, 1) and kids(lr)[0].kernel_size == (kh, kh) for lr in loras):
+        def _pad2(c: Any) -> tuple:
+            return tuple(c.padding) if isinstance(c.padding, (tuple, list)) else (c.padding, c.padding)
+
+        def mergeable(lr: Any) -> bool:
+            # B.A folds into the target's weights only when the down conv sees the input exactly like the target does and the
+            # up conv is a plain per-pixel 1x1 (same checks as the run-time K-segment path below; anything else keeps that path)
+            d, u = kids(lr)[0], kids(lr)[1]
+            return (u.kernel_size == (1, 1) and tuple(u.stride) == (1, 1) and _pad2(u) == (0, 0) and d.kernel_size == (kh, kh)
+                    and tuple(d.stride) == tuple(leaf.stride) and _pad2(d) == _pad2(leaf) and tuple(d.dilation) == (1, 1) and d.groups == 1 and u.groups == 1
+                    and d.weight.shape[1] == i and u.weight.shape[0] == o and u.weight.shape[1] == d.weight.shape[0])
+
+        if loras and self.lora_mode == "merged" and all(mergeable(lr) for lr in loras):
             dws = [kids(lr)[0].weight for lr in loras]
             uws = [kids(lr)[1].weight for lr in loras]
             scs = tuple(float(kids(lr)[2].scale) for lr in loras)
@@ -414,22 +451,66 @@ class Lowering:
         return self.cache.get(("kblocked",) + PackCache.ident(w), lambda: native.KBlocked(w))
 
     def linear(self, x: Any, spec: LinSpec, *, res: Optional[Tensor] = None, out: Optional[Tensor] = None,
-               rows: Optional[int] = None, lora_t: Optional[Tensor] = None, gelu: bool = False, out_kblocked: bool = False) -> Tensor:
+               rows: Optional[int] = None, lora_t: Optional[Tensor] = None, gelu: bool = False, out_kblocked: bool = False,
+               ln: Optional[tuple] = None, stats_out: Optional[Tensor] = None) -> Tensor:
         """out[M, N(/2 if geglu)] = epi(x W^T + b (+ LoRA) (+ res)).  `lora_t` lets callers share one down-projection
-        launch between Linears that read the same x."""
+        launch between Linears that read the same x.  `ln` = (stats, LayerNorm node): x is the UN-normalised tensor and the
+        LayerNorm is applied inside this launch (ln_fold); `stats_out`: also write the output rows' statistics."""
         M = x.shape[0]
         n_cols = spec.N // 2 if spec.geglu else spec.N
         if out is None:
             out = self.pool.get(M, n_cols)
+        if ln is not None:
+            assert spec.lora is None
+            stats, node = ln
+            wl, ls, lc = self.ln_fold(spec, node)
+            native.gemm([(x, self.kblocked(wl))], out, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, ln=(stats, ls, lc, float(node.eps)),
+                        stats_out=stats_out)
+            return out
         segs = [(x, self.kblocked(spec.w))]
         t = None
         if spec.lora is not None:
             t = lora_t if lora_t is not None else self.lora_down(x, spec.lora)
             segs.append((t, spec.lora.bs_cat))
-        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked)
+        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, stats_out=stats_out)
         if t is not None and lora_t is None:
             self.pool.put(t)
         return out
+
+    # -- LayerNorm folded into its consumer ------------------------------------------------------------------------------------
+    def ln_fold(self, spec: LinSpec, node: Any) -> tuple[Tensor, Tensor, Tensor]:
+        """(W', s, c) of `Linear(LayerNorm(x))` for mi355x_gemm's ln_* arguments: W' = W diag(gamma) in the compute dtype,
+        s[n] = sum_k W'[n][k] (of the ROUNDED W', which is what the matrix cores multiply), c = W beta + b, both float32.
+        spec.w may already be row-permuted (GEGLU) or a merged LoRA weight: everything here is per row."""
+        _expect(isa(node, "LayerNorm") and tuple(node.normalized_shape) == (spec.K,) and node.weight is not None, "LayerNorm shape mismatch")
+        key = ("ln_fold",) + PackCache.ident(spec.w, spec.b, node.weight, node.bias)
+
+        def make() -> tuple[Tensor, Tensor, Tensor]:
+            w32 = spec.w.detach().to(self.device, torch.float32)
+            g32 = node.weight.detach().to(self.device, torch.float32)
+            wl = (w32 * g32.unsqueeze(0)).to(self.dtype).contiguous()
+            ls = wl.to(torch.float32).sum(dim=1).contiguous()
+            lc = torch.zeros(w32.shape[0], device=self.device, dtype=torch.float32)
+            if node.bias is not None:
+                lc = w32 @ node.bias.detach().to(self.device, torch.float32)
+            if spec.b is not None:
+                lc = lc + spec.b.detach().to(self.device, torch.float32)
+            return wl, ls, lc.contiguous()
+
+        return self.cache.get(key, make)
+
+    def ln_fusable(self, stats: Optional[Tensor], *specs: LinSpec) -> bool:
+        return (stats is not None and self.ln_fuse and self.device.type != "meta" and all(sp.lora is None and sp.N % 64 == 0 and sp.K % 64 == 0 for sp in specs))
+
+    def row_stats(self, M: int, C: int) -> Optional[Tensor]:
+        """The [C / 32][M][2] float32 buffer a producing GEMM's epilogue fills with per-row (mean, M2) partials.  One per (M, C):
+        the program is sequential, every consumer of a set of statistics runs before the next producer of that size."""
+        if not self.ln_fuse or C % 64 or self.device.type == "meta":
+            return None
+        store = self.__dict__.setdefault("_row_stats", {})
+        if (M, C) not in store:
+            store[(M, C)] = torch.empty(C // 32, M, 2, device=self.device, dtype=torch.float32)
+        return store[(M, C)]
 
     def linear_T(self, x: Tensor, spec: LinSpec, out_t: Tensor) -> Tensor:
         """out_t[N, M] = W x^T (+ LoRA): the V^T layout mi355x_attention consumes (operands swapped, no bias)."""
@@ -610,39 +691,61 @@ class Lowering:
             self.linear_T(h[b * L : (b + 1) * L], vs, vt[:, b * lp : b * lp + L])
         return vt
 
-    def self_attention(self, x: Tensor, B: int, ln: Any, att: Any) -> Tensor:
-        """x += Wo SDPA(Wq h, Wk h, Wv h), h = LN(x)   (cross_attention.py:44-49; attentions.py:319-385)."""
+    def self_attention(self, x: Tensor, B: int, ln: Any, att: Any, stats: Optional[Tensor] = None, stats_out: Optional[Tensor] = None) -> Tensor:
+        """x += Wo SDPA(Wq h, Wk h, Wv h), h = LN(x)   (cross_attention.py:44-49; attentions.py:319-385).
+        `stats`: row statistics of x (LayerNorm then runs inside the projection launches); `stats_out`: buffer for the
+        statistics of the updated x."""
         (qn, kn, vn), sd, on, ip = self._split_attention(att)
         _expect(ip is None, "image cross-attention on a self-attention")
         heads = sd.num_heads
-        h = self.layernorm(x, ln)
         qs, ks, vs = self.linear_spec(qn), self.linear_spec(kn), self.linear_spec(vn)
         _expect(qs.b is None and ks.b is None and vs.b is None, "q/k/v bias not supported")
         M, C = x.shape
         native_path = self.head_kernel(C // heads) is not None
         L = M // B
-        # The V^T projection and the packed Q|K projection read the same h and do not depend on each other; neither fills the
-        # chip at a CFG pair's 2048 rows, so V^T is issued on the side stream (native.side_branch) and joined before attention.
-        concurrent = native_path and self.side_branches and vs.lora is None
-        vt = None
-        if concurrent:
-            native.fork()
-            with native.side_branch():
-                vt = self._project_vt(h, vs, B, L, C)
-        if qs.lora is None and ks.lora is None:
-            wqk = self.cache.get(("qk",) + PackCache.ident(qs.w, ks.w), lambda: torch.cat([qs.w, ks.w], 0).contiguous())
+        fold = self.ln_fusable(stats, qs, ks, vs)
+        lnarg = (stats, ln) if fold else None
+        h = x if fold else self.layernorm(x, ln)
+        no_lora = qs.lora is None and ks.lora is None and vs.lora is None
+        qk = q = k = vt = None
+        if no_lora and native_path and self.qkv_merge and L % 64 == 0 and C % 128 == 0 and self.device.type != "meta":
+            # ONE launch for the three projections: [Wq; Wk; Wv] stacked, Q | K row-major, V stored transposed
+            wqkv = LinSpec(self.cache.get(("qkv",) + PackCache.ident(qs.w, ks.w, vs.w), lambda: torch.cat([qs.w, ks.w, vs.w], 0).contiguous()), None)
             qk = self.pool.get(M, 2 * C)
-            native.gemm([(h, self.kblocked(wqk))], qk)
+            vt = self.pool.get(C, M)
+            if fold:
+                wl, ls, lc = self.ln_fold(wqkv, ln)
+                native.gemm([(h, self.kblocked(wl))], qk, out_t=vt, nt_begin=2 * C, ln=(stats, ls, lc, float(ln.eps)))
+            else:
+                native.gemm([(h, self.kblocked(wqkv.w))], qk, out_t=vt, nt_begin=2 * C)
             q, k = qk[:, :C], qk[:, C:]
         else:
-            qk = None
-            q = self.linear(h, qs)
-            k = self.linear(h, ks)
-        if native_path:
+            # The V^T projection and the packed Q|K projection read the same h and do not depend on each other; neither fills the
+            # chip at a CFG pair's 2048 rows, so V^T may be issued on the side stream (native.side_branch) and joined before attention.
+            if fold and not (native_path and L % 64 == 0):
+                h, lnarg, fold = self.layernorm(x, ln), None, False  # the per-sample / torch V paths want a materialised h
+            concurrent = native_path and self.side_branches and vs.lora is None and not fold
             if concurrent:
-                native.join()
+                native.fork()
+                with native.side_branch():
+                    vt = self._project_vt(h, vs, B, L, C)
+            if qs.lora is None and ks.lora is None:
+                wqk = LinSpec(self.cache.get(("qk",) + PackCache.ident(qs.w, ks.w), lambda: torch.cat([qs.w, ks.w], 0).contiguous()), None)
+                qk = self.linear(h, wqk, ln=lnarg)
+                q, k = qk[:, :C], qk[:, C:]
             else:
-                vt = self._project_vt(h, vs, B, L, C)
+                q = self.linear(h, qs)
+                k = self.linear(h, ks)
+            if native_path:
+                if concurrent:
+                    native.join()
+                elif fold:  # V^T = (Wv LN(x)^T): the transposed column group alone (nt_begin = 0)
+                    vt = self.pool.get(C, M)
+                    wl, ls, lc = self.ln_fold(vs, ln)
+                    native.gemm([(h, self.kblocked(wl))], None, out_t=vt, nt_begin=0, ln=(stats, ls, lc, float(ln.eps)))
+                else:
+                    vt = self._project_vt(h, vs, B, L, C)
+        if native_path:
             o = self.sdpa(q, B, heads, [(k, vt, L, 1.0)])
             if L % 64 == 0:
                 self.pool.put(vt)
@@ -650,17 +753,19 @@ class Lowering:
             v = self.linear(h, vs)
             o = self.sdpa(q, B, heads, [(k, v, M // B, 1.0)], v_plain=[v])
             self.pool.put(v)
-        self.pool.put(h)
+        if h is not x:
+            self.pool.put(h)
         if qk is not None:
             self.pool.put(qk)
         else:
             self.pool.put(q)
             self.pool.put(k)
-        self.linear(o, self.linear_spec(on), res=x, out=x)
+        self.linear(o, self.linear_spec(on), res=x, out=x, stats_out=stats_out)
         self.pool.put(o)
         return x
 
-    def cross_attention(self, x: Tensor, B: int, ln: Any, par: Any, att: Any, ctx: "UNetContext") -> Tensor:
+    def cross_attention(self, x: Tensor, B: int, ln: Any, par: Any, att: Any, ctx: "UNetContext", stats: Optional[Tensor] = None,
+                        stats_out: Optional[Tensor] = None) -> Tensor:
         """x += Wo (SDPA(Wq LN(x), K_text, V_text) [+ s SDPA(q, K_img, V_img)])   (cross_attention.py:50-68,
         image_prompt.py:237-309).  K / V^T of the text and image tokens are produced in the prologue."""
         pc = kids(par)
@@ -687,37 +792,47 @@ class Lowering:
             streams.append((k2, v2, ilk, float(ic[2].scale)))
             plains.append(vp2)
             self.stats["ip_sites"] += 1
-        h = self.layernorm(x, ln)
-        q = self.linear(h, self.linear_spec(qn))
-        self.pool.put(h)
+        qspec = self.linear_spec(qn)
+        if self.ln_fusable(stats, qspec):
+            q = self.linear(x, qspec, ln=(stats, ln))
+        else:
+            h = self.layernorm(x, ln)
+            q = self.linear(h, qspec)
+            self.pool.put(h)
         o = self.sdpa(q, B, heads, streams, v_plain=plains if plains[0] is not None else None)
         self.pool.put(q)
-        self.linear(o, self.linear_spec(on), res=x, out=x)
+        self.linear(o, self.linear_spec(on), res=x, out=x, stats_out=stats_out)
         self.pool.put(o)
         return x
 
-    def feed_forward(self, x: Tensor, ln: Any, w1: Any, glu: Any, w2: Any) -> Tensor:
+    def feed_forward(self, x: Tensor, ln: Any, w1: Any, glu: Any, w2: Any, stats: Optional[Tensor] = None, stats_out: Optional[Tensor] = None) -> Tensor:
         """x += W2 GEGLU(W1 LN(x))   (cross_attention.py:69-72): GEGLU is the epilogue of the first GEMM."""
         _expect(isa(glu, "GLU") and isa(glu.activation, "GeLU") and glu.activation.approximation.value == "none", "only GLU(GeLU(exact)) is fused")
-        h = self.layernorm(x, ln)
         s1, s2 = self.linear_spec(w1, geglu=True), self.linear_spec(w2)
         # the intermediate [M, 4C] has 10 KB rows at C = 1280: the second GEMM would stream it at half rate, so the GEGLU epilogue
         # stores it K-blocked (same bytes, [column block][M][128 B]) whenever the kernel's vector store path applies
         blocked = self.kblock_policy > 0 and s1.lora is None and s2.lora is None and s1.N % 256 == 0 and self.device.type != "meta"
-        ff = self.linear(h, s1, out_kblocked=blocked)
-        self.pool.put(h)
-        self.linear(native.KBlocked.adopt(ff.view(-1), ff.shape[0], ff.shape[1]) if blocked else ff, s2, res=x, out=x)
+        if self.ln_fusable(stats, s1):
+            ff = self.linear(x, s1, out_kblocked=blocked, ln=(stats, ln))
+        else:
+            h = self.layernorm(x, ln)
+            ff = self.linear(h, s1, out_kblocked=blocked)
+            self.pool.put(h)
+        self.linear(native.KBlocked.adopt(ff.view(-1), ff.shape[0], ff.shape[1]) if blocked else ff, s2, res=x, out=x, stats_out=stats_out)
         self.pool.put(ff)
         return x
 
-    def cross_attention_block(self, blk: Any, x: Tensor, B: int, ctx: "UNetContext") -> Tensor:
+    def cross_attention_block(self, blk: Any, x: Tensor, B: int, ctx: "UNetContext", stats: Optional[Tensor] = None, last: bool = True) -> Tensor:
+        """`stats`: the statistics buffer of x's size class when x's PRODUCER filled it (else None); every residual update
+        inside the block refills it for the next LayerNorm -- except the last one of the last block (`last`)."""
         ch = kids(blk)
         _expect(len(ch) == 3 and all(isa(c, "Residual") for c in ch), "unexpected CrossAttentionBlock layout")
         r1, r2, r3 = (kids(c) for c in ch)
         _expect(len(r1) == 2 and len(r2) == 3 and len(r3) == 4, "unexpected CrossAttentionBlock residual bodies")
-        x = self.self_attention(x, B, r1[0], r1[1])
-        x = self.cross_attention(x, B, r2[0], r2[1], r2[2], ctx)
-        return self.feed_forward(x, r3[0], r3[1], r3[2], r3[3])
+        buf = self.row_stats(x.shape[0], x.shape[1])
+        x = self.self_attention(x, B, r1[0], r1[1], stats, buf)
+        x = self.cross_attention(x, B, r2[0], r2[1], r2[2], ctx, buf, buf)
+        return self.feed_forward(x, r3[0], r3[1], r3[2], r3[3], buf, None if last else buf)
 
     def cross_attention_2d(self, node: Any, a: Act, ctx: "UNetContext") -> Act:
         """CrossAttentionBlock2d (cross_attention.py:92-175).  Token-major layout makes flatten / transpose free."""
@@ -731,11 +846,13 @@ class Lowering:
         others = [m for m in head[1:] + tail if m is not proj_in and m is not proj_out]
         _expect(all(isa(m, "StatefulFlatten", "Transpose", "Parallel", "Unflatten") for m in others), "unexpected layers around the transformer")
         g = self.groupnorm(a, head[0], silu=False)
-        h = self.linear(g.t, self.linear_spec(proj_in))
+        pin = self.linear_spec(proj_in)
+        stats = self.row_stats(g.t.shape[0], pin.N)
+        h = self.linear(g.t, pin, stats_out=stats)
         self.pool.put(g.t)
-        for blk in blocks:
+        for i, blk in enumerate(blocks):
             _expect(isa(blk, "CrossAttentionBlock"), f"unexpected {cname(blk)} among transformer layers")
-            h = self.cross_attention_block(blk, h, a.B, ctx)
+            h = self.cross_attention_block(blk, h, a.B, ctx, stats, last=i == len(blocks) - 1)
         out = self.linear(h, self.linear_spec(proj_out), res=a.t)
         self.pool.put(h)
         return Act(out, a.B, a.H, a.W)

@@ -1,0 +1,41 @@
+"""Measured tile choices for mi355x_gemm on MI355X (gfx950).
+
+The library's own heuristic only knows the output size; which tile / LDS depth wins also depends on K, on whether the
+launch's weights arrive cold, and on what the neighbouring launches leave in the caches.  `tools/autotune.py` therefore
+measures every candidate IN PLACE (the whole recorded SDXL step replayed with one shape class switched at a time) on the
+GPU and writes `tuning_gfx950.json`: {signature: [tile, stages]} (signature = native.gemm_signature).  Shapes the table
+does not know fall back to the heuristic in gemm_kernel.cuh (pick_tile / pick_stages).  Set REFINERS_AMD_TUNING=0 to
+ignore the table (A/B runs, and the tuner itself)."""
+from __future__ import annotations
+
+import json
+import os
+from pathlib import Path
+from typing import Optional
+
+TABLE_PATH = Path(__file__).resolve().parent / "tuning_gfx950.json"
+_table: Optional[dict] = None
+enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
+
+
+def table() -> dict:
+    global _table
+    if _table is None:
+        try:
+            _table = {k: tuple(v) for k, v in json.loads(TABLE_PATH.read_text())["choices"].items()}
+        except (OSError, ValueError, KeyError):
+            _table = {}
+    return _table
+
+
+def lookup(signature: str, stages: int = 0) -> tuple[int, int]:
+    """(tile, stages) for a launch whose caller did not choose: the table's entry, else (0, stages) = library heuristic."""
+    if enabled:
+        got = table().get(signature)
+        if got is not None:
+            return int(got[0]), int(got[1])
+    return 0, stages
+
+
+def summary() -> dict:
+    return {"table": TABLE_PATH.name if table() else None, "entries": len(table()), "enabled": enabled}

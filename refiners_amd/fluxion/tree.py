@@ -107,7 +107,15 @@ class Module(nn.Module):
         self.load_state_dict(load_file(str(tensors_path)), strict=strict)
         return self
 
+    def load_state_dict(self, *args: Any, **kwargs: Any) -> Any:  # type: ignore[override]
+        # weights may be replaced (assign=True swaps the Parameter objects) or rewritten in place: either way every program
+        # lowered from a tree that contains this module holds stale converted / merged / K-blocked copies
+        out = super().load_state_dict(*args, **kwargs)
+        bump_epoch()
+        return out
+
     def to(self: T, device: Any = None, dtype: Any = None) -> T:  # type: ignore[override]
+        bump_epoch()  # parameters move / change dtype
         return super().to(device=device, dtype=dtype)  # type: ignore[return-value]
 
     # -- printing ------------------------------------------------------------------------------------------

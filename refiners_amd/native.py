@@ -121,6 +121,16 @@ class GemmArgs(C.Structure):
         ("prefetch_bytes", C.c_int64 * MAX_PREFETCH),
         ("prefetch_blocks", C.c_int32),
         ("out_kblocked", C.c_int32),
+        ("stages", C.c_int32),
+        ("nt_begin", C.c_int32),
+        ("out_t", C.c_void_p),
+        ("ldt", C.c_int64),
+        ("ln_stats", C.c_void_p),
+        ("ln_parts", C.c_int32),
+        ("ln_eps", C.c_float),
+        ("ln_s", C.c_void_p),
+        ("ln_c", C.c_void_p),
+        ("stats_out", C.c_void_p),
     ]
 
 
@@ -284,7 +294,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_relpos_pack.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
-    if lib.mi355x_abi_version() != 2:
+    if lib.mi355x_abi_version() != 3:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
     return lib
@@ -490,7 +500,7 @@ def _seg_plain(x: Any, w: Any) -> tuple:
 
 def gemm(
     segs: Sequence[tuple[Tensor, Tensor]],
-    out: Tensor,
+    out: Optional[Tensor],
     *,
     bias: Optional[Tensor] = None,
     rowbias: Optional[Tensor] = None,
@@ -501,14 +511,22 @@ def gemm(
     M: Optional[int] = None,
     N: Optional[int] = None,
     tile: int = 0,
+    stages: int = 0,
     ksplit: int = 1,
     ws: Optional[Tensor] = None,
     prefetch: Optional[Tensor] = None,
     weight_operand: str = "w",
     out_kblocked: bool = False,
-) -> Tensor:
+    out_t: Optional[Tensor] = None,
+    nt_begin: int = 0,
+    ln: Optional[tuple[Tensor, Tensor, Tensor, float]] = None,
+    stats_out: Optional[Tensor] = None,
+) -> Optional[Tensor]:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
-    weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch."""
+    weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch.
+    out_t / nt_begin: columns >= nt_begin are written transposed, out_t[n - nt_begin][m] (`out` then has nt_begin columns).
+    ln = (stats [parts, M, 2] float32, s [N] float32, c [N] float32, eps): LayerNorm of x folded into this launch (see the header);
+    stats_out [N / 32, M, 2] float32: per-row (mean, M2) of every 32-column chunk of the stored output."""
     a = GemmArgs()
     a.weight_is_x = weight_operand == "x"
     a.out_kblocked = int(out_kblocked)
@@ -528,9 +546,28 @@ def gemm(
         sg.ksize, sg.stride, sg.ups, sg.H, sg.W, sg.kblocked = 1, 1, 1, 0, 0, t[5]
         keep.append((x, w))
     assert not (geglu and gelu)
-    _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, (3 if gelu == "quick" else 2) if gelu else geglu)
-    _fill_split(a, tile, ksplit, ws)
-    _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm")
+    if out_t is not None:
+        assert out_t.dim() == 2 and out_t.stride(1) == 1 and out_t.shape[0] >= a.N - nt_begin and out_t.shape[1] >= a.M
+        a.out_t, a.ldt, a.nt_begin = out_t.data_ptr(), out_t.stride(0), nt_begin
+    if out is None:
+        assert out_t is not None and nt_begin == 0
+        a.out, a.ldo = None, 0
+        a.bias = bias.data_ptr() if bias is not None else None
+        a.rowbias, a.ld_rowbias, a.rows_per_group, a.res, a.ldres, a.geglu = None, 0, 1, None, 0, 0
+    else:
+        _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, (3 if gelu == "quick" else 2) if gelu else geglu)
+    if ln is not None:
+        stats, ls, lc, eps = ln
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 3 and stats.shape[1] == a.M and stats.shape[2] == 2
+        assert ls.dtype == torch.float32 and lc.dtype == torch.float32 and ls.numel() == a.N and lc.numel() == a.N and bias is None
+        a.ln_stats, a.ln_parts, a.ln_eps, a.ln_s, a.ln_c = stats.data_ptr(), stats.shape[0], eps, ls.data_ptr(), lc.data_ptr()
+        keep.append(ln)
+    if stats_out is not None:
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= (a.N // 32) * a.M * 2 and a.N % 64 == 0
+        a.stats_out = stats_out.data_ptr()
+        keep.append(stats_out)
+    _fill_split(a, tile, ksplit, ws, stages)
+    _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm", keep=tuple(keep))
     return out
 
 
@@ -548,6 +585,7 @@ def conv_gemm(
     tile: int = 0,
     ksplit: int = 1,
     ws: Optional[Tensor] = None,
+    stages: int = 0,
 ) -> Tensor:
     """Implicit-GEMM convolution over NHWC images.
 
@@ -575,7 +613,7 @@ def conv_gemm(
         sg.kblocked = 1 if isinstance(w, KBlocked) else 0
     a.zeros = zero_page(img0.device).data_ptr()
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, False)
-    _fill_split(a, tile, ksplit, ws)
+    _fill_split(a, tile, ksplit, ws, stages)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm(conv)")
     return out
 
@@ -625,8 +663,19 @@ def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 1
     return {"linked": linked, "bytes": nbytes_total, "launches": len(gemms)}
 
 
-def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor]) -> None:
-    a.tile, a.ksplit = tile, ksplit
+def gemm_signature(a: GemmArgs) -> str:
+    """Shape class of a GEMM / conv launch: the key of the measured tile table (refiners_amd/engine/tuning.py)."""
+    k = sum(int(a.seg[s].k) * (int(a.seg[s].ksize) ** 2 if a.conv else 1) for s in range(a.nseg))
+    flags = ("geglu" if a.geglu == 1 else "") + ("T%d" % a.nt_begin if a.out_t else "") + ("ln" if a.ln_stats else "") + ("st" if a.stats_out else "")
+    return f"{'conv' if a.conv else 'gemm'}:{'f32' if a.dtype == 0 else 'bf16'}:{a.M}x{a.N}x{k}:s{a.nseg}:{flags}"
+
+
+def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor], stages: int = 0) -> None:
+    if tile == 0 and ksplit <= 1:  # no explicit choice: the measured table of this GPU, if it knows the shape
+        from .engine import tuning
+
+        tile, stages = tuning.lookup(gemm_signature(a), stages)
+    a.tile, a.ksplit, a.stages = tile, ksplit, stages
     if ksplit > 1:
         assert ws is not None and ws.is_contiguous(), "split-K needs a scratch tensor of ksplit * M * N float32"
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()

@@ -34,49 +34,55 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local
 
 
-def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int = 512 << 20) -> int:
-    """In-place broadcast of many tensors through few large flat buckets (same dtype and device per bucket).
-    Returns the number of collective launches."""
+def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int = 512 << 20, align: int = 256) -> int:
+    """In-place broadcast of many tensors through ONE flat arena per (dtype, device), sent in large bucket-sized pieces.
+
+    No staging copies on the receivers: every tensor's storage is RE-POINTED into the arena (`t.data = arena[off : off + n]`,
+    256-byte aligned so the kernels' 16-byte vector loads stay legal) and RCCL writes straight into it; only the source
+    rank pays one copy-in pass.  The arena stays the weights' home afterwards (one allocation instead of thousands, which is
+    also what a packed / direct-to-GPU checkpoint load wants).  Each `dist.broadcast` moves up to `bucket_bytes`; RCCL
+    pipelines a large message over all its channels / xGMI links by itself, so fewer, larger messages are the lever here
+    (SURVEY.md section 8(e)).  Returns the number of collective launches."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
+    rank = dist.get_rank()
     groups: dict[tuple[torch.dtype, torch.device], list[Tensor]] = {}
     for t in tensors:
         groups.setdefault((t.dtype, t.device), []).append(t)
     launches = 0
     for (dtype, device), items in groups.items():
-        bucket: list[Tensor] = []
-        size = 0
-
-        def flush() -> None:
-            nonlocal bucket, size, launches
-            if not bucket:
-                return
-            flat = torch.cat([b.detach().reshape(-1) for b in bucket])
-            dist.broadcast(flat, src=src)
-            launches += 1
-            off = 0
-            for b in bucket:
-                n = b.numel()
-                b.detach().copy_(flat[off : off + n].view_as(b))
-                off += n
-            bucket, size = [], 0
-
+        es = items[0].element_size()
+        step = max(align // es, 1)
+        offs, total = [], 0
         for t in items:
-            nbytes = t.numel() * t.element_size()
-            if size and size + nbytes > bucket_bytes:
-                flush()
-            bucket.append(t)
-            size += nbytes
-        flush()
+            offs.append(total)
+            total += (t.numel() + step - 1) // step * step
+        arena = torch.empty(total, dtype=dtype, device=device)
+        for t, off in zip(items, offs):
+            view = arena[off : off + t.numel()].view(t.shape)
+            if rank == src:
+                view.copy_(t.detach())
+            t.data = view  # the parameter now lives in the arena (no copy-back after the collective)
+        per = max(bucket_bytes // es, 1)
+        for lo in range(0, total, per):
+            dist.broadcast(arena[lo : min(lo + per, total)], src=src)
+            launches += 1
     return launches
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 512 << 20) -> int:
-    """Broadcast every parameter and buffer of a (possibly adapted) Chain tree from `src`."""
+    """Broadcast every parameter and buffer of a (possibly adapted) Chain tree from `src`.  Programs lowered from the tree
+    before the call are invalidated (the weights moved into the broadcast arena)."""
     seen: dict[int, Tensor] = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        seen.setdefault(id(t), t)
-    return broadcast_tensors(seen.values(), src=src, bucket_bytes=bucket_bytes)
+        if t.device.type != "meta":
+            seen.setdefault(id(t), t)
+    n = broadcast_tensors(seen.values(), src=src, bucket_bytes=bucket_bytes)
+    if n:
+        from .fluxion.tree import bump_epoch
+
+        bump_epoch()
+    return n
 
 
 def shard_range(n_items: int, rank: int, world: int) -> range:

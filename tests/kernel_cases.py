@@ -485,6 +485,121 @@ def sinusoidal_case(n, dim, group, dtype, seed=130):
     return (out[:, col0 : col0 + group * dim].float() - ref).abs().max().item(), 1.0, (2e-4 if dtype == torch.float32 else 8e-3)
 
 
+# ------------------------------------------------------------------------------------------------ round-2 kernel features
+def gemm_tile_case(M, K, N, dtype, tile, stages, *, res=True, prefetch=False, seed=200):
+    """A forced (tile, LDS depth) pair, incl. tile 6 = 8 waves in two K groups: every configuration the tuner may pick."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2)
+    r = _rand(M, N, dtype=dtype, seed=seed + 3) if res else None
+    pf = _rand(1 << 20, dtype=dtype, seed=seed + 4) if prefetch else None
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, native.KBlocked(w))], out, bias=b, res=r, tile=tile, stages=stages, prefetch=pf)
+    out2 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, native.KBlocked(w))], out2, bias=b, res=r, tile=tile, stages=stages, prefetch=pf)
+    assert torch.equal(out, out2), "forced tile must be bit-reproducible"
+    ref = x.float() @ w.float().t() + b.float() + (r.float() if res else 0)
+    return _cmp(out, ref, dtype)
+
+
+def gemm_kgroups_multiseg_case(M, K1, K2, N, dtype, seed=210):
+    """Two K groups over TWO segments with an odd total block count (the odd group idles through the last trip)."""
+    x1, x2 = _rand(M, K1, dtype=dtype, seed=seed), _rand(M, K2, dtype=dtype, seed=seed + 1)
+    w1, w2 = _rand(N, K1, dtype=dtype, seed=seed + 2, scale=(K1 + K2) ** -0.5), _rand(N, K2, dtype=dtype, seed=seed + 3, scale=(K1 + K2) ** -0.5)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x1, w1), (x2, native.KBlocked(w2))], out, tile=6)
+    ref = x1.float() @ w1.float().t() + x2.float() @ w2.float().t()
+    return _cmp(out, ref, dtype)
+
+
+def conv_tile_case(B, Cin, Cout, H, W, dtype, tile, stages, ksplit=1, seed=220):
+    x = _rand(B, H, W, Cin, dtype=dtype, seed=seed)
+    w4 = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=(9 * Cin) ** -0.5)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2)
+    out = torch.full((B * H * W, Cout), float("nan"), dtype=dtype, device=DEV)
+    ws = torch.empty(ksplit * B * H * W * Cout, dtype=torch.float32, device=DEV) if ksplit > 1 else None
+    native.conv_gemm([(x, native.KBlocked(native.pack_conv_weight(w4)), 3, 1, 1)], out, B, H, W, bias=b, tile=tile, stages=stages, ksplit=ksplit, ws=ws)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w4.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    return _cmp(out, ref, dtype)
+
+
+def gemm_qkv_case(M, K, Cc, dtype, tile=0, bias=False, seed=230):
+    """One launch over [Wq; Wk; Wv]: Q | K row-major into `out`, V transposed into `out_t` (transposed column group)."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(3 * Cc, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(3 * Cc, dtype=dtype, seed=seed + 2) if bias else None
+    qk = torch.full((M, 2 * Cc), float("nan"), dtype=dtype, device=DEV)
+    vt = torch.full((Cc, M), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, native.KBlocked(w))], qk, bias=b, out_t=vt, nt_begin=2 * Cc, tile=tile)
+    ref = x.float() @ w.float().t() + (b.float() if bias else 0)
+    e1 = _cmp(qk, ref[:, : 2 * Cc], dtype)
+    e2 = _cmp(vt, ref[:, 2 * Cc :].t(), dtype)
+    return max(e1[0], e2[0]), max(e1[1], e2[1]), e1[2]
+
+
+def gemm_t_only_case(M, K, Cc, dtype, tile=0, seed=235):
+    """nt_begin = 0: the whole output transposed (out = NULL), ragged M (scalar row tail) and a column count below one tile."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(Cc, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    ldt = (M + 7) // 8 * 8
+    vt = torch.full((Cc, ldt), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, w)], None, out_t=vt, nt_begin=0, tile=tile)
+    return _cmp(vt[:, :M], (x.float() @ w.float().t()).t(), dtype)
+
+
+def _stats_ref(y: torch.Tensor) -> torch.Tensor:
+    """[N / 32][M][2] (mean, M2) of consecutive 32-column chunks, float64 -> float32."""
+    M, N = y.shape
+    c = y.double().view(M, N // 32, 32)
+    mean = c.mean(-1)
+    m2 = ((c - mean.unsqueeze(-1)) ** 2).sum(-1)
+    return torch.stack([mean, m2], -1).permute(1, 0, 2).float().contiguous()
+
+
+def gemm_ln_chain_case(M, Cc, N2, dtype, *, geglu=False, tile1=0, tile2=0, transposed=False, seed=240):
+    """Producer GEMM (+ residual) writes its rows' statistics; the consumer applies LayerNorm + Linear in one launch.
+    Reference: torch layer_norm of the STORED producer output, then the Linear (+ GEGLU / transposed store)."""
+    x = _rand(M, Cc, dtype=dtype, seed=seed)
+    w1 = _rand(Cc, Cc, dtype=dtype, seed=seed + 1, scale=Cc ** -0.5)
+    b1 = _rand(Cc, dtype=dtype, seed=seed + 2)
+    r = _rand(M, Cc, dtype=dtype, seed=seed + 3) + 3.0  # a non-zero row mean: exercises the mean * s cancellation
+    gamma = (1 + 0.2 * _rand(Cc, dtype=torch.float32, seed=seed + 4)).float()
+    beta = (0.3 * _rand(Cc, dtype=torch.float32, seed=seed + 5)).float()
+    w2 = _rand(N2, Cc, dtype=dtype, seed=seed + 6, scale=Cc ** -0.5)
+    b2 = _rand(N2, dtype=dtype, seed=seed + 7)
+    y = torch.full((M, Cc), float("nan"), dtype=dtype, device=DEV)
+    stats = torch.full((Cc // 32, M, 2), float("nan"), dtype=torch.float32, device=DEV)
+    native.gemm([(x, w1)], y, bias=b1, res=r, stats_out=stats, tile=tile1)
+    yref = x.float() @ w1.float().t() + b1.float() + r.float()
+    e0 = _cmp(y, yref, dtype)
+    sref = _stats_ref(y.float())
+    es = (stats - sref).abs().max().item() / max(sref.abs().max().item(), 1e-6)
+    assert es < 2e-5, f"row statistics off by {es:.2e}"
+    eps = 1e-5
+    h = torch.nn.functional.layer_norm(y.float(), (Cc,), gamma, beta, eps)
+    wsrc, bsrc = w2, b2
+    if geglu:
+        idx = native.geglu_pack_index(N2 // 2, device=DEV)
+        wsrc, bsrc = w2[idx].contiguous(), b2[idx].contiguous()
+    wl = (wsrc.float() * gamma.unsqueeze(0)).to(dtype).contiguous()
+    ls = wl.float().sum(1).contiguous()
+    lc = (wsrc.float() @ beta + bsrc.float()).contiguous()
+    full = h @ w2.float().t() + b2.float()
+    if transposed:
+        out_t = torch.full((N2, M), float("nan"), dtype=dtype, device=DEV)
+        native.gemm([(y, wl)], None, out_t=out_t, nt_begin=0, ln=(stats, ls, lc, eps), tile=tile2)
+        e1 = _cmp(out_t, full.t(), dtype)
+    elif geglu:
+        out = torch.full((M, N2 // 2), float("nan"), dtype=dtype, device=DEV)
+        native.gemm([(y, native.KBlocked(wl))], out, geglu=True, ln=(stats, ls, lc, eps), tile=tile2)
+        e1 = _cmp(out, full[:, : N2 // 2] * torch.nn.functional.gelu(full[:, N2 // 2 :]), dtype)
+    else:
+        out = torch.full((M, N2), float("nan"), dtype=dtype, device=DEV)
+        native.gemm([(y, native.KBlocked(wl))], out, ln=(stats, ls, lc, eps), tile=tile2)
+        e1 = _cmp(out, full, dtype)
+    return max(e0[0], e1[0]), max(e0[1], e1[1]), e1[2] * (2.0 if dtype == torch.bfloat16 else 1.0)
+
+
 def all_cases():
     """(name, thunk) list; sizes chosen so the whole list runs in well under a minute on one MI355X."""
     cases = []
@@ -556,5 +671,31 @@ def all_cases():
             (f"patchify_gather_{tag}", lambda dt=dt: patchify_gather_case(dt)),
             (f"sinusoidal_{tag}_timestep", lambda dt=dt: sinusoidal_case(2, 320, 1, dt)),
             (f"sinusoidal_{tag}_time_ids", lambda dt=dt: sinusoidal_case(12, 256, 6, dt)),
+        ]
+        for tile in (1, 2, 3, 4, 5, 6):
+            for st in ((2,) if tile == 6 else (2, 3) if tile == 5 else (2, 3, 4)):
+                cases.append((f"gemm_{tag}_tile{tile}_s{st}_300x1472x328", lambda dt=dt, tile=tile, st=st: gemm_tile_case(300, 1472, 328, dt, tile, st)))
+        cases += [
+            (f"gemm_{tag}_tile6_2048x1280x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 1280, dt, 6, 2, prefetch=True)),
+            (f"gemm_{tag}_tile6_oneblock", lambda dt=dt: gemm_tile_case(200, 128 // (4 if dt == torch.float32 else 2), 136, dt, 6, 2)),
+            (f"gemm_{tag}_tile1_s4_short_k", lambda dt=dt: gemm_tile_case(256, 2 * 128 // (4 if dt == torch.float32 else 2), 256, dt, 1, 4)),
+            (f"gemm_{tag}_tile6_two_segments_odd", lambda dt=dt: gemm_kgroups_multiseg_case(300, 640, 320 + 64, 200, dt)),
+            (f"conv_{tag}_tile6", lambda dt=dt: conv_tile_case(2, 320, 320, 16, 16, dt, 6, 2)),
+            (f"conv_{tag}_tile6_splitk2", lambda dt=dt: conv_tile_case(1, 640, 256, 16, 16, dt, 6, 2, ksplit=2)),
+            (f"conv_{tag}_tile1_s3", lambda dt=dt: conv_tile_case(2, 320, 384, 16, 24, dt, 1, 3)),
+            (f"conv_{tag}_tile5_s3", lambda dt=dt: conv_tile_case(2, 320, 320, 32, 32, dt, 5, 3)),
+            (f"gemm_{tag}_qkv_2048x1280", lambda dt=dt: gemm_qkv_case(2048, 1280, 1280, dt)),
+            (f"gemm_{tag}_qkv_1000x640_bias_tile4", lambda dt=dt: gemm_qkv_case(1000, 640, 640, dt, tile=4, bias=True)),
+            (f"gemm_{tag}_qkv_tile6", lambda dt=dt: gemm_qkv_case(512, 640, 384, dt, tile=6)),
+            (f"gemm_{tag}_qkv_tile5", lambda dt=dt: gemm_qkv_case(520, 640, 256, dt, tile=5)),
+            (f"gemm_{tag}_t_only_ragged", lambda dt=dt: gemm_t_only_case(77 * 2, 2048, 640, dt)),
+            (f"gemm_{tag}_t_only_tile2_small_n", lambda dt=dt: gemm_t_only_case(300, 640, 72, dt, tile=2)),
+            (f"gemm_{tag}_ln_chain_2048x1280", lambda dt=dt: gemm_ln_chain_case(2048, 1280, 1280, dt)),
+            (f"gemm_{tag}_ln_chain_geglu", lambda dt=dt: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True)),
+            (f"gemm_{tag}_ln_chain_tiles_4_6", lambda dt=dt: gemm_ln_chain_case(1000, 640, 640, dt, tile1=4, tile2=6)),
+            (f"gemm_{tag}_ln_chain_tiles_6_2", lambda dt=dt: gemm_ln_chain_case(300, 320, 384, dt, tile1=6, tile2=2)),
+            (f"gemm_{tag}_ln_chain_tiles_5_3", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=5, tile2=3)),
+            (f"gemm_{tag}_ln_chain_tiles_2_5", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=2, tile2=5)),
+            (f"gemm_{tag}_ln_chain_transposed", lambda dt=dt: gemm_ln_chain_case(1024, 1280, 1280, dt, transposed=True)),
         ]
     return cases

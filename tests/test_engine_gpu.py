@@ -182,7 +182,7 @@ def test_merged_lora_mode_matches_reference(case):
     print(f"{case} f32 merged: l2 {l2:.2e} max {mx:.2e} ops {fast.stats['step_ops']}")
     assert l2 < F32_TOL and mx < F32_TOL, (case, l2, mx)
     if case == "sdxl_lora_ip":
-        assert fast.stats["step_ops"] == 981  # no launch added by 1 444 LoRA chains + 70 image cross-attentions
+        assert fast.stats["step_ops"] <= 981  # no launch added by 1 444 LoRA chains + 70 image cross-attentions (981 = the bare step before LN / QKV fusion)
         for a in handles["loras"]:
             a.loras["l1"].scale = 0.0
             a.loras["l2"].scale = 0.0
@@ -522,3 +522,182 @@ def test_t2i_adapter_matches_reference():
     bare = fast(torch.cat((inp["x"], inp["x"])))
     l2, mx = S.rel_err(y0, bare)
     assert mx < 1e-5, (l2, mx)
+
+
+# ------------------------------------------------------------------------------------------------ round 2: parity holes closed
+@pytest.mark.parametrize("case", ["sdxl_lora_ip", "sdxl_control"])
+def test_merged_lora_mode_bfloat16(case):
+    """bf16 + lora_mode="merged" -- the configuration bench.py times for configs[2] / [3] -- against the float32 golden of
+    the real reference, with the same bar as the run-time LoRA mode: norm-wise <= 3e-2 and not worse than stock torch
+    bf16 kernels on the unfused tree.  W' = bf16(W + sum s B A) rounds each adapted weight once more; the direct check
+    below measures how much of the LoRA delta survives that rounding."""
+    cfg, unet, specs, handles, inp = build(case, torch.bfloat16)
+    fast = CompiledUNet(unet, lora_mode="merged")
+    set_context(unet, cfg, inp, torch.bfloat16)
+    y = fast(torch.cat((inp["x"], inp["x"])).to(torch.bfloat16))
+    gold = S.golden(case)["unet_out"]
+    l2, mx = S.rel_err(y.float(), gold)
+    set_context(unet, cfg, inp, torch.bfloat16)
+    y_t = unet(torch.cat((inp["x"], inp["x"])).to(torch.bfloat16))
+    l2_t, _ = S.rel_err(y_t.float(), gold)
+    fused = CompiledUNet(unet, lora_mode="fused")
+    set_context(unet, cfg, inp, torch.bfloat16)
+    y_f = fused(torch.cat((inp["x"], inp["x"])).to(torch.bfloat16))
+    l2_f, _ = S.rel_err(y_f.float(), gold)
+    print(f"{case} bf16 merged: l2 {l2:.2e} max {mx:.2e}; fused l2 {l2_f:.2e}; torch-bf16 unfused l2 {l2_t:.2e}; ops {fast.stats['step_ops']} / {fused.stats['step_ops']}")
+    assert l2 < BF16_TOL, (case, l2, mx)
+    assert l2 < 1.15 * l2_t + 1e-3, "merged bf16 must not be less accurate than the unfused bf16 path"
+
+
+def test_merged_weights_keep_the_lora_delta():
+    """Direct check on the merged copies: bf16(W + s B A) - bf16(W) must reproduce s B A, not round it away (a delta below
+    half an ulp of W would vanish).  Reported as ||(W' - W) - D|| / ||D|| over the adapted Linears of one transformer block."""
+    cfg, unet, specs, handles, inp = build("sdxl_lora_ip", torch.bfloat16)
+    worst, n = 0.0, 0
+    for ad in handles["loras"][:40]:
+        w = ad.target.weight.detach().float()
+        delta = torch.zeros_like(w)
+        for lr in ad.loras.values():
+            delta += float(lr.scale) * (lr.up.weight.detach().float() @ lr.down.weight.detach().float())
+        merged = (w + delta).to(torch.bfloat16).float()
+        lost = float(((merged - w) - delta).norm() / delta.norm())
+        assert float((merged - w).abs().max()) > 0, "the LoRA delta vanished in the bf16 merge"
+        worst, n = max(worst, lost), n + 1
+    print(f"merged-weight delta survival over {n} sites: worst relative loss {worst:.3e}")
+    assert worst < 0.1, worst
+
+
+@pytest.fixture(scope="module")
+def full_size_lora_ip_oracle():
+    """BASELINE configs[2] at its benchmarked geometry (128x128 latents, CFG pair): one CPU-oracle step, shared by the tests below."""
+    from oracle import unet_oracle as O
+
+    shapes = S.key_shapes("sdxl")
+    specs = {"loras": [S.synth.lora_spec(shapes, "l1", 1.0, seed=5), S.synth.lora_spec(shapes, "l2", 0.8, seed=5)],
+             "ip": S.synth.ip_spec(shapes, 0.6, batch=2, seed=5), "control": []}
+    inp = S.synth.sdxl_inputs(1, (128, 128), seed=8)
+    ref = O.sdxl_cfg_step(S.weights("sdxl", 0), inp["x"], 7, 50, inp["text"], inp["pooled"], inp["time_ids"], condition_scale=5.0,
+                          loras=specs["loras"], ip=specs["ip"])
+    return specs, inp, ref
+
+
+@pytest.mark.parametrize("mode", ["merged", "fused"])
+def test_full_size_lora_ip_step_matches_oracle(mode, full_size_lora_ip_oracle):
+    """configs[2] (2 LoRAs x 722 Linears + IP-Adapter) at 128x128 latents, float32, both LoRA modes, vs the CPU oracle: the
+    tile choices, split-K and XCD regions of the benchmarked geometry are the ones exercised here."""
+    specs, inp, ref = full_size_lora_ip_oracle
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", 0), device="cuda", dtype=torch.float32)
+    S.synth.apply_adapters(unet, refiners_amd.namespace(), device="cuda", dtype=torch.float32, **specs)
+    sd = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, lora_mode=mode)
+    sd.set_inputs(inp["x"].cuda(), clip_text_embedding=inp["text"].cuda(), pooled_text_embedding=inp["pooled"].cuda(), time_ids=inp["time_ids"].cuda(),
+                  clip_image_embedding=specs["ip"]["tokens"].cuda())
+    x1 = sd.step(7).clone()
+    l2, mx = S.rel_err(x1, ref)
+    print(f"full-size lora_ip f32 {mode}: l2 {l2:.2e} max {mx:.2e} ops {sd.engine.stats['step_ops']}")
+    assert l2 < F32_TOL and mx < F32_TOL, (mode, l2, mx)
+
+
+def test_full_size_control_batch_of_four():
+    """configs[3]'s per-GPU shape: ControlLora (canny), 4 images per GPU -> UNet batch 8 at 128x128 latents, float32.
+    (a) against the mirror's unfused Chain forward (the reference's ATen path) on the same GPU for the whole batch,
+    (b) batch invariance (reference tests/e2e/test_diffusion.py:1539-1597): image 0 of the batch == the same image alone,
+    (c) that single image against the CPU oracle."""
+    from oracle import unet_oracle as O
+    from refiners_amd.latent_diffusion.sampling import SDXLDenoiser
+
+    n = 4
+    ctl = S.synth.control_spec("canny", 0.9, 2 * n, (128, 128), seed=6)
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", 0), device="cuda", dtype=torch.float32)
+    S.synth.apply_adapters(unet, refiners_amd.namespace(), device="cuda", dtype=torch.float32, loras=[], ip=None, control=[ctl])
+    inp = {k: v.cuda() for k, v in S.synth.sdxl_inputs(n, (128, 128), seed=9).items()}
+    sd = CompiledSDXL(unet, num_inference_steps=30, condition_scale=7.5)
+    sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], conditions={"canny": ctl["condition"].cuda()})
+    x4 = sd.step(12).clone()
+    assert sd.engine.stats["fallback_nodes"] == []
+    ref = SDXLDenoiser(unet, DDIM(30, device="cuda"))
+    with torch.no_grad():
+        xr = ref(inp["x"], 12, clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], condition_scale=7.5)
+    l2, mx = S.rel_err(x4, xr)
+    print(f"full-size control x4 f32 vs unfused mirror: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    pick = torch.tensor([0, n], device="cuda")  # [neg_0 .. neg_3, cond_0 .. cond_3] -> [neg_0, cond_0]
+    one = S.synth.control_spec("canny", 0.9, 2, (128, 128), seed=6)
+    one["condition"] = ctl["condition"][pick.cpu()]
+    sd1 = CompiledSDXL(unet, num_inference_steps=30, condition_scale=7.5)
+    sd1.set_inputs(inp["x"][:1], clip_text_embedding=inp["text"][pick], pooled_text_embedding=inp["pooled"][pick], time_ids=inp["time_ids"][pick],
+                   conditions={"canny": one["condition"].cuda()})
+    x1 = sd1.step(12).clone()
+    l2, mx = S.rel_err(x1, x4[:1])
+    print(f"full-size control batch invariance: l2 {l2:.2e} max {mx:.2e}")
+    assert mx < 5e-3, (l2, mx)
+    cpu = {k: v.cpu() for k, v in inp.items()}
+    refo = O.sdxl_cfg_step(S.weights("sdxl", 0), cpu["x"][:1], 12, 30, cpu["text"][pick.cpu()], cpu["pooled"][pick.cpu()], cpu["time_ids"][pick.cpu()], condition_scale=7.5,
+                           control=[one])
+    l2, mx = S.rel_err(x1, refo)
+    print(f"full-size control single image vs oracle: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+
+
+def test_two_trajectories_through_one_graph_multistep_solver():
+    """Regression: DPM-Solver++'s history buffer must live as long as the captured graph.  Two prompts sampled
+    back to back through ONE CompiledSDXL with the graph on must equal the same prompts sampled by fresh graph-less engines."""
+    from refiners_amd.latent_diffusion.solvers import DPMSolver
+
+    cfg, unet, specs, handles, inp = build("sdxl_bare", torch.float32)
+    steps = 6
+    a = {k: v.cuda() for k, v in S.synth.sdxl_inputs(1, (32, 32), seed=31).items()}
+    b = {k: v.cuda() for k, v in S.synth.sdxl_inputs(1, (32, 32), seed=32).items()}
+    sd = CompiledSDXL(unet, condition_scale=5.0, solver=DPMSolver(steps), use_graph=True)
+    outs = []
+    for inp_ in (a, b, a):
+        sd.set_inputs(inp_["x"], clip_text_embedding=inp_["text"], pooled_text_embedding=inp_["pooled"], time_ids=inp_["time_ids"])
+        junk = torch.full((64, 4, 32, 32), float("nan"), device="cuda")  # whatever the allocator hands out next must not be the history
+        outs.append(sd.sample().clone())
+        del junk
+    for inp_, got in zip((a, b), outs):
+        ref = CompiledSDXL(unet, condition_scale=5.0, solver=DPMSolver(steps), use_graph=False)
+        ref.set_inputs(inp_["x"], clip_text_embedding=inp_["text"], pooled_text_embedding=inp_["pooled"], time_ids=inp_["time_ids"])
+        assert torch.equal(got, ref.sample()), "graph replay of a multistep solver diverged from direct replay"
+    assert torch.equal(outs[0], outs[2])
+
+
+def test_new_prompt_tensor_at_a_recycled_address_reruns_the_prologue():
+    """Regression: prompt-side inputs are identified by a key that used to survive the tensor; a new embedding
+    allocated at the same address must not be mistaken for the old one."""
+    cfg, unet, specs, handles, inp = build("sdxl_bare", torch.float32)
+    fast = CompiledUNet(unet)
+    xx = torch.cat((inp["x"], inp["x"]))
+    outs = []
+    for seed in (41, 42):
+        text = torch.randn((2, 77, 2048), generator=S.synth._gen("t", seed)).cuda()
+        ptr = text.data_ptr()
+        unet.set_timestep(torch.tensor([500.0], device="cuda"))
+        unet.set_clip_text_embedding(text)
+        unet.set_pooled_text_embedding(inp["pooled"])
+        unet.set_time_ids(inp["time_ids"])
+        outs.append(fast(xx))
+        del text  # the context was reset by the call: nothing but the engine can keep the tensor alive
+    assert not torch.equal(outs[0], outs[1])
+    print("second prompt at", hex(ptr))
+
+
+def test_in_place_weight_update_invalidates_the_program():
+    """Regression: weights rewritten in place (load_state_dict without assign, broadcast, optimizer step) must
+    reach the converted / K-blocked copies."""
+    cfg, unet, specs, handles, inp = build("sdxl_bare", torch.float32)
+    fast = CompiledUNet(unet)
+    xx = torch.cat((inp["x"], inp["x"]))
+    set_context(unet, cfg, inp, torch.float32)
+    y0 = fast(xx)
+    lin = next(m for m in unet.modules() if type(m).__name__ == "Linear" and m.weight.shape == (1280, 1280))
+    with torch.no_grad():
+        lin.weight.mul_(0.5)
+    set_context(unet, cfg, inp, torch.float32)
+    y1 = fast(xx)
+    set_context(unet, cfg, inp, torch.float32)
+    y_ref = unet(xx)
+    assert not torch.equal(y0, y1)
+    l2, mx = S.rel_err(y1, y_ref)
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)

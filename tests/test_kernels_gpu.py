@@ -24,23 +24,6 @@ def test_kernel_parity(name):
     assert err <= tol * scale + 1e-7, f"{name}: max|err|={err:.3e} vs ref max {scale:.3e} (tol {tol:g} relative)"
 
 
-def test_register_staging_matches_glds():
-    """The register-staged loader (A/B switch) must produce bit-identical tiles to the global_load_lds loader."""
-    from refiners_amd import native
-
-    x = torch.randn(512, 640, device="cuda").bfloat16()
-    w = torch.randn(384, 640, device="cuda").bfloat16()
-    o1 = torch.empty(512, 384, device="cuda", dtype=torch.bfloat16)
-    o2 = torch.empty_like(o1)
-    native.gemm([(x, w)], o1)
-    native.set_glds(False)
-    try:
-        native.gemm([(x, w)], o2)
-    finally:
-        native.set_glds(True)
-    assert torch.equal(o1, o2)
-
-
 def test_bit_reproducible():
     """Two runs of the same launch are bit-identical (reference: test_sd15_unet.py:21-37 torch.equal contract)."""
     e1 = kernel_cases.attention_case(2, 4, 1024, 1024, torch.bfloat16)

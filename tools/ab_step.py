@@ -1,0 +1,73 @@
+"""A/B of the lowering switches on the SDXL step, one process, one set of weights: step time (HIP graph) per variant and the
+per-family replay of the last one.  Variants are given as name=ENV1:val,ENV2:val ...; flags read at lowering time
+(REFINERS_AMD_LN_FUSE, REFINERS_AMD_QKV_MERGE, REFINERS_AMD_TUNING, REFINERS_AMD_KBLOCK, REFINERS_AMD_WEIGHT_PREFETCH).
+
+    python tools/ab_step.py --workload lora_ip base=REFINERS_AMD_LN_FUSE:0,REFINERS_AMD_QKV_MERGE:0,REFINERS_AMD_TUNING:0 all=
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from refiners_amd import native  # noqa: E402
+from refiners_amd.engine import tuning  # noqa: E402
+from refiners_amd.engine.compiled import CompiledSDXL  # noqa: E402
+
+KEYS = ("REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="lora_ip")
+    ap.add_argument("--images", type=int, default=1)
+    ap.add_argument("--lora-mode", default="merged")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("variants", nargs="*")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    native.load()
+    unet, specs, bare_sd, pipe0, _ = bench.build_pipeline(args.workload, args.images, 0, dev, torch.bfloat16, args.lora_mode, use_graph=True, broadcast=False)
+    inputs, x0 = pipe0.inputs, pipe0.x.clone()
+    del pipe0
+    variants = [v.split("=", 1) for v in (args.variants or ["default="])]
+    pipes = {}
+    for name, envs in variants:
+        for k in KEYS:
+            os.environ.pop(k, None)
+        for kv in filter(None, envs.split(",")):
+            k, v = kv.split(":")
+            os.environ[k] = v
+        tuning.enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
+        tuning._table = None
+        p = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=True, lora_mode=args.lora_mode)
+        p.inputs, p.x = inputs, x0.clone()
+        p._tables(dev)
+        p.step(0)
+        p.step(1)
+        torch.cuda.synchronize()
+        pipes[name] = p
+        print(f"{name}: {p.engine.stats['step_ops']} launches/step, tuning {p.engine.stats.get('gemm_tuning')}", flush=True)
+    res = {n: [] for n in pipes}
+    for _ in range(args.rounds):  # interleaved rounds
+        for name, p in pipes.items():
+            res[name].append(bench.timed_steps(p, args.steps, 2, 1, dev) / args.steps * 1e3)
+    for name, vals in res.items():
+        print(f"{name:24s} ms/step: " + "  ".join(f"{v:.3f}" for v in vals) + f"   min {min(vals):.3f}", flush=True)
+    last = list(pipes)[-1]
+    roof = bench.family_roofline(pipes[last], args.workload, args.images, min(res[last]))
+    print(json.dumps({"variant": last, "ms_per_step": min(res[last]), "families": roof["families"], "step": roof["step"]}), flush=True)
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    (ROOT / "gpurun_out" / "ab_step.json").write_text(json.dumps({"ms": res, "families_of_last": roof["families"]}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
