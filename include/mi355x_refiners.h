@@ -151,6 +151,8 @@ typedef struct {
     /* Producer side: besides `out`, write per-row (mean, M2) of every 32-column chunk of the STORED (rounded) output row into
        stats_out[(n / 32) * M + m] (float32 pairs; N a multiple of 64, vectorisable epilogue, no geglu / ksplit / out_t). */
     void* stats_out;
+    int32_t out_f32;        /* 1 = `out` is float32 whatever `dtype` says (ldo in float elements; 16-byte aligned rows): raw scores for
+                               mi355x_softmax_rows.  Not combinable with geglu / stats_out / out_t / ksplit. */
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);
@@ -308,6 +310,13 @@ int mi355x_concat2(int32_t dtype, const void* a, int64_t lda, int32_t C1, const 
                    void* out, int64_t ldo, int64_t M, void* stream);
 /* out = alpha*a + beta*b elementwise over n elements (fl.Sum / Residual glue, ControlLora residual injection). */
 int mi355x_axpby(int32_t dtype, const void* a, float alpha, const void* b, float beta, void* out, int64_t n, void* stream);
+/* Row softmax for attention heads too wide for the flash kernels (the SDXL VAE's single 512-wide head over H*W tokens,
+ * src/refiners/foundationals/latent_diffusion/auto_encoder.py:108,175 -> fluxion/layers/attentions.py:388): with
+ *   S = Q K^T (mi355x_gemm, out_f32)  ->  P = mi355x_softmax_rows(S)  ->  O = P V (mi355x_gemm with V^T as the weight operand)
+ * out[m][j] = exp(scale * (s[m][j] - max_j s[m][j])) / sum_j ... for j < L, and exactly 0 for L <= j < Lp (the K padding of
+ * the second GEMM).  s: float32 rows of stride lds; out: `dtype` rows of stride ldo.  Bit-reproducible. */
+int mi355x_softmax_rows(int32_t dtype, const float* s, int64_t lds, void* out, int64_t ldo, int64_t M, int32_t L, int32_t Lp, float scale,
+                        void* stream);
 /* out = silu(x) over n elements. */
 int mi355x_silu(int32_t dtype, const void* x, void* out, int64_t n, void* stream);
 

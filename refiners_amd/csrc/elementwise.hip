@@ -214,6 +214,77 @@ __global__ __launch_bounds__(256) void pointwise_nchw_kernel(const T* __restrict
 
 }  // namespace
 
+// P[m][0..L) = softmax(scale * S[m][0..L)), P[m][L..Lp) = 0: one 256-thread workgroup per row, the row held in registers
+// (<= 64 values per thread, i.e. L <= 16384) or re-read from L2 in three passes beyond that.  S is float32 (mi355x_gemm with
+// out_f32): scores of a 512-wide head reach tens, which bf16 storage would quantise to steps of 0.06-0.12 before the exponential.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds, T* __restrict__ out, int64_t ldo, int L, int Lp, float c) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* row = s + (int64_t)blockIdx.x * lds;
+    T* orow = out + (int64_t)blockIdx.x * ldo;
+    auto block_max = [&](float v) {
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+        if (lane == 0) red[wid] = v;
+        __syncthreads();
+        v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        return v;
+    };
+    auto block_sum = [&](float v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wid] = v;
+        __syncthreads();
+        v = (red[0] + red[1]) + (red[2] + red[3]);  // fixed order: bit-reproducible
+        __syncthreads();
+        return v;
+    };
+    constexpr int VPT = 16;  // float4 vectors per thread on the register path
+    const bool vec = (lds % 4 == 0) && ((reinterpret_cast<uintptr_t>(s) & 15) == 0);
+    if (L <= 256 * 4 * VPT && vec) {
+        f32x4 v[VPT];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int col = (i * 256 + tid) * 4;
+            if (col + 4 <= L) v[i] = *reinterpret_cast<const f32x4*>(row + col);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = col + e < L ? row[col + e] : -3.0e38f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, v[i][e]);
+        }
+        mx = block_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = (i * 256 + tid) * 4 + e;
+                v[i][e] = col < L ? fast_exp2((v[i][e] - mx) * c) : 0.f;
+                sum += v[i][e];
+            }
+        sum = block_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = (i * 256 + tid) * 4 + e;
+                if (col < Lp) orow[col] = from_f32<T>(v[i][e] * inv);
+            }
+        return;
+    }
+    float mx = -3.0e38f;
+    for (int col = tid; col < L; col += 256) mx = fmaxf(mx, row[col]);
+    mx = block_max(mx);
+    float sum = 0.f;
+    for (int col = tid; col < L; col += 256) sum += fast_exp2((row[col] - mx) * c);
+    sum = block_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int col = tid; col < Lp; col += 256) orow[col] = from_f32<T>(col < L ? fast_exp2((row[col] - mx) * c) * inv : 0.f);
+}
+
 #define DISPATCH_T(dtype, CALL)                          \
     do {                                                 \
         if ((dtype) == MI355X_F32) {                     \
@@ -392,5 +463,14 @@ extern "C" int mi355x_relpos_pack(int32_t dtype, const void* src, int64_t lds, v
     const int grid = grid_for(M * H * Dq);
     DISPATCH_T(dtype, hipLaunchKernelGGL((relpos_pack_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(src), lds, static_cast<T*>(out), ldo, M, H, d,
                                          S1, S2, Lp, Dq));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_softmax_rows(int32_t dtype, const float* s, int64_t lds, void* out, int64_t ldo, int64_t M, int32_t L, int32_t Lp, float scale,
+                                   void* stream) {
+    if (!s || !out || M <= 0 || L <= 0 || Lp < L || lds < L || ldo < Lp) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float c = scale * 1.44269504088896340736f;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)M), dim3(256), 0, st, s, lds, static_cast<T*>(out), ldo, L, Lp, c));
     return LAUNCH_OK();
 }

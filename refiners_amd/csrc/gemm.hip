@@ -100,7 +100,8 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     p.res = static_cast<const char*>(a->res);
     p.ldres = a->ldres;
     p.zeros = static_cast<const char*>(a->zeros);
-    bool vec = (!a->out || (aligned16(a->out) && (a->ldo * es) % 16 == 0));
+    const int eso = a->out_f32 ? 4 : es;
+    bool vec = (!a->out || (aligned16(a->out) && (a->ldo * eso) % 16 == 0));
     if (a->bias) vec = vec && aligned16(a->bias);
     if (a->rowbias) vec = vec && aligned16(a->rowbias) && (a->ld_rowbias * es) % 16 == 0;
     if (a->res) vec = vec && aligned16(a->res) && (a->ldres * es) % 16 == 0;
@@ -129,6 +130,10 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         p.ln_eps = a->ln_eps;
         p.ln_s = static_cast<const float*>(a->ln_s);
         p.ln_c = static_cast<const float*>(a->ln_c);
+    }
+    if (a->out_f32) {
+        if (a->conv || a->ksplit > 1 || a->geglu == 1 || has_t || a->stats_out || !a->out) return MI355X_ESHAPE;
+        p.out_f32 = 1;
     }
     if (a->stats_out) {
         if (a->conv || a->ksplit > 1 || a->geglu == 1 || has_t || !vec || a->N % 64 || (reinterpret_cast<uintptr_t>(a->stats_out) & 7)) return MI355X_ESHAPE;

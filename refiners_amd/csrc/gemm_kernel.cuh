@@ -77,6 +77,7 @@ struct GemmP {
     const float* ln_s;  // [N]: sum_k W'[n][k]
     const float* ln_c;  // [N]: sum_k beta[k] W[n][k] (+ bias[n])
     float* stats_out;   // [N / 32][M][2], or NULL
+    int out_f32;        // store `out` as float32 (scores for mi355x_softmax_rows)
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
     const char* pf_ptr[MI355X_MAX_PREFETCH];
@@ -329,9 +330,28 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
         const int row = tid_all / TPR, sub = tid_all % TPR;
         const int m = min(m0 + row, p.M - 1);
         float cn = 0.f, mean = 0.f, m2 = 0.f;
-        for (int part = sub; part < p.ln_parts; part += TPR) {
-            const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + ((int64_t)part * p.M + m) * 2);
-            stat_merge(cn, mean, m2, 32.f, st[0], st[1]);
+        // all of this thread's partials are loaded BEFORE the first merge (independent loads, one L2 round trip instead of
+        // ln_parts / TPR serialized ones: 20 dependent trips at the head of every consumer cost more than the LayerNorm launch saved)
+        constexpr int MAXP = 24;
+        const float* sp = p.ln_stats + (int64_t)m * 2;
+        const int64_t pstride = (int64_t)p.M * 2;
+        f32x2 st[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int part = sub + i * TPR;
+            st[i] = part < p.ln_parts ? *reinterpret_cast<const f32x2*>(sp + part * pstride) : f32x2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i)
+            if (sub + i * TPR < p.ln_parts) {  // Chan's update with equal counts of 32: n = 32 i so far, f = 32 / (32 (i + 1)) is a constant
+                const float d = st[i][0] - mean, f = 1.0f / (float)(i + 1);
+                mean += d * f;
+                m2 += st[i][1] + d * d * (32.0f * i) * f;
+                cn = 32.0f * (i + 1);
+            }
+        for (int part = sub + MAXP * TPR; part < p.ln_parts; part += TPR) {  // wider than MAXP * TPR * 32 columns: the slow way
+            const f32x2 s2 = *reinterpret_cast<const f32x2*>(sp + part * pstride);
+            stat_merge(cn, mean, m2, 32.f, s2[0], s2[1]);
         }
 #pragma unroll
         for (int o = 1; o < TPR; o <<= 1) {
@@ -605,6 +625,14 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
                         for (int e = 0; e < EPC; ++e) v[c * EPC + e] += rv.get(e);
                     }
                 }
+                if (p.out_f32) {
+                    if (mok) {
+                        float* of = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
+#pragma unroll
+                        for (int c = 0; c < RUN / 4; ++c) *reinterpret_cast<f32x4*>(of + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+                    }
+                    continue;
+                }
                 T* op = out + (int64_t)m * p.ldo + n;
                 float rs = 0.f;  // sum of the values AS STORED (rounded to T): the next LayerNorm normalises the stored tensor
 #pragma unroll
@@ -657,7 +685,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
                     if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
                     if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
                     if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
-                    out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
+                    if (p.out_f32) reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + nn] = val;
+                    else out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
                 }
             }
         }

@@ -313,10 +313,11 @@ class CompiledSDXL:
 
     def set_inputs(self, x: Tensor, *, clip_text_embedding: Tensor, pooled_text_embedding: Optional[Tensor] = None, time_ids: Optional[Tensor] = None,
                    clip_image_embedding: Optional[Tensor] = None, conditions: Optional[dict[str, Tensor]] = None,
-                   t2i_features: Optional[dict[str, Any]] = None) -> None:
+                   t2i_features: Optional[dict[str, Any]] = None, generator: Optional[torch.Generator] = None) -> None:
         """x: (N, 4, H, W) initial latents; embeddings are [negative ; conditional] stacks of 2N rows;
         `conditions` maps a ControlLora name to its (2N, 3, 8H, 8W) control image; `t2i_features` maps a T2I-Adapter name to
         the tuple its `compute_condition_features` returned (batch 1 or 2N)."""
+        self.generator = generator  # stochastic solvers (LCM) draw their per-step noise from it, in the reference's order
         tokens = {("cross_attention_block", "clip_text_embedding"): clip_text_embedding}
         if clip_image_embedding is not None:
             tokens[("ip_adapter", "clip_image_embedding")] = clip_image_embedding
@@ -380,8 +381,13 @@ class CompiledSDXL:
         return self.x
 
     def _linear_step(self, step: int, io: Any, low: Any, eng: Any) -> Tensor:
-        """Euler / DPM-Solver++: the UNet program then ONE kernel (guidance, update, history, next model input)."""
+        """Euler / DPM-Solver++ / LCM: the UNet program then ONE kernel (guidance, update, history, next model input)."""
         assert self.x is not None and self.hist is not None
+        if getattr(self.solver, "needs_noise", None) is not None and self.solver.needs_noise(step):
+            # LCMSolver re-noises the consistency estimate (solvers/lcm.py:143-150): same draw as the reference (shape, device,
+            # dtype, generator), placed in the kernel's history slot whose coefficient is the next timestep's noise std
+            noise = torch.randn(tuple(self.x.shape), generator=getattr(self, "generator", None), device=self.x.device, dtype=self.x.dtype)
+            self.hist.copy_(noise)
         if not self.primed or self.primed_key != eng.key:  # first step of a trajectory, or the engine re-lowered into new buffers
             self._fill()  # cat(x, x) ...
             s0 = float(self.solver.input_scale(step))

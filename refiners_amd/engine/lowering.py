@@ -625,8 +625,30 @@ class Lowering:
                     native.axpby(out, 1.0, dst, 1.0, out)
                     self.pool.put(dst)
             return out
-        # head dims no kernel covers (the VAE's single 512-wide head): torch SDPA on the same token-major tensors
+        # head dims no flash kernel covers (the VAE's single 512-wide head over H*W tokens): S = Q K^T (float32 scores), row
+        # softmax, O = P V as three native launches per (sample, head) -- the score matrix is 1 GB at 1024x1024 px, nothing
+        # next to 288 GB of HBM, and both GEMMs run at matrix-core speed (K = 512 and K = H*W)
         assert v_plain is not None
+        kblk = 128 // self.es
+        if d % kblk == 0 and all(Lk % kblk == 0 and k.shape[0] == B * Lk for (k, _v, Lk, _o) in streams) and len(streams) == 1 and streams[0][3] == 1.0 and self.device.type != "meta":
+            (k, _unused, Lk, osc), v = streams[0], v_plain[0]
+            vt = self.pool.get(B * C, Lk)  # [B][C][Lk]: V^T per sample
+            native.nhwc_to_nchw(v.view(B, Lk, C), vt.view(B, C, Lk, 1), C)
+            scores = self.__dict__.setdefault("_wide_scores", {})
+            if (Lq, Lk) not in scores:
+                scores[(Lq, Lk)] = (torch.empty(Lq, Lk, device=self.device, dtype=torch.float32), torch.empty(Lq, Lk, device=self.device, dtype=self.dtype))
+            sc, pr = scores[(Lq, Lk)]
+            for b in range(B):
+                for hh in range(heads):
+                    qb = q[b * Lq : (b + 1) * Lq, hh * d : (hh + 1) * d]
+                    kb = k[b * Lk : (b + 1) * Lk, hh * d : (hh + 1) * d]
+                    native.gemm([(qb, kb)], sc, out_f32=self.dtype != torch.float32)
+                    native.softmax_rows(sc, pr, Lk, d ** -0.5)
+                    vtb = vt.view(B, C, Lk)[b, hh * d : (hh + 1) * d]
+                    ob = out[b * Lq : (b + 1) * Lq, hh * d : (hh + 1) * d]
+                    native.gemm([(pr, vtb)], ob)
+            self.pool.put(vt)
+            return out
 
         def run() -> None:
             acc = None

@@ -2,6 +2,7 @@
 
 * `Euler`      `latent_diffusion/solvers/euler.py:13-100`  (k-diffusion Euler, noise prediction; scales the model input)
 * `DPMSolver`  `latent_diffusion/solvers/dpm.py:36-329`    (DPM-Solver++ 2M, `sde_variance = 0`; SD1.5's default solver)
+* `LCMSolver`  `latent_diffusion/solvers/lcm.py:15-150`    (consistency jump + re-noising to an emulated DPM schedule; stochastic)
 
 on the reference's default schedule (`solvers/solver.py:96-123, 386-416`: 1000 train steps, quadratic betas
 8.5e-4 .. 1.2e-2, noise prediction).  Both are LINEAR in (x, eps, previous data estimate), so each exposes
@@ -92,12 +93,16 @@ class DPMSolver(_Schedule):
 
     def __init__(self, num_inference_steps: int, first_inference_step: int = 0, last_step_first_order: bool = False, device: Any = "cpu",
                  dtype: torch.dtype = torch.float32, num_train_timesteps: int = 1000, initial_diffusion_rate: float = 8.5e-4,
-                 final_diffusion_rate: float = 1.2e-2) -> None:
+                 final_diffusion_rate: float = 1.2e-2, timesteps_spacing: str = "custom") -> None:
         super().__init__(num_inference_steps, first_inference_step, num_train_timesteps, initial_diffusion_rate, final_diffusion_rate)
+        assert timesteps_spacing in ("custom", "trailing")
         self.last_step_first_order = last_step_first_order
         # (the reference builds the train-time schedule in float32 and only then switches to float64: dpm.py:74-81)
         csf, nstd = self.cumulative_scale_factors.double(), self.noise_std.double()
-        spaced = torch.tensor(np.linspace(0, num_train_timesteps - 1, num_inference_steps + 1).round().astype(int)[1:]).flip(0)
+        if timesteps_spacing == "custom":  # DPM's own spacing (dpm.py:112-123)
+            spaced = torch.tensor(np.linspace(0, num_train_timesteps - 1, num_inference_steps + 1).round().astype(int)[1:]).flip(0)
+        else:  # TRAILING (solver.py:229-232): what LCMSolver asks of the DPM solver it emulates
+            spaced = torch.arange(num_train_timesteps - 1, 0, -(num_train_timesteps // num_inference_steps))
         sigmas_all = nstd / csf
         sig = torch.tensor(np.interp(spaced.numpy(), np.arange(0, len(sigmas_all)), sigmas_all.numpy()))
         self.sigmas = torch.cat([sig, sigmas_all[0:1]])
@@ -127,6 +132,10 @@ class DPMSolver(_Schedule):
     def input_scale(self, step: int) -> float:
         return 1.0
 
+    def add_noise(self, x: Tensor, noise: Tensor, step: int) -> Tensor:
+        """DPMSolver._add_noise (dpm.py:171-191): the tables are indexed by inference STEP here, not by train timestep."""
+        return self.cumulative_scale_factors[step] * x + self.noise_std[step] * noise
+
     def _first_order(self, step: int) -> bool:
         return step == self.first_inference_step or (self.last_step_first_order and step == self.num_inference_steps - 1)
 
@@ -155,3 +164,57 @@ class DPMSolver(_Schedule):
         est_delta = (cur - prev) / ((lam[step] - lam[step - 1]) / (lam[step + 1] - lam[step]))
         f = 1.0 - torch.exp(delta)
         return (n[step + 1] / n[step]) * x + a[step + 1] * f * cur + 0.5 * a[step + 1] * f * est_delta
+
+
+class LCMSolver(_Schedule):
+    """Latent Consistency Model solver (solvers/lcm.py:15-150): every step jumps to the consistency function's data estimate
+    and, except on the last one, re-noises it to the next timestep of an emulated `num_orig_steps`-step DPM schedule
+    (TRAILING spacing).  The update is linear in (x, eps, fresh noise):
+        x' = a2 (c_skip + c_out / a) x  -  a2 c_out n / a  eps  +  n2 noise
+    so it runs on the same fused guidance + update kernel as Euler / DPM++ with the kernel's history buffer pre-loaded with
+    the step's noise draw (`needs_noise`); `__call__` is the unfused path with the reference's formulas and operation order."""
+
+    def __init__(self, num_inference_steps: int, first_inference_step: int = 0, num_orig_steps: int = 50, device: Any = "cpu",
+                 dtype: torch.dtype = torch.float32, num_train_timesteps: int = 1000, initial_diffusion_rate: float = 8.5e-4,
+                 final_diffusion_rate: float = 1.2e-2) -> None:
+        assert num_orig_steps >= num_inference_steps, f"num_orig_steps ({num_orig_steps}) < num_inference_steps ({num_inference_steps})"
+        super().__init__(num_inference_steps, first_inference_step, num_train_timesteps, initial_diffusion_rate, final_diffusion_rate)
+        self.dpm = DPMSolver(num_orig_steps, device=device, dtype=dtype, num_train_timesteps=num_train_timesteps, initial_diffusion_rate=initial_diffusion_rate,
+                             final_diffusion_rate=final_diffusion_rate, timesteps_spacing="trailing")
+        self.timestep_indices: list[int] = torch.floor(torch.linspace(start=0, end=num_orig_steps, steps=num_inference_steps + 1)[:-1]).int().tolist()
+        self.timesteps = self.dpm.timesteps[self.timestep_indices]
+        self._move(("scale_factors", "cumulative_scale_factors", "noise_std"), device, dtype)
+
+    def scale_model_input(self, x: Tensor, step: int) -> Tensor:
+        return x
+
+    def input_scale(self, step: int) -> float:
+        return 1.0
+
+    def needs_noise(self, step: int) -> bool:
+        return step != self.num_inference_steps - 1
+
+    def _consistency(self, step: int) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+        t_now = self.timesteps[step]
+        sigma = 0.5  # assumed standard deviation of the data distribution (lcm.py:137)
+        t = t_now * 10
+        return self.cumulative_scale_factors[t_now], self.noise_std[t_now], sigma ** 2 / (t ** 2 + sigma ** 2), t / torch.sqrt(sigma ** 2 + t ** 2)
+
+    def __call__(self, x: Tensor, predicted_noise: Tensor, step: int, generator: Any = None) -> Tensor:
+        assert self.first_inference_step <= step < self.num_inference_steps, f"invalid step {step}"
+        a, n, c_skip, c_out = self._consistency(step)
+        data = (x - n * predicted_noise) / a
+        denoised = c_skip * x + c_out * data
+        if not self.needs_noise(step):
+            return denoised
+        noise = torch.randn(predicted_noise.shape, generator=generator, device=self.device, dtype=self.dtype)
+        return self.dpm.add_noise(x=denoised, noise=noise, step=int(self.timestep_indices[step + 1]))
+
+    def linear_step(self, step: int) -> tuple[float, ...]:
+        """(hx, he, kx, ke, kd, kp, s_next); the history slot holds this step's NOISE draw (kp = its coefficient)."""
+        a, n, c_skip, c_out = (float(v) for v in self._consistency(step))
+        a2, n2 = 1.0, 0.0
+        if self.needs_noise(step):
+            nxt = int(self.timestep_indices[step + 1])
+            a2, n2 = float(self.dpm.cumulative_scale_factors[nxt]), float(self.dpm.noise_std[nxt])
+        return (0.0, 0.0, a2 * (c_skip + c_out / a), -a2 * c_out * n / a, 0.0, n2, 1.0)

@@ -131,6 +131,7 @@ class GemmArgs(C.Structure):
         ("ln_s", C.c_void_p),
         ("ln_c", C.c_void_p),
         ("stats_out", C.c_void_p),
+        ("out_f32", C.c_int32),
     ]
 
 
@@ -243,6 +244,7 @@ EXPORTS = [
     "mi355x_concat2",
     "mi355x_axpby",
     "mi355x_silu",
+    "mi355x_softmax_rows",
     "mi355x_cfg_ddim_step",
     "mi355x_cfg_linear_step",
     "mi355x_sinusoidal",
@@ -285,6 +287,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_concat2.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.mi355x_axpby.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_silu.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mi355x_softmax_rows.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     lib.mi355x_cfg_ddim_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_cfg_linear_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_sinusoidal.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
@@ -293,10 +296,15 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_pointwise_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     lib.mi355x_relpos_pack.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.mi355x_groupnorm_set_fused.argtypes = [C.c_int, C.c_int64]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     if lib.mi355x_abi_version() != 3:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
+    import os
+
+    if os.environ.get("REFINERS_AMD_GN_FUSED", "1") == "0":  # A/B: always the three-kernel GroupNorm
+        lib.mi355x_groupnorm_set_fused(0, 0)
     return lib
 
 
@@ -521,6 +529,7 @@ def gemm(
     nt_begin: int = 0,
     ln: Optional[tuple[Tensor, Tensor, Tensor, float]] = None,
     stats_out: Optional[Tensor] = None,
+    out_f32: bool = False,
 ) -> Optional[Tensor]:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
     weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch.
@@ -556,6 +565,9 @@ def gemm(
         a.rowbias, a.ld_rowbias, a.rows_per_group, a.res, a.ldres, a.geglu = None, 0, 1, None, 0, 0
     else:
         _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, (3 if gelu == "quick" else 2) if gelu else geglu)
+    if out_f32:
+        assert out is not None and out.dtype == torch.float32
+        a.out_f32 = 1
     if ln is not None:
         stats, ls, lc, eps = ln
         assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 3 and stats.shape[1] == a.M and stats.shape[2] == 2
@@ -827,6 +839,14 @@ def concat2(a_: Tensor, b_: Tensor, out: Tensor) -> Tensor:
 def axpby(a_: Tensor, alpha: float, b_: Tensor, beta: float, out: Tensor) -> Tensor:
     assert a_.is_contiguous() and b_.is_contiguous() and out.is_contiguous() and a_.numel() == b_.numel() == out.numel()
     _launch("mi355x_axpby", (dtype_code(a_.dtype), a_.data_ptr(), alpha, b_.data_ptr(), beta, out.data_ptr(), a_.numel(),), "mi355x_axpby")
+    return out
+
+
+def softmax_rows(s: Tensor, out: Tensor, L: int, scale: float) -> Tensor:
+    """out[m, :L] = softmax(scale * s[m, :L]), out[m, L:] = 0.  s: float32 [M, >= L] rows; out: [M, Lp] rows of the compute dtype."""
+    assert s.dtype == torch.float32 and s.dim() == 2 and out.dim() == 2 and s.stride(1) == 1 and out.stride(1) == 1 and s.shape[0] == out.shape[0]
+    assert s.shape[1] >= L and out.shape[1] >= L
+    _launch("mi355x_softmax_rows", (dtype_code(out.dtype), s.data_ptr(), s.stride(0), out.data_ptr(), out.stride(0), s.shape[0], L, out.shape[1], scale), "mi355x_softmax_rows")
     return out
 
 

@@ -600,6 +600,33 @@ def gemm_ln_chain_case(M, Cc, N2, dtype, *, geglu=False, tile1=0, tile2=0, trans
     return max(e0[0], e1[0]), max(e0[1], e1[1]), e1[2] * (2.0 if dtype == torch.bfloat16 else 1.0)
 
 
+def wide_head_attention_case(L, D, dtype, seed=250):
+    """The VAE mid-block head (one head of 512 over H*W tokens) as S = Q K^T (float32 scores), row softmax, O = P V."""
+    q = _rand(L, D, dtype=dtype, seed=seed)
+    k = _rand(L, D, dtype=dtype, seed=seed + 1)
+    v = _rand(L, D, dtype=dtype, seed=seed + 2)
+    sc = torch.full((L, L), float("nan"), dtype=torch.float32, device=DEV)
+    native.gemm([(q, k)], sc, out_f32=dtype != torch.float32)
+    pr = torch.full((L, L), float("nan"), dtype=dtype, device=DEV)
+    native.softmax_rows(sc, pr, L, D ** -0.5)
+    o = torch.full((L, D), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(pr, v.t().contiguous())], o)
+    ref = torch.softmax((q.float() @ k.float().t()) * D ** -0.5, dim=-1) @ v.float()
+    e0 = _cmp(sc, q.float() @ k.float().t(), torch.float32)
+    assert e0[0] <= 2e-3 * e0[1] if dtype == torch.float32 else e0[0] <= 1e-5 * e0[1] + 1e-3, "raw scores must be float32-accurate"
+    return _cmp(o, ref, dtype)
+
+
+def softmax_rows_case(M, L, Lp, dtype, seed=255):
+    s = _rand(M, Lp + 4, dtype=torch.float32, seed=seed, scale=6.0)
+    out = torch.full((M, Lp), float("nan"), dtype=dtype, device=DEV)
+    native.softmax_rows(s[:, : Lp], out, L, 0.37)
+    ref = torch.zeros(M, Lp, device=DEV)
+    ref[:, :L] = torch.softmax(s[:, :L] * 0.37, dim=-1)
+    assert float(out[:, L:].float().abs().max()) == 0.0 if Lp > L else True
+    return _cmp(out, ref, dtype)
+
+
 def all_cases():
     """(name, thunk) list; sizes chosen so the whole list runs in well under a minute on one MI355X."""
     cases = []
@@ -696,6 +723,11 @@ def all_cases():
             (f"gemm_{tag}_ln_chain_tiles_6_2", lambda dt=dt: gemm_ln_chain_case(300, 320, 384, dt, tile1=6, tile2=2)),
             (f"gemm_{tag}_ln_chain_tiles_5_3", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=5, tile2=3)),
             (f"gemm_{tag}_ln_chain_tiles_2_5", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=2, tile2=5)),
+            (f"wide_head_{tag}_384x512", lambda dt=dt: wide_head_attention_case(384, 512, dt)),
+            (f"wide_head_{tag}_1024x512", lambda dt=dt: wide_head_attention_case(1024, 512, dt)),
+            (f"softmax_rows_{tag}_vec", lambda dt=dt: softmax_rows_case(33, 1000, 1024, dt)),
+            (f"softmax_rows_{tag}_unaligned", lambda dt=dt: softmax_rows_case(5, 77, 77, dt)),
+            (f"softmax_rows_{tag}_long", lambda dt=dt: softmax_rows_case(3, 20000, 20032, dt)),
             (f"gemm_{tag}_ln_chain_transposed", lambda dt=dt: gemm_ln_chain_case(1024, 1280, 1280, dt, transposed=True)),
         ]
     return cases

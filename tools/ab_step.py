@@ -21,7 +21,7 @@ from refiners_amd import native  # noqa: E402
 from refiners_amd.engine import tuning  # noqa: E402
 from refiners_amd.engine.compiled import CompiledSDXL  # noqa: E402
 
-KEYS = ("REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH")
+KEYS = ("REFINERS_AMD_GN_FUSED", "REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH")
 
 
 def main() -> None:
@@ -46,6 +46,7 @@ def main() -> None:
         for kv in filter(None, envs.split(",")):
             k, v = kv.split(":")
             os.environ[k] = v
+        native.load().mi355x_groupnorm_set_fused(int(os.environ.get("REFINERS_AMD_GN_FUSED", "1") != "0"), 0)  # decided at launch / capture time
         tuning.enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
         tuning._table = None
         p = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=True, lora_mode=args.lora_mode)
