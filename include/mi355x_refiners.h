@@ -153,6 +153,17 @@ typedef struct {
     void* stats_out;
     int32_t out_f32;        /* 1 = `out` is float32 whatever `dtype` says (ldo in float elements; 16-byte aligned rows): raw scores for
                                mi355x_softmax_rows.  Not combinable with geglu / stats_out / out_t / ksplit. */
+    /* LoRA inside the parent launch -- LoraAdapter = Sum(target, *loras), src/refiners/fluxion/adapters/lora.py:383-397, with
+       Lora = Chain(down, up, Multiply(scale)) (:14-60) -- for a stacked rank of at most 32 (zero-padded to 32):
+         out += T( x . A_g^T ) . lora_b[n]^T      g = column group of n (lora_nb[g] <= n, groups start on multiples of 128)
+       lora_a[g]: the 32 stacked down-projection rows of group g, K-BLOCKED: [K*sizeof/128][32][128 bytes]; lora_b: [N][32] row-major,
+       the up-projections already multiplied by their scales (rows follow the same N-packing as w).  x A^T is accumulated in the
+       same K loop as x W^T and rounded to `dtype` (the reference's intermediate tensor) before the up-projection step.
+       One segment, no conv / ksplit / ln_stats.  lora_b == NULL: off. */
+    const void* lora_a[3];
+    int32_t lora_nb[3];
+    int32_t lora_groups;
+    const void* lora_b;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

@@ -102,7 +102,16 @@ MI_DEV int xcd_remap(int bid, int nblk) {
 // v_exp_f32 without the denormal-range fix-up sequence exp2f() expands to: softmax arguments are <= 0 and results that
 // would be denormal are flushed to 0, which is what an online softmax wants.
 MI_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-MI_DEV float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (fl.GeLU with approximation NONE): erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. float32 round-off level:
+// two transcendentals + a degree-5 Horner instead of libm's erff, which costs 3x the VALU work of the GEGLU epilogue's 32 calls per lane)
+MI_DEV float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float y = 1.0f - poly * __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+    return copysignf(y, x);
+}
+MI_DEV float gelu_exact(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 // CLIP's "quick GELU" (GeLUApproximation.SIGMOID, fluxion/layers/activations.py:83-118)
 MI_DEV float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 MI_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }

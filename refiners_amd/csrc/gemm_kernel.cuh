@@ -24,6 +24,12 @@
 //     epilogue applies y = rstd[m] * (acc - mean[m] * s[n]) + c[n] with s = W' 1, c = W beta + bias.  mean / rstd come from
 //     per-row (mean, M2) partials over 32-column chunks that the launch PRODUCING r wrote from its epilogue (Chan-merged
 //     in a fixed order: deterministic, no atomics);
+//   * LoRA inside the parent launch (LORA = true): the stacked down-projection rows A_cat [32][K] ride in the K loop as 32 extra
+//     weight rows of every stage (t = x A_cat^T accumulates next to the main product, the two waves that share a row block
+//     compute one half each), and after the loop t -- rounded to the storage type like the reference's intermediate tensor --
+//     goes through LDS as one more K step against the stacked, pre-scaled up-projections (s B_cat) [N][32]:
+//     y = x W^T + b + sum_i s_i (x A_i^T) B_i^T from ONE kernel (fluxion/adapters/lora.py:383-397), per-column-group A so that a
+//     merged Q|K|V launch keeps its three LoRA sets;
 //   * bf16 -> v_mfma_f32_16x16x32_bf16, f32 (parity mode) -> v_mfma_f32_16x16x4_f32; identical LDS image.
 #pragma once
 #include <type_traits>
@@ -78,6 +84,12 @@ struct GemmP {
     const float* ln_c;  // [N]: sum_k beta[k] W[n][k] (+ bias[n])
     float* stats_out;   // [N / 32][M][2], or NULL
     int out_f32;        // store `out` as float32 (scores for mi355x_softmax_rows)
+    // LoRA inside the launch: per column group g (columns >= lora_nb[g]) the K-blocked stacked down rows, [K blocks][32][128 B];
+    // lora_b: [N][32] pre-scaled up-projections (row n = output column n), row-major
+    const char* lora_a[3];
+    int lora_nb[3];
+    int lora_groups;
+    const char* lora_b;
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
     const char* pf_ptr[MI355X_MAX_PREFETCH];
@@ -98,15 +110,18 @@ MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, flo
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1>
+constexpr int LORA_R = 32;  // stacked LoRA rank handled inside a launch (two rank-16 adapters, or anything that pads to 32)
+
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
 __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     constexpr int NW = WM * WN;           // waves per K group
     constexpr int NTHR = NW * 64;         // threads per K group: the loader geometry
     constexpr int NTHR_ALL = NTHR * KG;   // threads per workgroup
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
     constexpr int XI = BM * 8 / NTHR, WI = BN * 8 / NTHR;
-    constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
+    constexpr int XBYTES = BM * 128, WBYTES = BN * 128, ABYTES = LORA ? LORA_R * 128 : 0, STAGE = XBYTES + WBYTES + ABYTES;
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
+    static_assert(!LORA || (!CONV && KG == 1 && NTHR == 256 && WN == 2), "in-launch LoRA: plain GEMM, 4 waves as 2 x 2");
     static_assert(KG == 1 || KG == 2, "one or two K groups");
     constexpr int WNE = 16 * NT;  // columns per wave
     constexpr int WME = 16 * MT;  // rows per wave
@@ -211,6 +226,17 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // in-launch LoRA: t[rows of this wave][16 of the 32 stacked ranks: half wn] = x A_cat^T, accumulated next to the main product
+    f32x4 tacc[LORA ? MT : 1];
+#pragma unroll
+    for (int i = 0; i < (LORA ? MT : 1); ++i) tacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* abase = nullptr;  // this thread's 16 bytes of the A_cat K block (K-blocked: [K block][32 rows][128 B])
+    int64_t aoff = 0;
+    if constexpr (LORA) {
+        const int gi = (p.lora_groups > 1 && n0 >= p.lora_nb[1] ? 1 : 0) + (p.lora_groups > 2 && n0 >= p.lora_nb[2] ? 1 : 0);
+        const int row = tid >> 3, pch = tid & 7;
+        abase = p.lora_a[gi] + row * 128 + ((pch ^ swz<128>(row)) << 4);
+    }
 
     // ---- K-block iteration state ----
     int seg = 0, kb = 0;  // kb = block index inside the current segment
@@ -275,6 +301,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
         if (seg >= p.nseg) return;
         ++kb;
         woff += wstep;
+        if constexpr (LORA) aoff += LORA_R * 128;
         if constexpr (CONV) {
             if (++cb == cur_cpb) {
                 cb = 0;
@@ -307,6 +334,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
         }
 #pragma unroll
         for (int it = 0; it < WI; ++it) glds16(wbase[it] + woff, ws + (it * NTHR + wid * 64) * 16);
+        if constexpr (LORA) glds16(abase + aoff, ws + WBYTES + wid * 64 * 16);
 #pragma unroll
         for (int a = 0; a < KG; ++a) advance();
     };
@@ -316,7 +344,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     // drain, guide section 5 "pipelining across barriers") -> issue block t+D into the buffer block t-1 was computed from
     // -> MFMA on block t.  One barrier per K block.
     constexpr int D = NSTAGE - 1;
-    constexpr int LPS = XI + WI;  // global_load_lds instructions per thread per stage
+    constexpr int LPS = XI + WI + (LORA ? 1 : 0);  // global_load_lds instructions per thread per stage
 #pragma unroll
     for (int s0 = 0; s0 < D; ++s0)
         if (s0 < my_kb) issue(s0);
@@ -380,25 +408,28 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     // machine scheduler otherwise sinks every ds_read to just before its first use and waits lgkmcnt(0) eight times per block).
     auto mainloop = [&](auto trc) {
         constexpr bool TR = decltype(trc)::value;
-        constexpr int RR = MT + NT;                                    // ds_read_b128 per phase
-        constexpr int MM = MT * NT * (sizeof(T) == 4 ? 4 : 1);         // MFMA instructions per phase
-        frag_t xf0[MT], wf0[NT], xf1[MT], wf1[NT];
-        auto read_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT], int blk, int kk) {
+        constexpr int RR = MT + NT + (LORA ? 1 : 0);                              // ds_read_b128 per phase
+        constexpr int MM = (MT * NT + (LORA ? MT : 0)) * (sizeof(T) == 4 ? 4 : 1);  // MFMA instructions per phase
+        frag_t xf0[MT], wf0[NT], xf1[MT], wf1[NT], af0 = frag_t{0, 0, 0, 0}, af1 = frag_t{0, 0, 0, 0};
+        auto read_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT], frag_t& af, int blk, int kk) {
             const char* xs = smem_g + (blk % NSTAGE) * STAGE;
             const char* ws = xs + XBYTES;
+            if constexpr (LORA) af = lds_read_frag(ws + WBYTES, tile_off<128>(16 * wn + c16, 4 * kk + g));
 #pragma unroll
             for (int i = 0; i < MT; ++i) xf[i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
 #pragma unroll
             for (int j = 0; j < NT; ++j) wf[j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
         };
-        auto mma_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT]) {
+        auto mma_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT], frag_t af) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     if constexpr (TR) mma_step<T>(acc[i][j], xf[i], wf[j]);
                     else mma_step<T>(acc[i][j], wf[j], xf[i]);
                 }
+                if constexpr (LORA) mma_step<T>(tacc[i], af, xf[i]);  // t^T tile: rank rows x this wave's activation rows (both orientations)
+            }
         };
         auto pin = [&]() {  // the phase's LDS reads go out early, one per MFMA, so that the last one is >= MM - RR MFMAs old at the phase end
             constexpr int HEAD = RR < MM ? RR : MM;
@@ -416,12 +447,12 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (D < my_kb) issue(D % NSTAGE);
-        if (my_kb > 0) read_half(xf0, wf0, 0, 0);
+        if (my_kb > 0) read_half(xf0, wf0, af0, 0, 0);
         for (int t = 0; t < max_kb; ++t) {
             const bool active = KG == 1 || t < my_kb;  // the odd group of an odd block count idles through the last trip
             if (active) {  // phase A
-                read_half(xf1, wf1, t, 1);
-                mma_half(xf0, wf0);
+                read_half(xf1, wf1, af1, t, 1);
+                mma_half(xf0, wf0, af0);
                 pin();
             }
             if (t + 1 < max_kb) {
@@ -432,8 +463,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
                 if (t + 1 + D < my_kb) issue((t + 1 + D) % NSTAGE);
             }
             if (active) {  // phase B
-                read_half(xf0, wf0, t + 1, 0);  // (past the last block: a harmless read of a stale stage; keeps the phase one basic block)
-                mma_half(xf1, wf1);
+                read_half(xf0, wf0, af0, t + 1, 0);  // (past the last block: a harmless read of a stale stage; keeps the phase one basic block)
+                mma_half(xf1, wf1, af1);
                 pin();
             }
         }
@@ -443,6 +474,52 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     } else {
         if (tr) mainloop(std::true_type{});
         else mainloop(std::false_type{});
+    }
+
+    if constexpr (LORA) {
+        // ---- up-projection: acc += T(t) . (s B_cat)^T, one more K step of LORA_R ranks through LDS -------------------------
+        constexpr int RB = LORA_R * (int)sizeof(T);  // bytes per row of both LDS images (64 / 128)
+        constexpr int CPRB = RB / 16;                // 16-byte chunks per row
+        constexpr int KS = LORA_R / DT<T>::KSTEP;    // MMA steps (bf16: 1, f32: 2)
+        char* tl = smem;                // [BM rows in LDS order][LORA_R] of T
+        char* bl = smem + BM * RB;      // [BN rows in LDS order][LORA_R] of T
+        __syncthreads();                // every wave is done with the stage buffers
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {  // lane holds t[LDS row wm*WME + 16 i + c16][rank 16 wn + 4 g + 0..3]
+            char* dst = tl + (wm * WME + 16 * i + c16) * RB + (16 * wn + 4 * g) * (int)sizeof(T);
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<f32x4*>(dst) = tacc[i];
+            } else {
+                bf16x4 v = {(bf16_t)tacc[i][0], (bf16_t)tacc[i][1], (bf16_t)tacc[i][2], (bf16_t)tacc[i][3]};
+                *reinterpret_cast<bf16x4*>(dst) = v;
+            }
+        }
+        constexpr int BI = BN * CPRB / NTHR;
+        static_assert(BN * CPRB % NTHR == 0, "up-projection tile / thread mismatch");
+#pragma unroll
+        for (int it = 0; it < BI; ++it) {
+            const int q = it * NTHR + tid, row = q / CPRB, ch = q % CPRB;
+            const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
+            int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
+            n = n < p.N ? n : p.N - 1;
+            *reinterpret_cast<frag_t*>(bl + row * RB + ch * 16) = *reinterpret_cast<const frag_t*>(p.lora_b + (int64_t)n * RB + ch * 16);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            frag_t tf[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) tf[i] = lds_read_frag(tl, (wm * WME + 16 * i + c16) * RB + (4 * ks + g) * 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = lds_read_frag(bl, (wn * WNE + 16 * j + c16) * RB + (4 * ks + g) * 16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (tr) mma_step<T>(acc[i][j], tf[i], bf[j]);
+                    else mma_step<T>(acc[i][j], bf[j], tf[i]);
+                }
+        }
     }
 
     if constexpr (KG > 1) {
@@ -735,12 +812,12 @@ extern int g_pf_mode;    // 1 = plain loads, 2 = non-temporal
 extern int g_tile;       // 0 = heuristic / caller's hint, 1..6 = force a tile configuration (probing / A-B runs)
 extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS pipeline depth
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
-    constexpr int LDS = KG * NSTAGE * (BM + BN) * 128 + BM * 8;
+    constexpr int LDS = KG * NSTAGE * ((BM + BN) * 128 + (LORA ? LORA_R * 128 : 0)) + BM * 8;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(KG == 1 || (BM / WM / 16) * (BN / WN / 16) * WM * WN * 1024 <= KG * NSTAGE * (BM + BN) * 128, "partial-tile exchange must fit the stage buffers");
-    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG>;
+    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG, LORA>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -833,6 +910,16 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
     int tile = pick_tile(p, CONV);
     if (p.geglu && (tile == 2 || tile == 4)) tile = 3;  // the GEGLU epilogue needs 64 packed columns per wave
     const int st = pick_stages(p);
+    if constexpr (!CONV) {
+        if (p.lora_b) {  // in-launch LoRA: the 4-wave tiles, two LDS stages
+            switch (tile) {
+                case 2: return launch_cfg<T, 128, 64, 2, 2, false, 2, 1, true>(p, stream);
+                case 3: return launch_cfg<T, 64, 128, 2, 2, false, 2, 1, true>(p, stream);
+                case 4: return launch_cfg<T, 64, 64, 2, 2, false, 2, 1, true>(p, stream);
+                default: return launch_cfg<T, 128, 128, 2, 2, false, 2, 1, true>(p, stream);
+            }
+        }
+    }
     switch (tile) {
         case 1: return launch_stages<T, 128, 128, CONV>(p, st, stream);
         case 2: return launch_stages<T, 128, 64, CONV>(p, st, stream);

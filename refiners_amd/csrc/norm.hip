@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, 
 }
 
 int g_gn_fused = 1;                       // A/B switch (mi355x_groupnorm_set_fused)
-int64_t g_gn_fused_max_bytes = 512 << 10;  // slab size up to which one workgroup per group set beats the three-kernel path
+int64_t g_gn_fused_max_bytes = 96 << 10;   // slab size up to which one workgroup per group set beats the three-kernel path (tools/probe_gn.py)
 
 inline int gn_ppc(int B, int HW, int C, int es) {
     const int nv = C * es / 16;

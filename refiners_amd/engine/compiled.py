@@ -115,6 +115,10 @@ class CompiledUNet:
         for name, d in c.items():
             if name.startswith("control_lora_") and d.get("condition") is not None:
                 got["conditions"][name] = d["condition"]
+            if name == "controlnet":  # SD1.5 Controlnet adapters share one context, one key per adapter (sd1/controlnet.py:200-204)
+                for key, v in d.items():
+                    if key.startswith("condition_") and v is not None:
+                        got["conditions"][f"controlnet.{key}"] = v
         for key, feats in c.get("t2iadapter", {}).items():  # T2IAdapter.set_condition_features (t2i_adapter.py:201-202)
             if key.startswith("condition_features_") and feats is not None:
                 got["t2i"][key.removeprefix("condition_features_")] = tuple(feats)
@@ -208,6 +212,8 @@ class CompiledUNet:
             sig.append(id(m))
             if isa(m, "Multiply", "T2IFeatures"):  # nodes whose live scale is baked into the program
                 sig.append(float(m.scale))
+            if isa(m, "Controlnet"):
+                sig.extend([float(m.scale), float(m.scale_decay)])
         return hash(tuple(sig))
 
     def prepare_explicit(self, x_shape: tuple, device: torch.device, got: dict[str, Any]) -> bool:

@@ -100,6 +100,8 @@ class LoraPack:
     a_cat: Tensor  # [rpad, K(...)] stacked down weights, zero padded rows
     bs_cat: Tensor  # [N, rpad] stacked (scale * up) columns
     conv: Optional[tuple[int, int, int]] = None  # (down ksize, up ksize, stride) for Conv2dLora
+    a32: Any = None  # native.KBlocked of the first 32 rows of a_cat, when the stacked rank fits the in-launch path
+    bs32: Optional[Tensor] = None  # [N, 32]
 
 
 @dataclass
@@ -236,6 +238,9 @@ class Lowering:
         # them off (A/B runs; the unfused kernels stay in the library)
         self.ln_fuse = os.environ.get("REFINERS_AMD_LN_FUSE", "1") != "0"
         self.qkv_merge = os.environ.get("REFINERS_AMD_QKV_MERGE", "1") != "0"
+        # lora_mode="fused": the LoRA down / up projections run INSIDE the parent GEMM's launch (stacked rank <= 32); 0 = the older
+        # skinny-GEMM + extra-K-segment pair of launches
+        self.lora_inlaunch = os.environ.get("REFINERS_AMD_LORA_INLAUNCH", "1") != "0"
         self.device, self.dtype = device, dtype
         self.es = 4 if dtype == torch.float32 else 2
         self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
@@ -321,7 +326,11 @@ class Lowering:
                 o += r
             if row_perm is not None:
                 bs = bs[row_perm].contiguous()
-            return LoraPack(a, bs)
+            pack = LoraPack(a, bs)
+            if rt <= native.LORA_R and self.device.type != "meta":  # fits mi355x_gemm's in-launch LoRA: ONE kernel per adapted Linear
+                pack.a32 = native.KBlocked(a[: native.LORA_R].contiguous())
+                pack.bs32 = bs[:, : native.LORA_R].contiguous()
+            return pack
 
         self.stats["lora_sites"] += 1
         return self.cache.get(key, make)
@@ -467,6 +476,11 @@ class Lowering:
             native.gemm([(x, self.kblocked(wl))], out, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, ln=(stats, ls, lc, float(node.eps)),
                         stats_out=stats_out)
             return out
+        if spec.lora is not None and spec.lora.a32 is not None and self.lora_inlaunch and not isinstance(x, native.KBlocked):
+            # LoraAdapter = Sum(target, loras) as ONE launch: x A_cat^T rides in the parent's K loop, the up-projections are its last K step
+            native.gemm([(x, self.kblocked(spec.w))], out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, stats_out=stats_out,
+                        lora=([(0, spec.lora.a32)], spec.lora.bs32))
+            return out
         segs = [(x, self.kblocked(spec.w))]
         t = None
         if spec.lora is not None:
@@ -515,6 +529,9 @@ class Lowering:
     def linear_T(self, x: Tensor, spec: LinSpec, out_t: Tensor) -> Tensor:
         """out_t[N, M] = W x^T (+ LoRA): the V^T layout mi355x_attention consumes (operands swapped, no bias)."""
         _expect(spec.b is None, "transposed projection with bias is not supported")
+        if spec.lora is not None and spec.lora.a32 is not None and self.lora_inlaunch and out_t.stride(1) == 1:
+            native.gemm([(x, self.kblocked(spec.w))], None, out_t=out_t, nt_begin=0, lora=([(0, spec.lora.a32)], spec.lora.bs32))
+            return out_t
         segs = [(self.kblocked(spec.w), x)]
         t = None
         if spec.lora is not None:
@@ -729,8 +746,9 @@ class Lowering:
         lnarg = (stats, ln) if fold else None
         h = x if fold else self.layernorm(x, ln)
         no_lora = qs.lora is None and ks.lora is None and vs.lora is None
+        all_inlaunch = self.lora_inlaunch and all(sp.lora is not None and sp.lora.a32 is not None for sp in (qs, ks, vs))
         qk = q = k = vt = None
-        if no_lora and native_path and self.qkv_merge and L % 64 == 0 and C % 128 == 0 and self.device.type != "meta":
+        if (no_lora or all_inlaunch) and native_path and self.qkv_merge and L % 64 == 0 and C % 128 == 0 and self.device.type != "meta":
             # ONE launch for the three projections: [Wq; Wk; Wv] stacked, Q | K row-major, V stored transposed
             wqkv = LinSpec(self.cache.get(("qkv",) + PackCache.ident(qs.w, ks.w, vs.w), lambda: torch.cat([qs.w, ks.w, vs.w], 0).contiguous()), None)
             qk = self.pool.get(M, 2 * C)
@@ -738,8 +756,11 @@ class Lowering:
             if fold:
                 wl, ls, lc = self.ln_fold(wqkv, ln)
                 native.gemm([(h, self.kblocked(wl))], qk, out_t=vt, nt_begin=2 * C, ln=(stats, ls, lc, float(ln.eps)))
-            else:
+            elif no_lora:
                 native.gemm([(h, self.kblocked(wqkv.w))], qk, out_t=vt, nt_begin=2 * C)
+            else:  # three LoRA sets in one launch: a stacked-down block per column group, the up rows stacked like the weights
+                bs = self.cache.get(("qkv_bs",) + PackCache.ident(qs.lora.bs32, ks.lora.bs32, vs.lora.bs32), lambda: torch.cat([qs.lora.bs32, ks.lora.bs32, vs.lora.bs32], 0).contiguous())
+                native.gemm([(h, self.kblocked(wqkv.w))], qk, out_t=vt, nt_begin=2 * C, lora=([(0, qs.lora.a32), (C, ks.lora.a32), (2 * C, vs.lora.a32)], bs))
             q, k = qk[:, :C], qk[:, C:]
         else:
             # The V^T projection and the packed Q|K projection read the same h and do not depend on each other; neither fills the
@@ -1000,6 +1021,8 @@ class UNetLowering(Lowering):
             for child in kids(unet):
                 if isa(child, "ControlLora"):
                     self.control_lora(child, ctx, H, W)
+                elif isa(child, "Controlnet"):
+                    self.controlnet(child, ctx, H, W)
                 elif isa(child, "TimestepEncoder"):
                     self.timestep_encoder(child, ctx)
                 elif cname(child) in ("DownBlocks", "UpBlocks"):
@@ -1247,8 +1270,10 @@ class UNetLowering(Lowering):
     def add_condition(self, m: Any, cur: Act) -> Act:
         """x + ConditionEncoder(condition)   (control_lora.py:190-202), encoder output produced in the prologue."""
         reader, enc = kids(m)
-        cond = self.io.conditions.get(reader.context)
-        _expect(cond is not None, f"no condition image registered for {reader.context}")
+        # ControlLora: one context per adapter, key "condition"; SD1.5 Controlnet: shared context "controlnet", key "condition_<name>"
+        cname_ = reader.context if reader.key == "condition" else f"{reader.context}.{reader.key}"
+        cond = self.io.conditions.get(cname_)
+        _expect(cond is not None, f"no condition image registered for {cname_}")
         with self.in_prologue():
             e = self.condition_encoder(enc, cond)
             self.pool.pin(e.t)
@@ -1279,6 +1304,41 @@ class UNetLowering(Lowering):
         native.axpby(cur.t, 1.0, tok, float(m.scale), out)
         self.stats["t2i_sites"] = self.stats.get("t2i_sites", 0) + 1
         return Act(out, cur.B, cur.H, cur.W)
+
+    # -- SD1.5 ControlNet -----------------------------------------------------------------------------------------
+    def controlnet(self, node: Any, ctx: UNetContext, H: int, W: int) -> None:
+        """Controlnet = Passthrough(TimestepEncoder', Slicing(:4), DownBlocks', MiddleBlock') (stable_diffusion_1/controlnet.py:72-166):
+        a second, separately weighted encoder half in front of the UNet; after every one of its 12 down blocks and after its
+        middle block, residuals[n] += scale * scale_decay^(12 - n) * conv1x1_n(x) (:152-166).  Same shape of work as ControlLora:
+        each tap is one GEMM (scale folded into the packed 1x1 weights, previous slot value as the residual operand)."""
+        ch = kids(node)
+        _expect(len(ch) == 4 and isa(ch[0], "TimestepEncoder") and isa(ch[1], "Slicing") and cname(ch[2]) == "DownBlocks" and cname(ch[3]) == "MiddleBlock",
+                "unexpected Controlnet layout")
+        _expect(ch[1].dim == 1 and ch[1].start == 0 and ch[1].end == 4 and self.io.x.shape[1] == 4, "Controlnet on a UNet input with more than 4 channels is not lowered")
+        sub = UNetContext(self, ctx.B, text=ctx.text, temb_silu=ctx.temb_silu, residuals=ctx.residuals, shapes=[])
+        self.timestep_encoder(ch[0], sub)
+        cur: Optional[Act] = None
+        stages = [(n, kids(stage)) for n, stage in enumerate(kids(ch[2]))] + [(12, kids(ch[3]))]
+        _expect(len(stages) == 13, "Controlnet must have 12 down blocks and a middle block")
+        for n, pieces in stages:
+            for piece in pieces:
+                if isa(piece, "Passthrough") and len(kids(piece)) == 2 and isa(kids(piece)[0], "Conv2d") and isa(kids(piece)[1], "Lambda"):
+                    self.controlnet_tap(node, kids(piece)[0], n, cur, sub)
+                else:
+                    cur = self.piece(piece, cur, sub, H, W)
+        self._release(cur)
+        self.stats["controlnets"] = self.stats.get("controlnets", 0) + 1
+
+    def controlnet_tap(self, node: Any, conv: Any, n: int, cur: Optional[Act], ctx: UNetContext) -> None:
+        _expect(cur is not None and conv.kernel_size == (1, 1) and conv.in_channels == cur.C, "unexpected Controlnet residual tap")
+        scale = float(node.scale) * float(node.scale_decays[n])
+        w = self.cache.get(("cn_w", scale) + PackCache.ident(conv.weight), lambda: (conv.weight.detach().to(self.device, torch.float32).reshape(conv.out_channels, conv.in_channels) * scale).to(self.dtype).contiguous())
+        b = self.cache.get(("cn_b", scale) + PackCache.ident(conv.bias), lambda: (conv.bias.detach().to(self.device, torch.float32) * scale).to(self.dtype).contiguous())
+        prev = ctx.residuals[n]
+        z = self.pool.get(cur.M, conv.out_channels)
+        self.pool.pin(z)
+        native.gemm([(cur.t, w)], z, bias=b, res=None if prev is None else prev.t)
+        ctx.residuals[n] = Act(z, cur.B, cur.H, cur.W)
 
     def control_lora(self, node: Any, ctx: UNetContext, H: int, W: int) -> None:
         """Passthrough(TimestepEncoder', DownBlocks', MiddleBlock'): fills ctx.residuals, returns nothing."""

@@ -90,6 +90,7 @@ class KBlocked:
 
 
 MAX_PREFETCH = 2  # == MI355X_MAX_PREFETCH
+LORA_R = 32  # stacked LoRA rank mi355x_gemm handles inside the parent launch (gemm_kernel.cuh)
 
 
 class GemmArgs(C.Structure):
@@ -132,6 +133,10 @@ class GemmArgs(C.Structure):
         ("ln_c", C.c_void_p),
         ("stats_out", C.c_void_p),
         ("out_f32", C.c_int32),
+        ("lora_a", C.c_void_p * 3),
+        ("lora_nb", C.c_int32 * 3),
+        ("lora_groups", C.c_int32),
+        ("lora_b", C.c_void_p),
     ]
 
 
@@ -530,6 +535,7 @@ def gemm(
     ln: Optional[tuple[Tensor, Tensor, Tensor, float]] = None,
     stats_out: Optional[Tensor] = None,
     out_f32: bool = False,
+    lora: Optional[tuple[Sequence[tuple[int, "KBlocked"]], Tensor]] = None,
 ) -> Optional[Tensor]:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
     weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch.
@@ -568,6 +574,14 @@ def gemm(
     if out_f32:
         assert out is not None and out.dtype == torch.float32
         a.out_f32 = 1
+    if lora is not None:  # ([(first column of the group, K-blocked stacked down rows [32, K])], pre-scaled up rows [N, 32]): LoRA inside this launch
+        groups, lb = lora
+        assert 1 <= len(groups) <= 3 and lb.dim() == 2 and lb.shape == (a.N, LORA_R) and lb.is_contiguous() and lb.dtype == x0.dtype
+        for g, (nb, la) in enumerate(groups):
+            assert isinstance(la, KBlocked) and la.shape == (LORA_R, tuple(x0.shape)[1]) and la.dtype == x0.dtype
+            a.lora_a[g], a.lora_nb[g] = la.data_ptr(), nb
+        a.lora_groups, a.lora_b = len(groups), lb.data_ptr()
+        keep.append(lora)
     if ln is not None:
         stats, ls, lc, eps = ln
         assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 3 and stats.shape[1] == a.M and stats.shape[2] == 2
@@ -678,7 +692,7 @@ def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 1
 def gemm_signature(a: GemmArgs) -> str:
     """Shape class of a GEMM / conv launch: the key of the measured tile table (refiners_amd/engine/tuning.py)."""
     k = sum(int(a.seg[s].k) * (int(a.seg[s].ksize) ** 2 if a.conv else 1) for s in range(a.nseg))
-    flags = ("geglu" if a.geglu == 1 else "") + ("T%d" % a.nt_begin if a.out_t else "") + ("ln" if a.ln_stats else "") + ("st" if a.stats_out else "")
+    flags = ("geglu" if a.geglu == 1 else "") + ("T%d" % a.nt_begin if a.out_t else "") + ("ln" if a.ln_stats else "") + ("st" if a.stats_out else "") + ("lora" if a.lora_b else "")
     return f"{'conv' if a.conv else 'gemm'}:{'f32' if a.dtype == 0 else 'bf16'}:{a.M}x{a.N}x{k}:s{a.nseg}:{flags}"
 
 

@@ -85,6 +85,25 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 
     return n
 
 
+def load_and_broadcast(module: torch.nn.Module, tensors_path: Any, device: torch.device | str, src: int = 0, strict: bool = True) -> int:
+    """Checkpoint -> every GPU without a host-side detour on the receivers: rank `src` reads the safetensors file STRAIGHT onto its
+    device (safetensors maps the file and copies each tensor to HBM; the keys are refiners' Chain-path names, which the mirror
+    shares) and adopts the tensors as its parameters (`assign=True`, no second copy); the other ranks only allocate uninitialised
+    storage; then ONE arena broadcast (broadcast_module) moves the weights over xGMI.  Works for a tree built on the meta device.
+    Returns the number of collective launches (0 in a single-process run)."""
+    from safetensors.torch import load_file
+
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == src:
+        state = load_file(str(tensors_path), device=str(device))
+        want = module.state_dict()
+        cast = {k: (v if k not in want or v.dtype == want[k].dtype else v.to(want[k].dtype)) for k, v in state.items()}
+        module.load_state_dict(cast, strict=strict, assign=True)
+    else:
+        module.to_empty(device=device)
+    return broadcast_module(module, src=src)
+
+
 def shard_range(n_items: int, rank: int, world: int) -> range:
     """Contiguous slice of `n_items` prompts for `rank` (sizes differ by at most one)."""
     base, extra = divmod(n_items, world)

@@ -121,3 +121,46 @@ def kohya_sdxl_lora_keys(rank: int = 8):
 # ------------------------------------------------------------------------------------------------ next-4: T2I-Adapter
 T2I_CASE = dict(weight_seed=0, input_seed=31, latent_hw=(32, 32), num_steps=50, step=20, scale=0.8)
 CONTROLNET_CASE = dict(weight_seed=0, input_seed=41, latent_hw=(16, 16), timestep=601, scale=0.8, scale_decay=0.9)
+
+
+# ------------------------------------------------------------------------------------------------ next-3: adapter checkpoint formats
+def tagged(keys, device="cpu"):
+    """{key: tensor of the given shape whose every element equals the key's index + 1} as stride-0 views (no memory)."""
+    import torch
+
+    return {k: torch.tensor(float(i + 1), device=device).expand(tuple(shape)) if shape else torch.tensor(float(i + 1), device=device) for i, (k, shape) in enumerate(keys)}
+
+
+def ip_adapter_file():
+    """(key, shape) list of an SDXL IP-Adapter checkpoint in refiners' converted format, in FILE order: `image_proj.*` then, per
+    text cross-attention NNN (70 of them, UNet walk order), `ip_adapter.NNN.to_k_ip.weight` and `ip_adapter.NNN.to_v_ip.weight`."""
+    out = [("image_proj.Linear.weight", (4 * 2048, 1024)), ("image_proj.Linear.bias", (4 * 2048,)), ("image_proj.LayerNorm.weight", (2048,)), ("image_proj.LayerNorm.bias", (2048,))]
+    widths = [640] * 4 + [1280] * 20 + [1280] * 10 + [1280] * 30 + [640] * 6  # down 2x2 + 2x10, middle 10, up 3x10 + 3x2 transformer blocks
+    for i, c in enumerate(widths):
+        # on the meta device nothing checks these shapes, so the second dimension doubles as a TAG (2048 + 2 i for the key tensor,
+        # + 1 for the value tensor): reading the shapes back from the loaded adapter tells which file tensor landed where
+        out.append((f"ip_adapter.{i:03d}.to_k_ip.weight", (c, 2048 + 2 * i)))
+        out.append((f"ip_adapter.{i:03d}.to_v_ip.weight", (c, 2048 + 2 * i + 1)))
+    return out
+
+
+def control_lora_file(rank: int = 8):
+    """(key, shape) list of a ControlLora checkpoint in refiners' converted format: LoRA pairs for a few encoder-half layers
+    (real files adapt all of them at rank 128), the ten zero convolutions, the condition encoder."""
+    from refiners_amd import synth
+
+    out = []
+    sites = [("DownBlocks.Chain_5.SDXLCrossAttention.Chain_2.CrossAttentionBlock_1.Residual_1.SelfAttention.Distribute.Linear_1", (640, 640)),
+             ("DownBlocks.Chain_5.SDXLCrossAttention.Chain_2.CrossAttentionBlock_1.Residual_3.Linear_1", (5120, 640)),
+             ("DownBlocks.Chain_2.ResidualBlock.Chain.Conv2d", (320, 320, 3, 3)),
+             ("MiddleBlock.ResidualBlock_1.Chain.RangeAdapter2d.Conv2d", (1280, 1280, 3, 3))]
+    for path, w in sites:
+        if len(w) == 2:
+            out += [(f"ControlLora.{path}.down", (rank, w[1])), (f"ControlLora.{path}.up", (w[0], rank))]
+        else:
+            out += [(f"ControlLora.{path}.down", (rank, w[1], w[2], w[3])), (f"ControlLora.{path}.up", (w[0], rank, 1, 1))]
+    for i, c in enumerate(synth.CONTROL_SLOT_CHANNELS):
+        out += [(f"ZeroConvolution_{i + 1:02d}.Conv2d.weight", (c, c, 1, 1)), (f"ZeroConvolution_{i + 1:02d}.Conv2d.bias", (c,))]
+    for k, (co, ci) in synth.CONTROL_ENCODER_SHAPES.items():
+        out += [(f"ConditionEncoder.{k}.weight", (co, ci, 3, 3)), (f"ConditionEncoder.{k}.bias", (co,))]
+    return out

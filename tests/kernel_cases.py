@@ -627,6 +627,68 @@ def softmax_rows_case(M, L, Lp, dtype, seed=255):
     return _cmp(out, ref, dtype)
 
 
+def _lora_pack(K, N, dtype, ranks, seed, perm=None):
+    """(A32 K-blocked, sB [N, 32], dense reference delta [N, K] float32) of stacked LoRAs with scales 1.0, 0.8, ..."""
+    rt = sum(ranks)
+    a = torch.zeros(native.LORA_R, K, dtype=dtype, device=DEV)
+    bs = torch.zeros(N, native.LORA_R, dtype=dtype, device=DEV)
+    delta = torch.zeros(N, K, dtype=torch.float32, device=DEV)
+    o = 0
+    for i, r in enumerate(ranks):
+        d = _rand(r, K, dtype=dtype, seed=seed + 10 * i, scale=K ** -0.5)
+        u = _rand(N, r, dtype=dtype, seed=seed + 10 * i + 1, scale=0.5)
+        sc = 1.0 - 0.2 * i
+        a[o : o + r] = d
+        bs[:, o : o + r] = (u.float() * sc).to(dtype)
+        delta += bs[:, o : o + r].float() @ d.float()
+        o += r
+    assert rt <= native.LORA_R
+    if perm is not None:
+        bs = bs[perm].contiguous()
+    return native.KBlocked(a), bs, delta
+
+
+def gemm_lora_inlaunch_case(M, K, N, dtype, *, ranks=(16, 16), tile=0, geglu=False, transposed=False, seed=260):
+    """LoraAdapter as ONE launch: x A_cat^T in the parent's K loop, the pre-scaled up-projections as its last K step."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2)
+    perm = native.geglu_pack_index(N // 2, device=DEV) if geglu else None
+    a32, bs, delta = _lora_pack(K, N, dtype, ranks, seed + 3, perm)
+    full = x.float() @ (w.float() + delta).t() + b.float()
+    if transposed:
+        vt = torch.full((N, M), float("nan"), dtype=dtype, device=DEV)
+        native.gemm([(x, w)], None, bias=b, out_t=vt, nt_begin=0, lora=([(0, a32)], bs), tile=tile)
+        return _cmp(vt, full.t(), dtype)
+    if geglu:
+        out = torch.full((M, N // 2), float("nan"), dtype=dtype, device=DEV)
+        native.gemm([(x, native.KBlocked(w[perm].contiguous()))], out, bias=b[perm].contiguous(), geglu=True, lora=([(0, a32)], bs), tile=tile)
+        return _cmp(out, full[:, : N // 2] * torch.nn.functional.gelu(full[:, N // 2 :]), dtype)
+    r = _rand(M, N, dtype=dtype, seed=seed + 4)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, native.KBlocked(w))], out, bias=b, res=r, lora=([(0, a32)], bs), tile=tile)
+    out2 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, native.KBlocked(w))], out2, bias=b, res=r, lora=([(0, a32)], bs), tile=tile)
+    assert torch.equal(out, out2)
+    return _cmp(out, full + r.float(), dtype)
+
+
+def gemm_qkv_lora_case(M, K, Cc, dtype, tile=0, seed=270):
+    """Q | K | V^T from one launch with a different LoRA set per column group."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(3 * Cc, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    packs = [_lora_pack(K, Cc, dtype, (16, 16) if g != 1 else (8,), seed + 20 * (g + 1)) for g in range(3)]
+    bs = torch.cat([p_[1] for p_ in packs], 0).contiguous()
+    delta = torch.cat([p_[2] for p_ in packs], 0)
+    qk = torch.full((M, 2 * Cc), float("nan"), dtype=dtype, device=DEV)
+    vt = torch.full((Cc, M), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x, native.KBlocked(w))], qk, out_t=vt, nt_begin=2 * Cc, lora=([(0, packs[0][0]), (Cc, packs[1][0]), (2 * Cc, packs[2][0])], bs), tile=tile)
+    ref = x.float() @ (w.float() + delta).t()
+    e1 = _cmp(qk, ref[:, : 2 * Cc], dtype)
+    e2 = _cmp(vt, ref[:, 2 * Cc :].t(), dtype)
+    return max(e1[0], e2[0]), max(e1[1], e2[1]), e1[2]
+
+
 def all_cases():
     """(name, thunk) list; sizes chosen so the whole list runs in well under a minute on one MI355X."""
     cases = []
@@ -723,6 +785,14 @@ def all_cases():
             (f"gemm_{tag}_ln_chain_tiles_6_2", lambda dt=dt: gemm_ln_chain_case(300, 320, 384, dt, tile1=6, tile2=2)),
             (f"gemm_{tag}_ln_chain_tiles_5_3", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=5, tile2=3)),
             (f"gemm_{tag}_ln_chain_tiles_2_5", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=2, tile2=5)),
+            (f"gemm_{tag}_lora1_2048x1280x1280", lambda dt=dt: gemm_lora_inlaunch_case(2048, 1280, 1280, dt)),
+            (f"gemm_{tag}_lora1_rank8_tile4_edges", lambda dt=dt: gemm_lora_inlaunch_case(300, 640, 200, dt, ranks=(8,), tile=4)),
+            (f"gemm_{tag}_lora1_tile2", lambda dt=dt: gemm_lora_inlaunch_case(520, 320, 384, dt, ranks=(16, 4), tile=2)),
+            (f"gemm_{tag}_lora1_tile3", lambda dt=dt: gemm_lora_inlaunch_case(154, 2048, 640, dt, tile=3)),
+            (f"gemm_{tag}_lora1_geglu", lambda dt=dt: gemm_lora_inlaunch_case(512, 640, 2560, dt, geglu=True)),
+            (f"gemm_{tag}_lora1_transposed", lambda dt=dt: gemm_lora_inlaunch_case(154, 2048, 640, dt, transposed=True)),
+            (f"gemm_{tag}_qkv_lora_1024x1280", lambda dt=dt: gemm_qkv_lora_case(1024, 1280, 1280, dt)),
+            (f"gemm_{tag}_qkv_lora_tile4", lambda dt=dt: gemm_qkv_lora_case(512, 640, 384, dt, tile=4)),
             (f"wide_head_{tag}_384x512", lambda dt=dt: wide_head_attention_case(384, 512, dt)),
             (f"wide_head_{tag}_1024x512", lambda dt=dt: wide_head_attention_case(1024, 512, dt)),
             (f"softmax_rows_{tag}_vec", lambda dt=dt: softmax_rows_case(33, 1000, 1024, dt)),

@@ -1,5 +1,6 @@
 """SD1.5 ControlNet: CPU oracle and host mirror vs the real reference's SD1UNet +
-SD1ControlnetAdapter.  (Host side only: the engine refuses this tree loudly until its lowering exists.)"""
+SD1ControlnetAdapter; the engine's lowering of the tree is checked here as a dry run (meta device) and on the GPU in
+tests/test_engine_gpu.py::test_sd1_controlnet_on_the_engine."""
 import json
 
 import pytest
@@ -52,14 +53,27 @@ def test_controlnet_mirror_matches_reference(cn_inputs):
         y = unet(x)
     l2, mx = S.rel_err(y, gold["unet_out"])
     assert l2 < TOL and mx < TOL, (l2, mx)
-    # the engine must refuse this tree loudly rather than skip the branch
-    from refiners_amd.engine.lowering import UNetIO, UNetLowering, Unsupported
+    # dry lowering (meta device): the branch becomes launches -- 13 residual taps -- and nothing falls back; without its
+    # condition image the engine refuses loudly rather than skip the branch
+    from refiners_amd.engine.lowering import UNetIO, UNetLowering, Unsupported, launches
 
     dev = torch.device("meta")
-    io = UNetIO(x=torch.empty(1, 4, 16, 16, device=dev), timestep=torch.empty(1, device=dev), out=torch.empty(1, 4, 16, 16, device=dev))
-    io.tokens[("cross_attention_block", "clip_text_embedding")] = (torch.zeros(128, 768, device=dev), 77)
+
+    def io_for(with_condition: bool) -> UNetIO:
+        io = UNetIO(x=torch.empty(1, 4, 16, 16, device=dev), timestep=torch.empty(1, device=dev), out=torch.empty(1, 4, 16, 16, device=dev))
+        io.tokens[("cross_attention_block", "clip_text_embedding")] = (torch.zeros(128, 768, device=dev), 77)
+        if with_condition:
+            io.conditions["controlnet.condition_canny"] = torch.empty(1, 3, 128, 128, device=dev)
+        return io
+
     meta_unet = SD1UNet(4, device="meta")
+    bare = UNetLowering(dev, torch.float32, None, "merged")
+    bare.lower(meta_unet, io_for(False))
     SD1ControlnetAdapter(meta_unet, name="canny").inject()
+    low = UNetLowering(dev, torch.float32, None, "merged")
+    low.lower(meta_unet, io_for(True))
+    assert low.stats["controlnets"] == 1 and low.stats["fallback_nodes"] == []
+    assert launches(low.step) > launches(bare.step) + 13 and launches(low.prologue) >= 8  # the condition encoder runs once per image
     with pytest.raises(Unsupported):
-        UNetLowering(dev, torch.float32, None, "merged").lower(meta_unet, io)
+        UNetLowering(dev, torch.float32, None, "merged").lower(meta_unet, io_for(False))
     adapter.eject()

@@ -59,6 +59,43 @@ def test_broadcast_shard_gather_world2():
     assert s0 == s1 == 2.0
 
 
+def _worker_load(rank: int, world: int, port: int, path: str, q) -> None:
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd import parallel
+
+    parallel.init_from_env("gloo")
+    model = fl.Chain(fl.Linear(16, 32, device="meta"), fl.SiLU(), fl.Linear(32, 8, device="meta"))  # nobody materialises weights up front
+    n = parallel.load_and_broadcast(model, path if rank == 0 else "/nonexistent: only rank 0 reads the file", device="cpu")
+    q.put((rank, n, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().sum().item(), all(p.device.type == "cpu" for p in model.parameters())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_checkpoint_is_read_once_and_broadcast(tmp_path):
+    """next-3: rank 0 loads the safetensors file directly to its device, the others receive through the arena broadcast."""
+    from safetensors.torch import save_file
+
+    import refiners_amd.fluxion.layers as fl
+
+    torch.manual_seed(5)
+    ref = fl.Chain(fl.Linear(16, 32), fl.SiLU(), fl.Linear(32, 8))
+    path = tmp_path / "m.safetensors"
+    save_file({k: v.contiguous() for k, v in ref.state_dict().items()}, str(path))
+    want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).double().sum().item()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_load, args=(r, 2, port, str(path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(g[1] >= 1 and g[2] == want and g[3] for g in got), got
+
+
 def test_shard_range_covers_everything():
     from refiners_amd.parallel import shard_range
 

@@ -55,3 +55,48 @@ def test_chain_round_trips_through_safetensors_under_reference_keys(tmp_path):
     vae = SDXLAutoencoder(device="cpu").load_from_safetensors(path)
     got = vae.state_dict()
     assert list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+
+
+def test_ip_adapter_checkpoint_lands_where_the_reference_puts_it():
+    """`image_proj.*` + `ip_adapter.NNN.*` (image_prompt.py:395-410): the NNN-th pair of tensors -- in FILE order -- becomes the
+    key / value projection of the NNN-th text cross-attention.  The tensors' second dimension is a tag (golden_cases.ip_adapter_file),
+    so the shapes read back from the loaded adapter say which file tensor landed where; compared with the real reference's result."""
+    from refiners_amd.latent_diffusion.adapters import SDXLIPAdapter
+    from tests.golden_cases import ip_adapter_file, tagged
+
+    gold = json.loads((S.GOLD / "adapter_wire_sdxl.json").read_text())["ip_adapter"]
+    keys = ip_adapter_file()
+    assert [[k, list(s)] for k, s in keys] == gold["keys"]
+    unet = SDXLUNet(4, device="meta")
+    ad = SDXLIPAdapter(target=unet, clip_image_encoder=SimpleNamespace(output_dim=1024, embedding_dim=1280), weights=tagged(keys, device="meta"))
+    landed = [[i, list(sub.image_key_projection.weight.shape), list(sub.image_value_projection.weight.shape)] for i, sub in enumerate(ad.sub_adapters)]
+    assert landed == gold["landed"]
+    assert [[k, list(v.shape)] for k, v in ad.image_proj.state_dict().items()] == gold["image_proj_keys"]
+    # a SHUFFLED file keeps working as long as each index's key tensor precedes its value tensor (the format is positional)
+    swapped = dict(reversed(list(tagged(keys, device="meta").items())))
+    ad2 = SDXLIPAdapter(target=SDXLUNet(4, device="meta"), clip_image_encoder=SimpleNamespace(output_dim=1024, embedding_dim=1280), weights=swapped)
+    assert [list(s.image_key_projection.weight.shape) for s in ad2.sub_adapters] == [row[2] for row in gold["landed"]]  # reversed order -> value tensor first
+
+
+def test_control_lora_checkpoint_lands_where_the_reference_puts_it():
+    """`ControlLora.<path>.{down,up}` / `ZeroConvolution_NN.*` / `ConditionEncoder.*` (xl/control_lora.py:345-411)."""
+    from refiners_amd.latent_diffusion.adapters import ConditionEncoder, ControlLoraAdapter, ZeroConvolution
+    from tests.golden_cases import control_lora_file, tagged
+
+    gold = json.loads((S.GOLD / "adapter_wire_sdxl.json").read_text())["control_lora"]
+    keys = control_lora_file()
+    assert [[k, list(s)] for k, s in keys] == gold["keys"]
+    unet = SDXLUNet(4, device="meta")
+    cad = ControlLoraAdapter(name="canny", target=unet, scale=0.7, weights=tagged(keys, device="meta"))
+    cl = cad.control_lora
+    attached = [[a.get_path(), [list(lr.down.weight.shape) for lr in a.loras.values()], list(a.names)] for a in cl.layers(LoraAdapter)]
+    assert attached == gold["attached"]
+    assert [[list(z.state_dict()), [list(v.shape) for v in z.state_dict().values()]] for z in cl.layers(ZeroConvolution)] == gold["zero"]
+    assert [[k, list(v.shape)] for k, v in cl.ensure_find(ConditionEncoder).state_dict().items()] == gold["encoder"]
+    assert hashlib.sha256(re.sub(r"Lambda\(.*\)", "Lambda", repr(cl)).encode()).hexdigest() == gold["repr_sha256"]
+    # values: real tensors through the same path end up in the parameters they are keyed for
+    small = {k: torch.randn(shape) for k, shape in keys if k.startswith(("ZeroConvolution_03", "ConditionEncoder.Chain_1"))}
+    zc = list(cl.layers(ZeroConvolution))[2]
+    zc.to_empty(device="cpu")
+    zc.load_state_dict({k.removeprefix("ZeroConvolution_03."): v for k, v in small.items() if k.startswith("ZeroConvolution_03")})
+    assert torch.equal(zc.state_dict()["Conv2d.weight"], small["ZeroConvolution_03.Conv2d.weight"])
