@@ -14,7 +14,7 @@ import torch  # noqa: E402
 from safetensors.torch import save_file  # noqa: E402
 
 from refiners.foundationals.clip.image_encoder import CLIPImageEncoderH  # noqa: E402
-from refiners.foundationals.latent_diffusion.image_prompt import ImageProjection  # noqa: E402
+from refiners.foundationals.latent_diffusion.image_prompt import ImageProjection, IPAdapter, PerceiverResampler  # noqa: E402
 
 from refiners_amd import synth  # noqa: E402
 from tests.golden_cases import CLIP_IMAGE_CASE  # noqa: E402
@@ -34,8 +34,21 @@ def main() -> None:
         emb = enc(image)
         # IPAdapter._compute_clip_image_embedding + compute_clip_image_embedding (image_prompt.py:457-510), one image
         tokens = torch.cat((proj(torch.zeros_like(emb)), proj(emb)))
-    save_file({"embedding": emb.contiguous(), "clip_image_embedding": tokens.contiguous()}, str(GOLD / "clip_image_h.safetensors"))
-    print(tuple(emb.shape), tuple(tokens.shape), float(emb.std()), float(tokens.std()))
+    # fine-grained ("plus") adapter: penultimate-layer token grid -> PerceiverResampler (SDXL sizes, xl/image_prompt.py:43-53);
+    # the negative tokens come from an all-zero IMAGE (image_prompt.py:516-525)
+    grid = IPAdapter.convert_to_grid_features(enc)
+    res = PerceiverResampler(latents_dim=1280, num_attention_layers=4, num_attention_heads=20, head_dim=64, num_tokens=16, input_dim=1280, output_dim=2048, device="meta")
+    rshapes = synth.model_shapes(res)
+    keys = json.loads((GOLD / "clip_image_h_keys.json").read_text())
+    keys["perceiver"] = {k: list(v) for k, v in rshapes.items()}
+    (GOLD / "clip_image_h_keys.json").write_text(json.dumps(keys))
+    res.load_state_dict(synth.synth_state_dict(rshapes, CLIP_IMAGE_CASE["weight_seed"] + 2), assign=True)
+    with torch.no_grad():
+        feats = grid(image)
+        plus = torch.cat((res(grid(torch.zeros_like(image))), res(feats)))
+    save_file({"embedding": emb.contiguous(), "clip_image_embedding": tokens.contiguous(), "grid_features_sample": feats[:, ::16, ::16].contiguous(),
+               "plus_image_embedding": plus.contiguous()}, str(GOLD / "clip_image_h.safetensors"))
+    print(tuple(emb.shape), tuple(tokens.shape), float(emb.std()), float(tokens.std()), tuple(plus.shape), float(plus.std()), float((plus[0] - plus[1]).abs().mean()))
 
 
 if __name__ == "__main__":

@@ -20,6 +20,7 @@ import refiners_amd.fluxion.layers as fl
 from refiners_amd.fluxion.adapters import Adapter, Lora, LoraAdapter, auto_attach_loras
 from refiners_amd.fluxion.tree import Contexts, bump_epoch
 
+from .perceiver import PerceiverResampler, convert_to_grid_features  # noqa: F401  (re-exported: the fine-grained image projection)
 from .blocks import CrossAttentionBlock2d, RangeAdapter2d, ResidualAccumulator, ResidualBlock
 
 
@@ -131,6 +132,8 @@ class IPAdapter(fl.Chain, Adapter[fl.Chain]):
             super().__init__(target)
         self.fine_grained = fine_grained
         self._clip_image_encoder = [clip_image_encoder]
+        if fine_grained and isinstance(clip_image_encoder, fl.Chain):
+            self._grid_image_encoder = [convert_to_grid_features(clip_image_encoder)]
         self._image_proj = [image_proj]
         self.sub_adapters = [
             CrossAttentionAdapter(target=att, scale=scale)
@@ -174,11 +177,28 @@ class IPAdapter(fl.Chain, Adapter[fl.Chain]):
     def set_clip_image_embedding(self, image_embedding: Tensor) -> None:
         self.set_context("ip_adapter", {"clip_image_embedding": image_embedding})
 
+    @property
+    def grid_image_encoder(self) -> fl.Chain:
+        assert hasattr(self, "_grid_image_encoder"), "fine_grained needs a real CLIPImageEncoder to derive the grid encoder from"
+        return self._grid_image_encoder[0]
+
     def compute_clip_image_embedding(self, clip_embedding: Tensor) -> Tensor:
-        """[negative ; conditional] image tokens from an already-encoded CLIP embedding (the image encoder itself is
-        out of scope; reference image_prompt.py:497-525 for the non fine-grained path)."""
+        """[negative ; conditional] image tokens from an already-encoded CLIP embedding (reference image_prompt.py:497-525 for
+        the non fine-grained path; `compute_image_tokens` below runs the encoder too)."""
+        assert not self.fine_grained, "the fine-grained path encodes a ZERO IMAGE for the negative prompt: use compute_image_tokens(image)"
         cond = self.image_proj(clip_embedding)
         neg = self.image_proj(torch.zeros_like(clip_embedding))
+        return torch.cat((neg, cond))
+
+    def compute_image_tokens(self, image_prompt: Tensor) -> Tensor:
+        """IPAdapter._compute_clip_image_embedding + the final cat (image_prompt.py:497-525) on a preprocessed (B, 3, 224, 224)
+        tensor: plain adapters project the class embedding and an all-zero embedding; fine-grained ("plus") adapters resample
+        the penultimate layer's token grid of the image and of an ALL-ZERO IMAGE."""
+        if not self.fine_grained:
+            return self.compute_clip_image_embedding(self.clip_image_encoder(image_prompt))
+        enc = self.grid_image_encoder
+        cond = self.image_proj(enc(image_prompt))
+        neg = self.image_proj(enc(torch.zeros_like(image_prompt)))
         return torch.cat((neg, cond))
 
 
@@ -192,13 +212,19 @@ class SDXLIPAdapter(IPAdapter):
         fine_grained: bool = False,
         weights: dict[str, Tensor] | None = None,
     ) -> None:
-        assert not fine_grained, "the fine-grained (PerceiverResampler) image projection is out of scope (SURVEY.md 8(f))"
         if image_proj is None:
             xattn = target.ensure_find(CrossAttentionBlock2d)
-            image_proj = ImageProjection(
-                clip_image_embedding_dim=getattr(clip_image_encoder, "output_dim", 1024),
-                clip_text_embedding_dim=xattn.context_embedding_dim, device=target.device, dtype=target.dtype,
-            )
+            if not fine_grained:
+                image_proj = ImageProjection(
+                    clip_image_embedding_dim=getattr(clip_image_encoder, "output_dim", 1024),
+                    clip_text_embedding_dim=xattn.context_embedding_dim, device=target.device, dtype=target.dtype,
+                )
+            else:  # xl/image_prompt.py:43-53
+                image_proj = PerceiverResampler(
+                    latents_dim=1280, num_attention_layers=4, num_attention_heads=20, head_dim=64, num_tokens=16,
+                    input_dim=getattr(clip_image_encoder, "embedding_dim", 1280), output_dim=xattn.context_embedding_dim,
+                    device=target.device, dtype=target.dtype,
+                )
         super().__init__(target=target, clip_image_encoder=clip_image_encoder, image_proj=image_proj, scale=scale,
                          fine_grained=fine_grained, weights=weights)
 

@@ -98,3 +98,32 @@ def test_image_prompt_mirror_matches_reference(image_inputs):
     for got, want in ((emb, gold["embedding"]), (tokens, gold["clip_image_embedding"])):
         l2, mx = S.rel_err(got, want)
         assert l2 < TOL and mx < TOL, (l2, mx)
+
+
+def test_fine_grained_image_prompt_mirror_matches_reference(image_inputs):
+    """The "plus" IP-Adapter (image_prompt.py:81-234, 516-525, 553-564): grid-feature encoder + PerceiverResampler mirror vs
+    the REAL reference's (2, 16, 2048) tokens; state-dict keys equal to the reference's; SDXLIPAdapter(fine_grained=True) builds
+    the same resampler and computes the same tokens."""
+    from refiners_amd.clip_image import CLIPImageEncoderH
+    from refiners_amd.latent_diffusion.adapters import PerceiverResampler, SDXLIPAdapter, convert_to_grid_features
+    from refiners_amd.latent_diffusion.sdxl import SDXLUNet
+    from tests.golden_cases import CLIP_IMAGE_CASE
+
+    shapes, _, sd, _, image, gold = image_inputs
+    rshapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "clip_image_h_keys.json").read_text())["perceiver"].items()}
+    enc = CLIPImageEncoderH(device="meta")
+    enc.load_state_dict(sd, assign=True)
+    ad = SDXLIPAdapter(target=SDXLUNet(4, device="meta"), clip_image_encoder=enc, fine_grained=True)
+    res = ad.image_proj
+    assert isinstance(res, PerceiverResampler) and list(res.state_dict()) == list(rshapes) and {k: tuple(v.shape) for k, v in res.state_dict().items()} == rshapes
+    res.load_state_dict(synth.synth_state_dict(rshapes, CLIP_IMAGE_CASE["weight_seed"] + 2), assign=True)
+    grid = ad.grid_image_encoder
+    assert len(grid) == 3 and len(grid[-1]) == 31 and len(enc[2]) == 32  # a structural copy: the adapter's own encoder is untouched
+    with torch.no_grad():
+        feats = grid(image)
+        tokens = ad.compute_image_tokens(image)
+    l2, mx = S.rel_err(feats[:, ::16, ::16], gold["grid_features_sample"])
+    assert l2 < TOL and mx < TOL, (l2, mx)
+    l2, mx = S.rel_err(tokens, gold["plus_image_embedding"])
+    assert l2 < TOL and mx < TOL, (l2, mx)
+    assert next(convert_to_grid_features(enc).parameters()) is next(enc.parameters())  # structural_copy shares the weighted leaves, like the reference's

@@ -774,3 +774,34 @@ def test_sd1_controlnet_on_the_engine():
         y_ref = unet(x)
     l2, mx = S.rel_err(y2, y_ref)
     assert not torch.equal(y, y2) and l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+
+
+def test_fine_grained_image_prompt_on_the_engine():
+    """the "plus" IP-Adapter's image prompt -- grid-feature CLIP ViT-H (31 layers, no pooling) +
+    PerceiverResampler (image_prompt.py:81-234) -- on the native kernels: (2, 16, 2048) [zero-image ; image] tokens, float32 vs
+    the real reference's output, bf16 norm-wise; no torch node."""
+    import json
+
+    from refiners_amd.clip_image import CLIPImageEncoderH
+    from refiners_amd.engine.image_prompt import CompiledImagePromptPlus
+    from refiners_amd.latent_diffusion.adapters import PerceiverResampler, convert_to_grid_features
+    from tests.golden_cases import CLIP_IMAGE_CASE
+
+    keys = json.loads((S.GOLD / "clip_image_h_keys.json").read_text())
+    sd = S.synth.synth_state_dict({k: tuple(v) for k, v in keys["encoder"].items()}, CLIP_IMAGE_CASE["weight_seed"])
+    rsd = S.synth.synth_state_dict({k: tuple(v) for k, v in keys["perceiver"].items()}, CLIP_IMAGE_CASE["weight_seed"] + 2)
+    image = torch.randn((1, 3, 224, 224), generator=S.synth._gen("clip.image", CLIP_IMAGE_CASE["input_seed"])).cuda()
+    gold = S.golden("clip_image_h")["plus_image_embedding"]
+    for dtype, tol in ((torch.float32, F32_TOL), (torch.bfloat16, 3e-2)):
+        enc = CLIPImageEncoderH(device="meta")
+        enc.load_state_dict({k: v.to("cuda", dtype) for k, v in sd.items()}, assign=True)
+        res = PerceiverResampler(latents_dim=1280, num_attention_layers=4, num_attention_heads=20, head_dim=64, num_tokens=16, input_dim=1280, output_dim=2048, device="meta")
+        res.load_state_dict({k: v.to("cuda", dtype) for k, v in rsd.items()}, assign=True)
+        fast = CompiledImagePromptPlus(convert_to_grid_features(enc), res)
+        tokens = fast(image.to(dtype))
+        assert torch.equal(tokens, fast(image.to(dtype))) and fast.stats["fallback_nodes"] == []
+        l2, mx = S.rel_err(tokens.float().cpu(), gold)
+        print(f"fine-grained image prompt {dtype}: l2 {l2:.2e} max {mx:.2e} launches {fast.stats['step_ops']}")
+        assert l2 < tol and tuple(tokens.shape) == (2, 16, 2048), (dtype, l2, mx)
+        if dtype == torch.float32:
+            assert mx < tol
