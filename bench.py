@@ -94,6 +94,24 @@ def pmc_mfma_util(family: str):
         return None
 
 
+def program_entry(e) -> dict:
+    """One launch of the recorded step program: entry point + shape class (the key the in-place profile aggregates on)."""
+    from refiners_amd import native
+
+    fn, args, what, _ = e
+    a = getattr(args[0], "_obj", None)
+    what = what.split("@")[0]
+    if what.startswith("mi355x_gemm"):
+        return {"what": what, "key": native.gemm_signature(a) + (f":tile{a.tile}/{a.stages}" if a.tile else ""), "ksplit": int(a.ksplit)}
+    if what == "mi355x_attention":
+        return {"what": what, "key": f"attention:B{a.B}:H{a.H}:Lq{a.Lq}:Lk{a.kv[0].Lk}" + (f"+{a.kv[1].Lk}" if a.nstream > 1 else "")}
+    if what == "mi355x_layernorm":
+        return {"what": what, "key": f"layernorm:{a.M}x{a.C}"}
+    if what == "mi355x_groupnorm":
+        return {"what": what, "key": f"groupnorm:B{a.B}:HW{a.HW}:C{a.C}"}
+    return {"what": what, "key": what}
+
+
 def pmc_traffic(family: str):
     """HBM-side bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are
     separate profiler runs, they cannot be taken inside this process): FETCH_SIZE doubled per MI355X_MICROARCH.md, KiB -> B."""
@@ -252,6 +270,7 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational extras (configs[1] line, fused-LoRA line, VAE decode, 4-images-per-GPU point)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-family replay (profiler passes: the kernel table then holds the timed steps only)")
+    ap.add_argument("--dump-program", default=None, help="write the recorded step program (one entry per launch: entry point + shape class) as JSON: tools/profile_round.py")
     ap.add_argument("--lora-mode", choices=["fused", "merged"], default="merged",
                     help="merged: W' = W + sum s B A formed at lowering time (one launch per adapted layer); fused: run-time LoRA inside the parent launch")
     args = ap.parse_args()
@@ -285,6 +304,8 @@ def main() -> None:
 
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = world * n_img / (ms_per_step * 1e-3 * 50)
+    if args.dump_program:
+        Path(args.dump_program).write_text(json.dumps([program_entry(e) for e in pipe.engine.low.step if e[0] is not None]))
     roofline = None if args.no_roofline else family_roofline(pipe, args.workload, n_img, ms_per_step)
     stats = dict(pipe.engine.stats)
 

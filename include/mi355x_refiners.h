@@ -159,11 +159,15 @@ typedef struct {
        lora_a[g]: the 32 stacked down-projection rows of group g, K-BLOCKED: [K*sizeof/128][32][128 bytes]; lora_b: [N][32] row-major,
        the up-projections already multiplied by their scales (rows follow the same N-packing as w).  x A^T is accumulated in the
        same K loop as x W^T and rounded to `dtype` (the reference's intermediate tensor) before the up-projection step.
-       One segment, no conv / ksplit / ln_stats.  lora_b == NULL: off. */
+       One segment, no conv / ksplit.  lora_b == NULL: off.
+       With ln_stats (x un-normalised): lora_a carries gamma like w does (A' = A . diag(gamma)) and the caller adds
+         lora_ls[g][r] = sum_k A'_g[r][k],   lora_lc[g][r] = sum_k beta[k] A_g[r][k]        (float32, [groups][32]). */
     const void* lora_a[3];
     int32_t lora_nb[3];
     int32_t lora_groups;
     const void* lora_b;
+    const void* lora_ls;
+    const void* lora_lc;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

@@ -132,7 +132,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         p.ln_c = static_cast<const float*>(a->ln_c);
     }
     if (a->lora_b) {
-        if (a->conv || a->nseg != 1 || a->ksplit > 1 || a->ln_stats || a->out_f32 || a->lora_groups < 1 || a->lora_groups > 3 || a->lora_nb[0] != 0 || !aligned16(a->lora_b))
+        if (a->conv || a->nseg != 1 || a->ksplit > 1 || (a->ln_stats && (!a->lora_ls || !a->lora_lc)) || a->out_f32 || a->lora_groups < 1 || a->lora_groups > 3 || a->lora_nb[0] != 0 || !aligned16(a->lora_b))
             return MI355X_ESHAPE;
         for (int g = 0; g < a->lora_groups; ++g) {
             if (!a->lora_a[g] || !aligned16(a->lora_a[g]) || a->lora_nb[g] % 128 || (g && a->lora_nb[g] <= a->lora_nb[g - 1])) return MI355X_ESHAPE;
@@ -141,6 +141,8 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         }
         p.lora_groups = a->lora_groups;
         p.lora_b = static_cast<const char*>(a->lora_b);
+        p.lora_ls = static_cast<const float*>(a->lora_ls);
+        p.lora_lc = static_cast<const float*>(a->lora_lc);
     }
     if (a->out_f32) {
         if (a->conv || a->ksplit > 1 || a->geglu == 1 || has_t || a->stats_out || !a->out) return MI355X_ESHAPE;

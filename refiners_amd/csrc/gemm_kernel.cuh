@@ -90,6 +90,8 @@ struct GemmP {
     int lora_nb[3];
     int lora_groups;
     const char* lora_b;
+    const float* lora_ls;  // LayerNorm folded into this launch AND LoRA: [groups][32] sum_k A'[r][k] and
+    const float* lora_lc;  //                                            [groups][32] sum_k beta[k] A[r][k]
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
     const char* pf_ptr[MI355X_MAX_PREFETCH];
@@ -484,8 +486,25 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
         char* tl = smem;                // [BM rows in LDS order][LORA_R] of T
         char* bl = smem + BM * RB;      // [BN rows in LDS order][LORA_R] of T
         __syncthreads();                // every wave is done with the stage buffers
+        float lsa[4] = {0.f, 0.f, 0.f, 0.f}, lca[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.ln_stats) {  // x is un-normalised: t = rstd (x A'^T - mean sA) + cA; what goes through LDS is t / rstd, the epilogue's
+                           // rstd * (acc - mean s) + c then scales the up-projected product back (one rounding of t, as in the reference)
+            const int gi = (p.lora_groups > 1 && n0 >= p.lora_nb[1] ? 1 : 0) + (p.lora_groups > 2 && n0 >= p.lora_nb[2] ? 1 : 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lsa[e] = p.lora_ls[gi * LORA_R + 16 * wn + 4 * g + e];
+                lca[e] = p.lora_lc[gi * LORA_R + 16 * wn + 4 * g + e];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {  // lane holds t[LDS row wm*WME + 16 i + c16][rank 16 wn + 4 g + 0..3]
+            if (p.ln_stats) {
+                const int R = wm * WME + 16 * i + c16, rl = R % WME;
+                const int row = tr ? (R - rl) + 4 * MT * ((rl >> 2) & 3) + 4 * (rl >> 4) + (rl & 3) : R;  // tile row in m order (rowstat's index)
+                const float mean = rowstat[2 * row], inv = 1.0f / rowstat[2 * row + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tacc[i][e] = (tacc[i][e] - mean * lsa[e]) + lca[e] * inv;
+            }
             char* dst = tl + (wm * WME + 16 * i + c16) * RB + (16 * wn + 4 * g) * (int)sizeof(T);
             if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<f32x4*>(dst) = tacc[i];

@@ -328,7 +328,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, 
 }
 
 int g_gn_fused = 1;                       // A/B switch (mi355x_groupnorm_set_fused)
-int64_t g_gn_fused_max_bytes = 96 << 10;   // slab size up to which one workgroup per group set beats the three-kernel path (tools/probe_gn.py)
+int64_t g_gn_fused_max_bytes = 160 << 10;  // slab size up to which one workgroup per group set beats the three-kernel path (tools/probe_gn.py,
+                                           // profiles/r02_c_probe_gn.log: 29.6 -> 20.6 us at 80 KB, 49.9 -> 34.8 at 160 KB, a loss from 240 KB up)
 
 inline int gn_ppc(int B, int HW, int C, int es) {
     const int nv = C * es / 16;

@@ -470,11 +470,14 @@ class Lowering:
         if out is None:
             out = self.pool.get(M, n_cols)
         if ln is not None:
-            assert spec.lora is None
             stats, node = ln
             wl, ls, lc = self.ln_fold(spec, node)
+            lo = None
+            if spec.lora is not None:  # LayerNorm AND the LoRAs inside the parent launch
+                al, als, alc = self.ln_fold_lora(spec.lora, node)
+                lo = ([(0, al)], spec.lora.bs32, als, alc)
             native.gemm([(x, self.kblocked(wl))], out, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, ln=(stats, ls, lc, float(node.eps)),
-                        stats_out=stats_out)
+                        stats_out=stats_out, lora=lo)
             return out
         if spec.lora is not None and spec.lora.a32 is not None and self.lora_inlaunch and not isinstance(x, native.KBlocked):
             # LoraAdapter = Sum(target, loras) as ONE launch: x A_cat^T rides in the parent's K loop, the up-projections are its last K step
@@ -514,7 +517,24 @@ class Lowering:
         return self.cache.get(key, make)
 
     def ln_fusable(self, stats: Optional[Tensor], *specs: LinSpec) -> bool:
-        return (stats is not None and self.ln_fuse and self.device.type != "meta" and all(sp.lora is None and sp.N % 64 == 0 and sp.K % 64 == 0 for sp in specs))
+        """LayerNorm can ride in the consumer launch when every consumer is a plain Linear or carries its LoRAs in-launch."""
+        ok_lora = lambda sp: sp.lora is None or (sp.lora.a32 is not None and self.lora_inlaunch)  # noqa: E731
+        return (stats is not None and self.ln_fuse and self.device.type != "meta" and all(ok_lora(sp) and sp.N % 64 == 0 and sp.K % 64 == 0 for sp in specs))
+
+    def ln_fold_lora(self, lora: LoraPack, node: Any) -> tuple[Any, Tensor, Tensor]:
+        """(A' K-blocked, sA [32], cA [32]) of the stacked down-projections behind a folded LayerNorm (see ln_fold)."""
+        a = lora.a32.dense()
+        key = ("ln_fold_lora",) + PackCache.ident(lora.a_cat, node.weight, node.bias)
+
+        def make() -> tuple[Any, Tensor, Tensor]:
+            a32 = a.detach().to(self.device, torch.float32)
+            g32 = node.weight.detach().to(self.device, torch.float32)
+            al = (a32 * g32.unsqueeze(0)).to(self.dtype).contiguous()
+            ls = al.to(torch.float32).sum(dim=1).contiguous()
+            lc = (a32 @ node.bias.detach().to(self.device, torch.float32)).contiguous() if node.bias is not None else torch.zeros_like(ls)
+            return native.KBlocked(al), ls, lc
+
+        return self.cache.get(key, make)
 
     def row_stats(self, M: int, C: int) -> Optional[Tensor]:
         """The [C / 32][M][2] float32 buffer a producing GEMM's epilogue fills with per-row (mean, M2) partials.  One per (M, C):
@@ -755,7 +775,13 @@ class Lowering:
             vt = self.pool.get(C, M)
             if fold:
                 wl, ls, lc = self.ln_fold(wqkv, ln)
-                native.gemm([(h, self.kblocked(wl))], qk, out_t=vt, nt_begin=2 * C, ln=(stats, ls, lc, float(ln.eps)))
+                lo = None
+                if not no_lora:
+                    packs = [self.ln_fold_lora(sp.lora, ln) for sp in (qs, ks, vs)]
+                    bs = self.cache.get(("qkv_bs",) + PackCache.ident(qs.lora.bs32, ks.lora.bs32, vs.lora.bs32), lambda: torch.cat([qs.lora.bs32, ks.lora.bs32, vs.lora.bs32], 0).contiguous())
+                    lsc = self.cache.get(("qkv_lsc",) + PackCache.ident(*[t for pk in packs for t in pk[1:]]), lambda: (torch.cat([pk[1] for pk in packs]).contiguous(), torch.cat([pk[2] for pk in packs]).contiguous()))
+                    lo = ([(0, packs[0][0]), (C, packs[1][0]), (2 * C, packs[2][0])], bs, lsc[0], lsc[1])
+                native.gemm([(h, self.kblocked(wl))], qk, out_t=vt, nt_begin=2 * C, ln=(stats, ls, lc, float(ln.eps)), lora=lo)
             elif no_lora:
                 native.gemm([(h, self.kblocked(wqkv.w))], qk, out_t=vt, nt_begin=2 * C)
             else:  # three LoRA sets in one launch: a stacked-down block per column group, the up rows stacked like the weights
@@ -765,8 +791,8 @@ class Lowering:
         else:
             # The V^T projection and the packed Q|K projection read the same h and do not depend on each other; neither fills the
             # chip at a CFG pair's 2048 rows, so V^T may be issued on the side stream (native.side_branch) and joined before attention.
-            if fold and not (native_path and L % 64 == 0):
-                h, lnarg, fold = self.layernorm(x, ln), None, False  # the per-sample / torch V paths want a materialised h
+            if fold and (not (native_path and L % 64 == 0) or not no_lora):
+                h, lnarg, fold = self.layernorm(x, ln), None, False  # the per-sample / torch V paths (and separate LoRA launches) want a materialised h
             concurrent = native_path and self.side_branches and vs.lora is None and not fold
             if concurrent:
                 native.fork()

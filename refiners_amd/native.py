@@ -137,6 +137,8 @@ class GemmArgs(C.Structure):
         ("lora_nb", C.c_int32 * 3),
         ("lora_groups", C.c_int32),
         ("lora_b", C.c_void_p),
+        ("lora_ls", C.c_void_p),
+        ("lora_lc", C.c_void_p),
     ]
 
 
@@ -575,12 +577,17 @@ def gemm(
         assert out is not None and out.dtype == torch.float32
         a.out_f32 = 1
     if lora is not None:  # ([(first column of the group, K-blocked stacked down rows [32, K])], pre-scaled up rows [N, 32]): LoRA inside this launch
-        groups, lb = lora
+        groups, lb = lora[0], lora[1]
         assert 1 <= len(groups) <= 3 and lb.dim() == 2 and lb.shape == (a.N, LORA_R) and lb.is_contiguous() and lb.dtype == x0.dtype
         for g, (nb, la) in enumerate(groups):
             assert isinstance(la, KBlocked) and la.shape == (LORA_R, tuple(x0.shape)[1]) and la.dtype == x0.dtype
             a.lora_a[g], a.lora_nb[g] = la.data_ptr(), nb
         a.lora_groups, a.lora_b = len(groups), lb.data_ptr()
+        if len(lora) > 2:  # (.., sA [groups, 32], cA [groups, 32]) float32: LayerNorm folded into this launch as well
+            ls_, lc_ = lora[2], lora[3]
+            assert ln is not None and ls_.dtype == torch.float32 and lc_.dtype == torch.float32 and ls_.is_contiguous() and lc_.is_contiguous()
+            assert ls_.numel() == len(groups) * LORA_R and lc_.numel() == len(groups) * LORA_R
+            a.lora_ls, a.lora_lc = ls_.data_ptr(), lc_.data_ptr()
         keep.append(lora)
     if ln is not None:
         stats, ls, lc, eps = ln

@@ -689,6 +689,35 @@ def gemm_qkv_lora_case(M, K, Cc, dtype, tile=0, seed=270):
     return max(e1[0], e2[0]), max(e1[1], e2[1]), e1[2]
 
 
+def gemm_ln_lora_case(M, Cc, N2, dtype, *, tile=0, transposed=False, seed=280):
+    """LayerNorm AND the LoRAs folded into ONE launch: y = LN(x) W^T + b + sum s (LN(x) A^T) B^T from the un-normalised x."""
+    x = _rand(M, Cc, dtype=dtype, seed=seed) + 1.5
+    gamma = (1 + 0.2 * _rand(Cc, dtype=torch.float32, seed=seed + 4)).float()
+    beta = (0.3 * _rand(Cc, dtype=torch.float32, seed=seed + 5)).float()
+    w2 = _rand(N2, Cc, dtype=dtype, seed=seed + 6, scale=Cc ** -0.5)
+    b2 = _rand(N2, dtype=dtype, seed=seed + 7)
+    a32, bs, delta = _lora_pack(Cc, N2, dtype, (16, 16), seed + 8)
+    stats = _stats_ref(x.float()).to(DEV)
+    eps = 1e-5
+    h = torch.nn.functional.layer_norm(x.float(), (Cc,), gamma, beta, eps)
+    full = h @ (w2.float() + delta).t() + b2.float()
+    wl = (w2.float() * gamma.unsqueeze(0)).to(dtype).contiguous()
+    ls, lc = wl.float().sum(1).contiguous(), (w2.float() @ beta + b2.float()).contiguous()
+    a = a32.dense().float()
+    al = (a * gamma.unsqueeze(0)).to(dtype).contiguous()
+    als, alc = al.float().sum(1).contiguous(), (a @ beta).contiguous()
+    lo = ([(0, native.KBlocked(al))], bs, als, alc)
+    if transposed:
+        out_t = torch.full((N2, M), float("nan"), dtype=dtype, device=DEV)
+        native.gemm([(x, wl)], None, out_t=out_t, nt_begin=0, ln=(stats, ls, lc, eps), lora=lo, tile=tile)
+        e = _cmp(out_t, full.t(), dtype)
+    else:
+        out = torch.full((M, N2), float("nan"), dtype=dtype, device=DEV)
+        native.gemm([(x, native.KBlocked(wl))], out, ln=(stats, ls, lc, eps), lora=lo, tile=tile)
+        e = _cmp(out, full, dtype)
+    return e[0], e[1], e[2] * (2.0 if dtype == torch.bfloat16 else 1.0)
+
+
 def all_cases():
     """(name, thunk) list; sizes chosen so the whole list runs in well under a minute on one MI355X."""
     cases = []
@@ -793,6 +822,9 @@ def all_cases():
             (f"gemm_{tag}_lora1_transposed", lambda dt=dt: gemm_lora_inlaunch_case(154, 2048, 640, dt, transposed=True)),
             (f"gemm_{tag}_qkv_lora_1024x1280", lambda dt=dt: gemm_qkv_lora_case(1024, 1280, 1280, dt)),
             (f"gemm_{tag}_qkv_lora_tile4", lambda dt=dt: gemm_qkv_lora_case(512, 640, 384, dt, tile=4)),
+            (f"gemm_{tag}_ln_lora_1024x1280", lambda dt=dt: gemm_ln_lora_case(1024, 1280, 1280, dt)),
+            (f"gemm_{tag}_ln_lora_tile4", lambda dt=dt: gemm_ln_lora_case(300, 640, 384, dt, tile=4)),
+            (f"gemm_{tag}_ln_lora_transposed_tile3", lambda dt=dt: gemm_ln_lora_case(512, 640, 256, dt, tile=3, transposed=True)),
             (f"wide_head_{tag}_384x512", lambda dt=dt: wide_head_attention_case(384, 512, dt)),
             (f"wide_head_{tag}_1024x512", lambda dt=dt: wide_head_attention_case(1024, 512, dt)),
             (f"softmax_rows_{tag}_vec", lambda dt=dt: softmax_rows_case(33, 1000, 1024, dt)),

@@ -103,3 +103,41 @@ def test_shard_range_covers_everything():
         for world in (1, 2, 3, 8):
             idx = [i for r in range(world) for i in shard_range(n, r, world)]
             assert idx == list(range(n))
+
+
+def _worker_nccl(rank: int, world: int, port: int, q) -> None:
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd import parallel
+
+    parallel.init_from_env("nccl")
+    dev = torch.device("cuda", rank)
+    torch.manual_seed(100 + rank)
+    model = fl.Chain(fl.Linear(256, 512, device=dev, dtype=torch.bfloat16), fl.SiLU(), fl.Linear(512, 128, device=dev, dtype=torch.bfloat16))
+    n = parallel.broadcast_module(model, src=0, bucket_bytes=64 << 10)
+    digest = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()]).double().sum().item()
+    aligned = all(p.data_ptr() % 256 == 0 for p in model.parameters())  # the arena keeps the kernels' 16-byte (here 256-byte) alignment
+    allx = parallel.gather_latents(torch.full((1 + rank, 4, 2, 2), float(rank), device=dev), dst=0)
+    q.put((rank, n, digest, aligned, None if allx is None else allx[:, 0, 0, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_broadcast_and_gather_over_rccl_world2():
+    """The same path with backend nccl (= RCCL over xGMI) on two GPUs of one node; skipped on single-GPU boxes."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nccl, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, n0, d0, a0, all0), (r1, n1, d1, a1, all1) = got
+    assert n0 == n1 and n0 >= 1 and d0 == d1 and a0 and a1
+    assert all0 == [0.0, 1.0, 1.0] and all1 is None

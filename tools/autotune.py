@@ -49,6 +49,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="lora_ip")
     ap.add_argument("--images", type=int, default=1)
+    ap.add_argument("--lora-mode", default="merged")
     ap.add_argument("--out", default=str(tuning.TABLE_PATH))
     ap.add_argument("--merge", action="store_true", help="keep the entries of an existing table for shapes this run does not see")
     ap.add_argument("--min-share", type=float, default=0.004, help="classes below this share of the step are tuned on their own replay")
@@ -59,7 +60,7 @@ def main() -> None:
     dev = torch.device("cuda", 0)
     native.load()
     t_start = time.time()
-    unet, specs, bare_sd, pipe, _ = bench.build_pipeline(args.workload, args.images, 0, dev, torch.bfloat16, "merged", use_graph=False, broadcast=False)
+    unet, specs, bare_sd, pipe, _ = bench.build_pipeline(args.workload, args.images, 0, dev, torch.bfloat16, args.lora_mode, use_graph=False, broadcast=False)
     pipe.step(0)
     torch.cuda.synchronize()
     ops = pipe.engine.low.step
@@ -137,7 +138,8 @@ def main() -> None:
            "workload": args.workload, "images_per_gpu": args.images, "baseline_ms": round(base, 4), "tuned_ms": round(final, 4), "choices": table, "log": log}
     Path(args.out).write_text(json.dumps(out, indent=1))
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
-    (ROOT / "gpurun_out" / "autotune_log.json").write_text(json.dumps(out, indent=1))
+    (ROOT / "gpurun_out" / f"autotune_log_{args.lora_mode}_{args.workload}_{args.images}.json").write_text(json.dumps(out, indent=1))
+    (ROOT / "gpurun_out" / "tuning_gfx950.json").write_text(json.dumps({k: out[k] for k in ("device", "how", "choices")}, indent=1))
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ def main():
         lib.mi355x_groupnorm_set_fused(1, 1 << 30)
         line += f"  fused {timeit(lambda: native.groupnorm_nhwc(x, g, b, 32, 1e-5, True, o)):7.1f} us"
         print(line, flush=True)
-    lib.mi355x_groupnorm_set_fused(1, 96 << 10)
+    lib.mi355x_groupnorm_set_fused(1, 160 << 10)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,225 @@
+"""Round profile on the GPU box: rocprofv3 kernel trace of the timed steps of bench.py (the final build, no extras) + separate PMC
+passes (HBM-side traffic, MFMA utilisation, SQ wait / issue breakdown), folded into the files that get committed under profiles/:
+
+  <tag>_bench_rocprof_kernel_stats.md   per-kernel table of the traced run (tools/rocpd_stats.py)
+  <tag>_inplace_by_shape.md/.json       every launch of one step mapped back to its program entry: time per (entry point, shape) IN PLACE
+  <tag>_pmc_traffic.json                FETCH_SIZE / WRITE_SIZE per family (what bench.py's roofline.traffic reads)
+  <tag>_pmc_mfma.json                   SQ_VALU_MFMA_BUSY_CYCLES vs SQ_BUSY_CYCLES per family (roofline.mfma_util)
+  <tag>_pmc_sq.json                     SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY / LDS conflicts per family
+
+    python tools/profile_round.py --tag r02_d [--workload lora_ip] [--skip-pmc]
+Counter passes use --kernel-trace only (never combined with sys / hip / hsa tracing)."""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import re
+import sqlite3
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "gpurun_out"
+
+
+def run(cmd: list[str], log: Path) -> int:
+    env = dict(os.environ, TMPDIR="/tmp")
+    with open(log, "w") as f:
+        return subprocess.call(cmd, stdout=f, stderr=subprocess.STDOUT, cwd="/tmp", env=env)
+
+
+def find_db(d: Path) -> str | None:
+    dbs = sorted(glob.glob(str(d / "**" / "*.db"), recursive=True), key=os.path.getmtime)
+    return dbs[-1] if dbs else None
+
+
+def family(kernel: str) -> str | None:
+    m = re.search(r"gemm_kernelI\w+?Li\d+ELi\d+ELi\d+ELi\d+ELb([01])E", kernel)
+    if m:
+        return "mi355x_gemm(conv)" if m.group(1) == "1" else "mi355x_gemm"
+    if "splitk_reduce_kernel" in kernel:
+        return "mi355x_gemm(conv)"
+    if "attn_kernel" in kernel or "attn_general_kernel" in kernel:
+        return "mi355x_attention"
+    if "layernorm_kernel" in kernel:
+        return "mi355x_layernorm"
+    if re.search(r"gn_(partial|finalize|apply|fused)_kernel", kernel):
+        return "mi355x_groupnorm"
+    return None
+
+
+def columns(con: sqlite3.Connection, table: str) -> list[str]:
+    return [r[1] for r in con.execute(f"pragma table_info({table})")]
+
+
+def kernel_rows(db: str) -> list[tuple[str, int, int]]:
+    con = sqlite3.connect(db)
+    cols = columns(con, "kernels")
+    start = "start" if "start" in cols else ("start_timestamp" if "start_timestamp" in cols else None)
+    if start is None:
+        raise RuntimeError(f"kernels view has columns {cols}")
+    return [(n, int(s), int(d)) for n, s, d in con.execute(f"select name, {start}, duration from kernels order by {start}")]
+
+
+def inplace(db: str, program: list[dict], tag: str) -> None:
+    rows = kernel_rows(db)
+    ours = [(n, s, d) for n, s, d in rows if "mi355x" in n or family(n) or "_kernel" in n and "at::" not in n]
+    ends = [i for i, (n, _, _) in enumerate(ours) if "cfg_ddim_kernel" in n or "cfg_linear_step_kernel" in n]
+    if len(ends) < 3:
+        print("in-place mapping: could not find the per-step boundary kernels", file=sys.stderr)
+        return
+    period = ends[-1] - ends[-2]
+    steps = []
+    for e in ends[-4:]:
+        if e - period + 1 >= 0:
+            steps.append(ours[e - period + 1 : e + 1])
+    per_class: dict[str, list[float]] = {}
+    used_steps = 0
+    for st in steps:
+        i = 0
+        ok = True
+        acc: dict[str, float] = {}
+        for ent in program:
+            what = ent["what"]
+            if i >= len(st):
+                ok = False
+                break
+            fam_want = what
+            dur = 0.0
+            n, _, d = st[i]
+            if what.startswith("mi355x_gemm"):
+                if "gemm_kernel" not in n:
+                    ok = False
+                    break
+                dur += d
+                i += 1
+                if i < len(st) and "splitk_reduce_kernel" in st[i][0] and ent.get("ksplit", 1) > 1:
+                    dur += st[i][2]
+                    i += 1
+            elif what == "mi355x_groupnorm":
+                if "gn_fused_kernel" in n:
+                    dur += d
+                    i += 1
+                else:
+                    for _ in range(3):
+                        dur += st[i][2]
+                        i += 1
+            else:
+                dur += d
+                i += 1
+            acc.setdefault(ent["key"], 0.0)
+            acc[ent["key"]] += dur
+        if ok:
+            used_steps += 1
+            for k, v in acc.items():
+                per_class.setdefault(k, []).append(v)
+    if not used_steps:
+        print("in-place mapping: program / trace mismatch", file=sys.stderr)
+        return
+    counts: dict[str, int] = {}
+    for ent in program:
+        counts[ent["key"]] = counts.get(ent["key"], 0) + 1
+    table = sorted(((k, sum(v) / len(v) / 1e6, counts[k]) for k, v in per_class.items()), key=lambda r: -r[1])
+    total = sum(r[1] for r in table)
+    lines = [f"in-place time per (entry point, shape) class, mean of {used_steps} traced steps; sum of kernel durations {total:.3f} ms per step", "",
+             "| class | launches | ms per step | us per launch | % |", "|---|---|---|---|---|"]
+    for k, ms, n in table:
+        lines.append(f"| `{k}` | {n} | {ms:.4f} | {ms / n * 1e3:.2f} | {100 * ms / total:.1f} |")
+    (OUT / f"{tag}_inplace_by_shape.md").write_text("\n".join(lines) + "\n")
+    (OUT / f"{tag}_inplace_by_shape.json").write_text(json.dumps({"steps": used_steps, "sum_ms": total, "classes": [{"class": k, "launches": n, "ms": ms} for k, ms, n in table]}, indent=1))
+    print("\n".join(lines[:24]))
+
+
+def pmc_families(db: str) -> dict:
+    con = sqlite3.connect(db)
+    out: dict = {}
+    for name, counter, n, total, dur in con.execute("select name, counter_name, count(*), sum(counter_value), avg(duration) from pmc_events group by name, counter_name"):
+        f = family(name)
+        if f is None:
+            continue
+        d = out.setdefault(f, {}).setdefault(counter, {"dispatches": 0, "sum": 0.0})
+        d["dispatches"] += n
+        d["sum"] += total
+    return out
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--workload", default="lora_ip")
+    ap.add_argument("--skip-pmc", action="store_true")
+    args = ap.parse_args()
+    OUT.mkdir(exist_ok=True)
+    tag = args.tag
+    prof = OUT / f"{tag}_prof"
+    prof.mkdir(exist_ok=True)
+    bench = [sys.executable, str(ROOT / "bench.py"), "--workload", args.workload, "--no-cpu-baseline", "--no-extra", "--no-roofline", "--no-graph"]
+    prog_path = prof / "program.json"
+    # 1. kernel trace of the timed steps
+    rc = run(["rocprofv3", "--kernel-trace", "--stats", "-d", str(prof / "kt"), "--", *bench, "--steps", "5", "--warmup", "2", "--dump-program", str(prog_path)], prof / "kt.log")
+    db = find_db(prof / "kt")
+    print("kernel trace rc", rc, "db", db)
+    if db:
+        subprocess.call([sys.executable, str(ROOT / "tools" / "rocpd_stats.py"), db, str(OUT / f"{tag}_bench_rocprof_kernel_stats.md")], stdout=subprocess.DEVNULL)
+        if prog_path.exists():
+            inplace(db, json.loads(prog_path.read_text()), tag)
+    if args.skip_pmc:
+        return
+    how = "rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-roofline --no-graph (one pass per counter set)" % args.workload
+    passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
+              "sq": ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES"]}
+    got: dict[str, dict] = {}
+    for name, counters in passes.items():
+        rc = run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", str(prof / name), "--", *bench, "--steps", "2", "--warmup", "1"], prof / f"{name}.log")
+        db = find_db(prof / name)
+        print("pmc pass", name, "rc", rc, "db", db)
+        if db:
+            try:
+                got[name] = pmc_families(db)
+            except Exception as exc:  # noqa: BLE001
+                print("  failed to read", exc)
+    if "fetch" in got and "write" in got:
+        fams = {}
+        for f in set(got["fetch"]) | set(got["write"]):
+            fams[f] = {}
+            for counter, src in (("FETCH_SIZE", got["fetch"]), ("WRITE_SIZE", got["write"])):
+                d = src.get(f, {}).get(counter)
+                if d:
+                    calls = d["dispatches"]
+                    kb = d["sum"] / calls
+                    fams[f][counter] = {"dispatches": calls, "raw_kb_per_launch": kb, "bytes_per_launch": kb * 1024 * (2 if counter == "FETCH_SIZE" else 1)}
+        (OUT / f"{tag}_pmc_traffic.json").write_text(json.dumps({"how": how, "units": "counter values are KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); per KERNEL dispatch (GroupNorm: per kernel, not per call)", "families": fams}, indent=1))
+        print({f: {c: round(v["bytes_per_launch"] / 1e6, 2) for c, v in cs.items()} for f, cs in fams.items()})
+    if "mfma" in got:
+        fams = {}
+        for f, cs in got["mfma"].items():
+            busy, sq, waves = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("sum"), cs.get("SQ_BUSY_CYCLES", {}).get("sum"), cs.get("SQ_WAVE_CYCLES", {}).get("sum")
+            gui = cs.get("GRBM_GUI_ACTIVE", {}).get("sum")
+            row = {"dispatches": next(iter(cs.values()))["dispatches"], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sq, "SQ_WAVE_CYCLES": waves, "GRBM_GUI_ACTIVE": gui}
+            if busy and gui:
+                # MFMA-busy cycles are summed over the chip's 1024 SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE = cycles the GPU was busy with the kernel
+                row["mfma_busy_per_simd_over_gpu_active"] = busy / (gui * 1024.0)
+            if busy and sq:
+                row["mfma_busy_over_sq_busy"] = busy / sq
+            fams[f] = row
+        (OUT / f"{tag}_pmc_mfma.json").write_text(json.dumps({"how": how, "note": "mfma_busy_per_simd_over_gpu_active = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): fraction of SIMD-cycles with the matrix pipe busy", "families": fams}, indent=1))
+        print({f: {k: (round(v, 4) if isinstance(v, float) and v < 10 else v) for k, v in r.items()} for f, r in fams.items()})
+    if "sq" in got:
+        fams = {}
+        for f, cs in got["sq"].items():
+            w = cs.get("SQ_WAVE_CYCLES", {}).get("sum") or 0
+            row = {c: d["sum"] for c, d in cs.items()}
+            if w:
+                for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                    if c in cs:
+                        row[c + "_frac_of_wave_cycles"] = cs[c]["sum"] / w
+            fams[f] = row
+        (OUT / f"{tag}_pmc_sq.json").write_text(json.dumps({"how": how, "families": fams}, indent=1))
+        print({f: {k: round(v, 3) for k, v in r.items() if k.endswith("frac_of_wave_cycles")} for f, r in fams.items()})
+
+
+if __name__ == "__main__":
+    main()
