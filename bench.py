@@ -89,7 +89,8 @@ def pmc_mfma_util(family: str):
     try:
         f = sorted((ROOT / "profiles").glob("r*_pmc_mfma.json"))[-1]
         fam = json.loads(f.read_text())["families"][family]
-        return dict(fam, source=f"profiles/{f.name}")
+        return {"mfma_util": round(fam["mfma_util"], 4), "SQ_VALU_MFMA_BUSY_CYCLES": fam["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": fam["GRBM_GUI_ACTIVE"],
+                "dispatches": fam["dispatches"], "source": f"profiles/{f.name}"}
     except Exception:  # noqa: BLE001 -- no committed pass
         return None
 

@@ -332,6 +332,17 @@ int mi355x_axpby(int32_t dtype, const void* a, float alpha, const void* b, float
  * the second GEMM).  s: float32 rows of stride lds; out: `dtype` rows of stride ldo.  Bit-reproducible. */
 int mi355x_softmax_rows(int32_t dtype, const float* s, int64_t lds, void* out, int64_t ldo, int64_t M, int32_t L, int32_t Lp, float scale,
                         void* stream);
+/* Self-Attention Guidance (src/refiners/foundationals/latent_diffusion/self_attention_guidance.py:22-105, xl/model.py:164-250).
+ * mi355x_colsum_rows: acc[j] (+)= scale * sum_{i < M} p[i*ldp + j], j < L  -- the attention mass a key receives from all queries of
+ *   one head (p = that head's softmax probabilities from mi355x_softmax_rows); heads are summed by consecutive launches with
+ *   accumulate = 1 and scale = 1 / heads, giving attn_map.mean(dim=1).sum(dim=1) of SAGAdapter.compute_sag_mask (:72-84).
+ * mi355x_sag_degrade: compute_degraded_latents (:86-95) in one kernel: x0 = (x - coef[2]*eps) / coef[1] (Solver.remove_noise), k x k
+ *   Gaussian blur with reflect padding (separable weights w1[ksize], fluxion/utils.py:65-113) where mass[b][cell] > 1 (cell = the
+ *   nearest-neighbour (ah, aw) attention cell of the pixel), then coef[1] * (.) + coef[2] * eps (Solver.add_noise).
+ *   x, eps, out: [n][C][h][w] contiguous; mass: float32 [n][ah*aw]; coef: device floats, the step's row of the CFG+DDIM table. */
+int mi355x_colsum_rows(int32_t dtype, const void* p, int64_t ldp, int32_t M, int32_t L, float* acc, int32_t accumulate, float scale, void* stream);
+int mi355x_sag_degrade(int32_t dtype, const void* x, const void* eps, const float* mass, int32_t ah, int32_t aw, const float* coef, const float* w1,
+                       int32_t ksize, void* out, int32_t n, int32_t C, int32_t h, int32_t w, void* stream);
 /* out = silu(x) over n elements. */
 int mi355x_silu(int32_t dtype, const void* x, void* out, int64_t n, void* stream);
 

@@ -1,0 +1,55 @@
+"""Golden vector for Self-Attention Guidance: the REAL reference's StableDiffusion_XL.forward with
+`set_self_attention_guidance(True, scale)` -- CFG pass, attention-map mask, blurred / re-noised latents, second UNet pass,
+guidance, DDIM update -- on synthetic weights, CPU float32, one step at 32x32 latents (the tapped attention sees 8x8 = 64 tokens).
+With and without the IP-Adapter (the reference halves the image embedding for the second pass, xl/model.py:240-246).
+Run in the build container only:  python oracle/make_golden_sag.py"""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT / "oracle" / "shim"), "/root/reference/src", str(ROOT)]
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+import refiners.fluxion.layers as rfl  # noqa: E402
+from refiners.foundationals.latent_diffusion.solvers import DDIM  # noqa: E402
+from refiners.foundationals.latent_diffusion.stable_diffusion_xl.model import StableDiffusion_XL  # noqa: E402
+from refiners.foundationals.latent_diffusion.stable_diffusion_xl.unet import SDXLUNet  # noqa: E402
+
+from oracle.make_golden import REF_API, reference_model  # noqa: E402
+from refiners_amd import synth  # noqa: E402
+from tests.golden_cases import SAG_CASE as CFG  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+
+def main() -> None:
+    shapes = synth.model_shapes(SDXLUNet(4, device="meta"))
+    out = {}
+    with torch.no_grad():
+        for tag, with_ip in (("plain", False), ("ip", True)):
+            unet = reference_model(SDXLUNet, shapes, CFG["weight_seed"])
+            kw = {}
+            if with_ip:
+                ip = synth.ip_spec(shapes, scale=0.6, batch=2, seed=CFG["weight_seed"] + 100)
+                synth.apply_adapters(unet, REF_API, loras=[], ip=ip, control=[])
+            sd = StableDiffusion_XL(unet=unet, lda=rfl.Chain(rfl.Identity()), clip_text_encoder=rfl.Chain(rfl.Identity()),  # type: ignore[arg-type]
+                                    solver=DDIM(num_inference_steps=CFG["num_steps"]))
+            sd.set_self_attention_guidance(enable=True, scale=CFG["sag_scale"])
+            inp = synth.sdxl_inputs(1, CFG["latent_hw"], CFG["input_seed"])
+            x1 = sd(inp["x"], step=CFG["step"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"],
+                    condition_scale=CFG["condition_scale"], **kw)
+            sd.set_self_attention_guidance(enable=False)
+            x0 = sd(inp["x"], step=CFG["step"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"],
+                    condition_scale=CFG["condition_scale"])
+            out[f"x_next_{tag}"] = x1.contiguous()
+            out[f"x_next_{tag}_without_sag"] = x0.contiguous()
+            print(tag, float((x1 - x0).abs().mean()), float(x1.abs().mean()), flush=True)
+    save_file(out, str(GOLD / "sdxl_sag.safetensors"))
+
+
+if __name__ == "__main__":
+    main()

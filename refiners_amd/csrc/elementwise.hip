@@ -285,6 +285,66 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int col = tid; col < Lp; col += 256) orow[col] = from_f32<T>(col < L ? fast_exp2((row[col] - mx) * c) * inv : 0.f);
 }
 
+// Self-Attention Guidance, mask side: acc[j] (+)= scale * sum_i P[i][j] -- the attention mass key j receives from all queries of one
+// head (self_attention_guidance.py:80: attn_map.mean(heads).sum(queries)).  One workgroup per 64 columns, 4 row lanes, fixed-order
+// LDS reduction; heads are accumulated by consecutive launches (accumulate = 1), so the result is deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const T* __restrict__ p, int64_t ldp, int M, int L, float* __restrict__ acc, int accumulate, float scale) {
+    __shared__ float red[256];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < L)
+        for (int i = rl; i < M; i += 4) s += to_f32(p[(int64_t)i * ldp + col]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && col < L) {
+        const float t = ((red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192])) * scale;
+        acc[col] = accumulate ? acc[col] + t : t;
+    }
+}
+
+// Self-Attention Guidance, latent side (SAGAdapter.compute_degraded_latents, self_attention_guidance.py:62-95) in one pass:
+//   x0   = (x - noise_std * eps) / scale_factor                      solver.remove_noise
+//   blur = gaussian_blur(x0, k x k, reflect padding)                 separable weights w1[k] from the host
+//   m    = mass[b][nearest (ah, aw) cell of the pixel] > 1           compute_sag_mask + nearest interpolate
+//   out  = scale_factor * (m ? blur : x0) + noise_std * eps          solver.add_noise
+// x, eps, out: [n][C][h][w]; coef[1] = scale factor, coef[2] = noise std of the step (the CFG+DDIM kernel's device table row).
+template <typename T>
+__global__ __launch_bounds__(256) void sag_degrade_kernel(const T* __restrict__ x, const T* __restrict__ eps, const float* __restrict__ mass, int ah, int aw,
+                                                           const float* __restrict__ coef, const float* __restrict__ w1, int ks, T* __restrict__ out, int n, int C, int h,
+                                                           int w) {
+    const int64_t total = (int64_t)n * C * h * w;
+    const float a = coef[1], sd = coef[2];
+    const int half = ks / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int px = (int)(i % w), py = (int)((i / w) % h);
+        const int64_t plane = i / ((int64_t)h * w);  // b * C + c
+        const int b = (int)(plane / C);
+        const T* xp = x + plane * h * w;
+        const T* ep = eps + plane * h * w;
+        const float e0 = to_f32(ep[py * w + px]);
+        const float x0 = (to_f32(xp[py * w + px]) - sd * e0) / a;
+        const int cy = (int)(((int64_t)py * ah) / h), cx = (int)(((int64_t)px * aw) / w);
+        float v = x0;
+        if (mass[(int64_t)b * ah * aw + cy * aw + cx] > 1.0f) {
+            float acc = 0.f;
+            for (int dy = 0; dy < ks; ++dy) {
+                int yy = py + dy - half;
+                yy = yy < 0 ? -yy : (yy >= h ? 2 * (h - 1) - yy : yy);
+                float row = 0.f;
+                for (int dx = 0; dx < ks; ++dx) {
+                    int xx = px + dx - half;
+                    xx = xx < 0 ? -xx : (xx >= w ? 2 * (w - 1) - xx : xx);
+                    row += w1[dx] * ((to_f32(xp[yy * w + xx]) - sd * to_f32(ep[yy * w + xx])) / a);
+                }
+                acc += w1[dy] * row;
+            }
+            v = acc;
+        }
+        out[i] = from_f32<T>(a * v + sd * e0);
+    }
+}
+
 #define DISPATCH_T(dtype, CALL)                          \
     do {                                                 \
         if ((dtype) == MI355X_F32) {                     \
@@ -472,5 +532,25 @@ extern "C" int mi355x_softmax_rows(int32_t dtype, const float* s, int64_t lds, v
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float c = scale * 1.44269504088896340736f;
     DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)M), dim3(256), 0, st, s, lds, static_cast<T*>(out), ldo, L, Lp, c));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_colsum_rows(int32_t dtype, const void* p, int64_t ldp, int32_t M, int32_t L, float* acc, int32_t accumulate, float scale, void* stream) {
+    if (!p || !acc || M <= 0 || L <= 0 || ldp < L) return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_rows_kernel<T>), dim3((L + 63) / 64), dim3(256), 0, st, static_cast<const T*>(p), ldp, M, L, acc, accumulate, scale));
+    return LAUNCH_OK();
+}
+
+extern "C" int mi355x_sag_degrade(int32_t dtype, const void* x, const void* eps, const float* mass, int32_t ah, int32_t aw, const float* coef, const float* w1,
+                                  int32_t ksize, void* out, int32_t n, int32_t C, int32_t h, int32_t w, void* stream) {
+    if (!x || !eps || !mass || !coef || !w1 || !out || n <= 0 || C <= 0 || h <= 0 || w <= 0 || ah <= 0 || aw <= 0 || ksize < 1 || !(ksize & 1) || ksize / 2 >= h || ksize / 2 >= w)
+        return MI355X_EARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)n * C * h * w;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((sag_degrade_kernel<T>), dim3((int)blocks), dim3(256), 0, st, static_cast<const T*>(x), static_cast<const T*>(eps), mass, ah, aw, coef, w1,
+                                         ksize, static_cast<T*>(out), n, C, h, w));
     return LAUNCH_OK();
 }

@@ -27,7 +27,7 @@ from torch import Tensor
 
 from .. import native
 from ..fluxion.tree import tree_epoch
-from .lowering import PackCache, UNetIO, UNetLowering, Unsupported, isa, kids, launches
+from .lowering import PackCache, UNetIO, UNetLowering, Unsupported, isa, kids, launches  # noqa: F401
 
 TOKEN_CONTEXTS = (("cross_attention_block", "clip_text_embedding"), ("ip_adapter", "clip_image_embedding"))
 
@@ -147,6 +147,7 @@ class CompiledUNet:
         for name, feats in got.get("t2i", {}).items():
             io.t2i[name] = [torch.empty(tuple(f.shape), device=dev, dtype=dtype) for f in feats]
         low = UNetLowering(dev, dtype, self.cache, self.lora_mode)
+        low.sag_capture = getattr(self, "sag_capture", True)
         low.lower(self.unet, io)
         self.cache.sweep()
         # the step program is replayed step after step: let every GEMM / conv pull the weights of the launches behind it into
@@ -285,6 +286,7 @@ class CompiledSDXL:
         self.x: Optional[Tensor] = None
         self.graph_key: Any = None
         self.inputs: dict[str, Any] = {}
+        self.engine2: Optional[CompiledUNet] = None  # self-attention guidance: the second (unconditional, batch n) UNet pass
 
     @property
     def condition_scale(self) -> float:
@@ -366,25 +368,78 @@ class CompiledSDXL:
         self.coef.copy_(self.coef_table[step])
         if self.linear:
             return self._linear_step(step, io, low, eng)
+        sag = self._sag_adapter()
+        tail = (lambda: None) if sag is None else self._prepare_sag(sag, got, n, io, low)
         if not self.use_graph:
             self._fill()
             native.replay(low.step)
+            tail()
             native.cfg_ddim_step(self.x, io.out, self.coef)
             return self.x
-        if self.graph is None or self.graph_key != eng.key:
+        gkey = (eng.key, None if self.engine2 is None or sag is None else self.engine2.key)
+        if self.graph is None or self.graph_key != gkey:
             keep = self.x.clone()
             self._fill()
             native.replay(low.step)  # warm-up outside capture (first-launch attribute calls, workspaces)
+            tail()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._fill()
                 native.replay(low.step)
+                tail()
                 native.cfg_ddim_step(self.x, io.out, self.coef)
             self.x.copy_(keep)
-            self.graph, self.graph_key = g, eng.key
+            self.graph, self.graph_key = g, gkey
         self.graph.replay()
         return self.x
+
+    # -- self-attention guidance (xl/model.py:164-250) ---------------------------------------------------------------------------
+    def _sag_adapter(self) -> Any:
+        p = getattr(self.unet, "parent", None)
+        while p is not None:
+            if isa(p, "SAGAdapter"):
+                return p
+            p = getattr(p, "parent", None)
+        return None
+
+    def _prepare_sag(self, sag: Any, got: dict[str, Any], n: int, io: Any, low: Any) -> Any:
+        """Stage the second UNet pass of Self-Attention Guidance and return the closure that runs between the CFG pass and the
+        guidance + DDIM kernel: degraded latents (mask from the tapped attention's column mass, Gaussian blur, re-noising: one
+        kernel) -> unconditional UNet pass on them (a second lowered program, batch n) -> cond += (sag / cfg) * (uncond - degraded),
+        which makes the unchanged CFG kernel produce eps_cfg + sag_scale * (eps_uncond - eps_degraded)   (model.py:147-155)."""
+        assert not self.linear, "self-attention guidance on the compiled loop is lowered for DDIM only"
+        assert self.condition_scale != 0.0 and not got["conditions"] and not got.get("t2i"), "SAG with ControlLora / T2I conditions or a zero guidance scale is not lowered"
+        assert getattr(low, "sag", None) is not None and getattr(low, "sag_shape", None) is not None, "SAG adapter present but its taps were not found in the lowered tree"
+        if self.engine2 is None:
+            self.engine2 = CompiledUNet(self.unet, use_graph=False, lora_mode=self.engine.lora_mode)
+            self.engine2.sag_capture = False  # the reference recomputes (and discards) the attention map in this pass
+        e2 = self.engine2
+        half = lambda t: None if t is None else t[: t.shape[0] // 2]  # noqa: E731 -- [negative ; conditional] stacks -> negative half
+        got2 = {"timestep": got["timestep"], "pooled": half(got["pooled"]), "time_ids": half(got["time_ids"]), "tokens": {k: half(v) for k, v in got["tokens"].items()},
+                "conditions": {}, "t2i": {}}
+        x = self.x
+        if e2.prepare_explicit((n,) + tuple(x.shape[1:]), x.device, got2):
+            e2.run_prologue()
+        io2, low2 = e2.io, e2.low
+        ks, sigma = int(sag.kernel_size), float(sag.sigma)
+        key = (ks, sigma, str(x.device))
+        if getattr(self, "_sag_w1_key", None) != key:
+            t = torch.linspace(-(ks - 1) * 0.5, (ks - 1) * 0.5, steps=ks, dtype=torch.float32)
+            pdf = torch.exp(-0.5 * (t / sigma).pow(2))
+            self._sag_w1, self._sag_w1_key = (pdf / pdf.sum()).to(x.device), key
+        mass, (ah, aw) = low.sag["mass"], low.sag_shape
+        assert ah * aw == low.sag["tokens"]
+        ratio = float(sag.scale) / float(self.condition_scale)
+        u, c = io.out[:n], io.out[n:]
+
+        def tail() -> None:
+            native.sag_degrade(x, u, mass, (ah, aw), self.coef, self._sag_w1, io2.x)
+            native.replay(low2.step)
+            native.axpby(u, ratio, c, 1.0, c)
+            native.axpby(io2.out, -ratio, c, 1.0, c)
+
+        return tail
 
     def _linear_step(self, step: int, io: Any, low: Any, eng: Any) -> Tensor:
         """Euler / DPM-Solver++ / LCM: the UNet program then ONE kernel (guidance, update, history, next model input)."""

@@ -622,7 +622,7 @@ class Lowering:
         if isa(att, "CrossAttentionAdapter"):
             att = kids(att)[0]
         _expect(isa(att, "Attention"), f"expected an Attention chain, got {cname(att)}")
-        ch = kids(att)
+        ch = [c for c in kids(att) if not isa(c, "SelfAttentionMap")]  # the SAG tap (handled by self_attention) stores probabilities, changes nothing
         if isa(att, "SelfAttention"):
             _expect(len(ch) == 4 and isa(ch[0], "Parallel") and all(isa(c, "Identity") for c in kids(ch[0])), "unexpected SelfAttention layout")
             ch = ch[1:]
@@ -814,6 +814,9 @@ class Lowering:
                     native.gemm([(h, self.kblocked(wl))], None, out_t=vt, nt_begin=0, ln=(stats, ls, lc, float(ln.eps)))
                 else:
                     vt = self._project_vt(h, vs, B, L, C)
+        tap = next((c for c in kids(att) if isa(c, "SelfAttentionMap")), None)
+        if tap is not None and getattr(self, "sag_capture", True):
+            self.sag_attention_mass(q, k, B, heads, L, C)
         if native_path:
             o = self.sdpa(q, B, heads, [(k, vt, L, 1.0)])
             if L % 64 == 0:
@@ -832,6 +835,28 @@ class Lowering:
         self.linear(o, self.linear_spec(on), res=x, out=x, stats_out=stats_out)
         self.pool.put(o)
         return x
+
+    def sag_attention_mass(self, q: Tensor, k: Tensor, B: int, heads: int, L: int, C: int) -> None:
+        """Self-Attention Guidance tap (SelfAttentionMap + SAGAdapter.compute_sag_mask, self_attention_guidance.py:22-84): for the
+        UNCONDITIONAL half of the CFG batch, mass[b][j] = mean over heads of the attention key j receives from all queries.  The
+        reference materialises softmax(Q K^T / sqrt(d)) for every head and sample; only these column sums are ever used, so per
+        (sample, head): scores GEMM (float32) -> row softmax -> column sum, three small launches on an L x L scratch."""
+        d = C // heads
+        kblk = 128 // self.es
+        _expect(d % kblk == 0 and B % 2 == 0, "self-attention guidance tap: head width / batch not supported")
+        n = B // 2
+        mass = torch.zeros(n, L, device=self.device, dtype=torch.float32)
+        sc = torch.empty(L, L, device=self.device, dtype=torch.float32)
+        pr = torch.empty(L, L, device=self.device, dtype=self.dtype)
+        self.__dict__.setdefault("_keep", []).extend([mass, sc, pr])
+        if self.device.type != "meta":
+            for b in range(n):
+                for h in range(heads):
+                    qb, kb = q[b * L : (b + 1) * L, h * d : (h + 1) * d], k[b * L : (b + 1) * L, h * d : (h + 1) * d]
+                    native.gemm([(qb, kb)], sc, out_f32=self.dtype != torch.float32)
+                    native.softmax_rows(sc, pr, L, d ** -0.5)
+                    native.colsum_rows(pr, mass[b], accumulate=h > 0, scale=1.0 / heads)
+        self.sag = {"mass": mass, "tokens": L}
 
     def cross_attention(self, x: Tensor, B: int, ln: Any, par: Any, att: Any, ctx: "UNetContext", stats: Optional[Tensor] = None,
                         stats_out: Optional[Tensor] = None) -> Tensor:
@@ -1198,6 +1223,9 @@ class UNetLowering(Lowering):
             out = self.add_condition(m, cur)
         elif isa(m, "T2IFeatures"):
             out = self.add_t2i_features(m, cur)
+        elif isa(m, "SelfAttentionShape"):  # SAG: remembers the (H, W) of the feature map the tapped attention runs on
+            self.sag_shape = (cur.H, cur.W)
+            return cur
         else:
             out = self.torch_node(m, cur)
         self._release(cur)

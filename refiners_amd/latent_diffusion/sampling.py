@@ -67,6 +67,11 @@ class DDIM:
         t = self.timesteps[step]
         return self.cumulative_scale_factors[t] * x + self.noise_std[t] * noise
 
+    def remove_noise(self, x: Tensor, noise: Tensor, step: int) -> Tensor:
+        """The data estimate (x - noise_std * noise) / scale at this step's timestep (solvers/solver.py:298-319)."""
+        t = self.timesteps[step]
+        return (x - self.noise_std[t] * noise) / self.cumulative_scale_factors[t]
+
     def __call__(self, x: Tensor, predicted_noise: Tensor, step: int, generator: Any = None) -> Tensor:
         assert self.first_inference_step <= step < self.num_inference_steps, f"invalid step {step}"
         t = self.timesteps[step]
@@ -129,6 +134,48 @@ class SDXLDenoiser:
         if self.classifier_free_guidance:
             uncond, cond = self.unet(latents).chunk(2)
             noise = uncond + condition_scale * (cond - uncond)
+            sag = self._find_sag_adapter()
+            if sag is not None:  # model.py:147-155
+                noise = noise + self.compute_self_attention_guidance(sag, x.narrow(1, 0, 4), uncond, step, clip_text_embedding=clip_text_embedding,
+                                                                     pooled_text_embedding=pooled_text_embedding, time_ids=time_ids)
         else:
             noise = self.unet(latents)
         return self.solver(x.narrow(1, 0, 4), predicted_noise=noise, step=step)
+
+    # -- self-attention guidance (xl/model.py:164-250) -----------------------------------------------------------------------
+    def _find_sag_adapter(self) -> Any:
+        from .sag import SAGAdapter
+
+        return next((p for p in self.unet.get_parents() if isinstance(p, SAGAdapter)), None)
+
+    def set_self_attention_guidance(self, enable: bool, scale: float = 1.0) -> None:
+        from .sag import SDXLSAGAdapter
+
+        sag = self._find_sag_adapter()
+        if enable:
+            if sag is not None:
+                sag.scale = scale
+            else:
+                SDXLSAGAdapter(target=self.unet, scale=scale).inject()
+        elif sag is not None:
+            sag.eject()
+
+    def has_self_attention_guidance(self) -> bool:
+        return self._find_sag_adapter() is not None
+
+    def compute_self_attention_guidance(self, sag: Any, x: Tensor, noise: Tensor, step: int, *, clip_text_embedding: Tensor, pooled_text_embedding: Tensor,
+                                        time_ids: Tensor) -> Tensor:
+        degraded = sag.compute_degraded_latents(solver=self.solver, latents=x, noise=noise, step=step, classifier_free_guidance=True)
+        neg_text, _ = clip_text_embedding.chunk(2)
+        neg_pooled, _ = pooled_text_embedding.chunk(2)
+        neg_ids, _ = time_ids.chunk(2)
+        self.set_unet_context(timestep=self.solver.timesteps[step].unsqueeze(dim=0), clip_text_embedding=neg_text, pooled_text_embedding=neg_pooled, time_ids=neg_ids)
+        if "ip_adapter" in self.unet.provider.contexts:
+            ctx = self.unet.use_context("ip_adapter")
+            keep = ctx["clip_image_embedding"].clone()
+            ctx["clip_image_embedding"], _ = ctx["clip_image_embedding"].chunk(2)
+            degraded_noise = self.unet(degraded)
+            ctx["clip_image_embedding"] = keep
+        else:
+            degraded_noise = self.unet(degraded)
+        return sag.scale * (noise - degraded_noise)

@@ -252,6 +252,8 @@ EXPORTS = [
     "mi355x_axpby",
     "mi355x_silu",
     "mi355x_softmax_rows",
+    "mi355x_colsum_rows",
+    "mi355x_sag_degrade",
     "mi355x_cfg_ddim_step",
     "mi355x_cfg_linear_step",
     "mi355x_sinusoidal",
@@ -294,6 +296,9 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_concat2.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.mi355x_axpby.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_silu.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mi355x_colsum_rows.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
+    lib.mi355x_sag_degrade.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_void_p]
     lib.mi355x_softmax_rows.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     lib.mi355x_cfg_ddim_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mi355x_cfg_linear_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -868,6 +873,23 @@ def softmax_rows(s: Tensor, out: Tensor, L: int, scale: float) -> Tensor:
     assert s.dtype == torch.float32 and s.dim() == 2 and out.dim() == 2 and s.stride(1) == 1 and out.stride(1) == 1 and s.shape[0] == out.shape[0]
     assert s.shape[1] >= L and out.shape[1] >= L
     _launch("mi355x_softmax_rows", (dtype_code(out.dtype), s.data_ptr(), s.stride(0), out.data_ptr(), out.stride(0), s.shape[0], L, out.shape[1], scale), "mi355x_softmax_rows")
+    return out
+
+
+def colsum_rows(p: Tensor, acc: Tensor, accumulate: bool, scale: float) -> Tensor:
+    """acc[j] (+)= scale * sum_i p[i, j]: p [M, L] rows of the compute dtype, acc float32 [L] (contiguous)."""
+    assert p.dim() == 2 and p.stride(1) == 1 and acc.dtype == torch.float32 and acc.is_contiguous() and acc.numel() >= p.shape[1]
+    _launch("mi355x_colsum_rows", (dtype_code(p.dtype), p.data_ptr(), p.stride(0), p.shape[0], p.shape[1], acc.data_ptr(), int(accumulate), scale), "mi355x_colsum_rows")
+    return acc
+
+
+def sag_degrade(x: Tensor, eps: Tensor, mass: Tensor, attn_hw: tuple[int, int], coef: Tensor, w1: Tensor, out: Tensor) -> Tensor:
+    """Self-attention-guidance degraded latents (see the header): x, eps, out [n, C, h, w]; mass float32 [n, ah*aw]; coef device row; w1 float32 [k]."""
+    n, Cc, h, w = x.shape
+    assert x.is_contiguous() and eps.is_contiguous() and out.is_contiguous() and eps.shape == x.shape == out.shape and x.dtype == eps.dtype == out.dtype
+    assert mass.dtype == torch.float32 and mass.is_contiguous() and mass.numel() == n * attn_hw[0] * attn_hw[1] and w1.dtype == torch.float32 and w1.is_contiguous()
+    _launch("mi355x_sag_degrade", (dtype_code(x.dtype), x.data_ptr(), eps.data_ptr(), mass.data_ptr(), attn_hw[0], attn_hw[1], coef.data_ptr(), w1.data_ptr(), w1.numel(),
+                                   out.data_ptr(), n, Cc, h, w), "mi355x_sag_degrade", keep=(mass, w1, coef))
     return out
 
 

@@ -164,3 +164,7 @@ def control_lora_file(rank: int = 8):
     for k, (co, ci) in synth.CONTROL_ENCODER_SHAPES.items():
         out += [(f"ConditionEncoder.{k}.weight", (co, ci, 3, 3)), (f"ConditionEncoder.{k}.bias", (co,))]
     return out
+
+
+# ------------------------------------------------------------------------------------------------ next-4: Self-Attention Guidance
+SAG_CASE = dict(weight_seed=0, input_seed=51, latent_hw=(32, 32), num_steps=30, step=11, condition_scale=5.0, sag_scale=0.75)

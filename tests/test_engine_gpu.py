@@ -805,3 +805,44 @@ def test_fine_grained_image_prompt_on_the_engine():
         assert l2 < tol and tuple(tokens.shape) == (2, 16, 2048), (dtype, l2, mx)
         if dtype == torch.float32:
             assert mx < tol
+
+
+@pytest.mark.parametrize("tag", ["plain", "ip"])
+def test_self_attention_guidance_on_the_engine(tag):
+    """Self-Attention Guidance (self_attention_guidance.py:22-105, xl/model.py:164-250) on the compiled
+    step: attention-mass tap of the middle block, mask + Gaussian blur + re-noising as one kernel, second (unconditional) UNet pass
+    as a second lowered program, guidance folded into the CFG + DDIM kernel.  float32 vs the REAL reference's step, direct replay
+    and HIP graph; with the IP-Adapter the image tokens of the second pass are the negative half (xl/model.py:240-246)."""
+    from refiners_amd.latent_diffusion.sag import SDXLSAGAdapter
+    from tests.golden_cases import SAG_CASE as CFG
+
+    gold = S.golden("sdxl_sag")
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", CFG["weight_seed"]), device="cuda", dtype=torch.float32)
+    kw = {}
+    if tag == "ip":
+        ip = S.synth.ip_spec(S.key_shapes("sdxl"), scale=0.6, batch=2, seed=CFG["weight_seed"] + 100)
+        S.synth.apply_adapters(unet, refiners_amd.namespace(), device="cuda", dtype=torch.float32, loras=[], ip=ip, control=[])
+        kw["clip_image_embedding"] = ip["tokens"].cuda()
+    sag = SDXLSAGAdapter(target=unet, scale=CFG["sag_scale"]).inject()
+    inp = {k: v.cuda() for k, v in S.synth.sdxl_inputs(1, CFG["latent_hw"], CFG["input_seed"]).items()}
+    outs = []
+    for use_graph in (False, True):
+        sd = CompiledSDXL(unet, num_inference_steps=CFG["num_steps"], condition_scale=CFG["condition_scale"], use_graph=use_graph)
+        sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], **kw)
+        x1 = sd.step(CFG["step"]).clone()
+        l2, mx = S.rel_err(x1, gold[f"x_next_{tag}"])
+        print(f"sag {tag} f32 graph={use_graph}: l2 {l2:.2e} max {mx:.2e}; launches {sd.engine.stats['step_ops']} + {sd.engine2.stats['step_ops']}")
+        assert l2 < F32_TOL and mx < F32_TOL, (tag, use_graph, l2, mx)
+        assert sd.engine.stats["fallback_nodes"] == [] and sd.engine2.stats["fallback_nodes"] == []
+        outs.append(x1)
+        if use_graph:  # replay, then a changed scale must take effect
+            sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], **kw)
+            assert torch.equal(x1, sd.step(CFG["step"]))
+            sag.scale = 0.0
+            sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], **kw)
+            x0 = sd.step(CFG["step"])
+            l2, mx = S.rel_err(x0, gold[f"x_next_{tag}_without_sag"])
+            assert l2 < F32_TOL and mx < F32_TOL, ("scale 0", l2, mx)
+            sag.scale = CFG["sag_scale"]
+    assert torch.equal(outs[0], outs[1])

@@ -1,0 +1,40 @@
+"""Self-Attention Guidance: the host mirror (SDXLSAGAdapter + SDXLDenoiser's second UNet pass) against
+the REAL reference's StableDiffusion_XL step (tests/golden/sdxl_sag.safetensors, oracle/make_golden_sag.py), CPU float32; the engine's
+version of the same step is checked on the GPU in tests/test_engine_gpu.py::test_self_attention_guidance_on_the_engine."""
+import pytest
+import torch
+
+import refiners_amd
+from refiners_amd import synth
+from refiners_amd.latent_diffusion.sag import SDXLSAGAdapter
+from refiners_amd.latent_diffusion.sampling import DDIM, SDXLDenoiser
+from refiners_amd.latent_diffusion.sdxl import SDXLUNet
+from tests import support as S
+from tests.golden_cases import SAG_CASE as CFG
+
+TOL = 2e-4
+
+
+@pytest.mark.parametrize("tag", ["plain", "ip"])
+def test_sag_mirror_matches_reference(tag):
+    gold = S.golden("sdxl_sag")
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", CFG["weight_seed"]))
+    bare = repr(unet)
+    if tag == "ip":
+        ip = synth.ip_spec(S.key_shapes("sdxl"), scale=0.6, batch=2, seed=CFG["weight_seed"] + 100)
+        synth.apply_adapters(unet, refiners_amd.namespace(), loras=[], ip=ip, control=[])
+    sd = SDXLDenoiser(unet, DDIM(CFG["num_steps"]))
+    sd.set_self_attention_guidance(True, CFG["sag_scale"])
+    assert sd.has_self_attention_guidance() and isinstance(sd._find_sag_adapter(), SDXLSAGAdapter)
+    inp = synth.sdxl_inputs(1, CFG["latent_hw"], CFG["input_seed"])
+    kw = dict(clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], condition_scale=CFG["condition_scale"])
+    with torch.no_grad():
+        x1 = sd(inp["x"], CFG["step"], **kw)
+    l2, mx = S.rel_err(x1, gold[f"x_next_{tag}"])
+    assert l2 < TOL and mx < TOL, (tag, l2, mx)
+    assert S.rel_err(x1, gold[f"x_next_{tag}_without_sag"])[0] > 5e-3  # the guidance matters in this fixture
+    sd.set_self_attention_guidance(False)
+    assert not sd.has_self_attention_guidance()
+    if tag == "plain":
+        assert repr(unet) == bare  # eject restores the tree

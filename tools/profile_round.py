@@ -154,7 +154,7 @@ def main() -> None:
     args = ap.parse_args()
     OUT.mkdir(exist_ok=True)
     tag = args.tag
-    prof = OUT / f"{tag}_prof"
+    prof = Path("/tmp") / f"{tag}_prof"  # raw profiler databases stay on the box: only the summaries go to gpurun_out/ (64 MiB cap)
     prof.mkdir(exist_ok=True)
     bench = [sys.executable, str(ROOT / "bench.py"), "--workload", args.workload, "--no-cpu-baseline", "--no-extra", "--no-roofline", "--no-graph"]
     prog_path = prof / "program.json"
@@ -193,6 +193,27 @@ def main() -> None:
                     fams[f][counter] = {"dispatches": calls, "raw_kb_per_launch": kb, "bytes_per_launch": kb * 1024 * (2 if counter == "FETCH_SIZE" else 1)}
         (OUT / f"{tag}_pmc_traffic.json").write_text(json.dumps({"how": how, "units": "counter values are KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); per KERNEL dispatch (GroupNorm: per kernel, not per call)", "families": fams}, indent=1))
         print({f: {c: round(v["bytes_per_launch"] / 1e6, 2) for c, v in cs.items()} for f, cs in fams.items()})
+    # calibration of the MFMA-busy counter on a launch whose MFMA count is known exactly (tools/probe_mfma_cal.py)
+    cal = None
+    rc = run(["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace", "-d", str(prof / "cal"), "--", sys.executable, str(ROOT / "tools" / "probe_mfma_cal.py")], prof / "cal.log")
+    db = find_db(prof / "cal")
+    if db:
+        try:
+            c = pmc_families(db).get("mi355x_gemm", {})
+            n_launch = c["SQ_VALU_MFMA_BUSY_CYCLES"]["dispatches"]
+            busy = c["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / n_launch
+            gui = c["GRBM_GUI_ACTIVE"]["sum"] / n_launch
+            n_mfma = 4096 ** 3 * 2 / 16384
+            con = sqlite3.connect(db)
+            dur = con.execute("select avg(duration) from kernels where name like '%gemm_kernel%'").fetchone()[0]
+            cal = {"launch": "4096^3 bf16, 128x128 tile", "mfma_instructions": n_mfma, "counter_per_launch": busy, "gui_active_per_launch": gui, "avg_duration_us": dur / 1e3,
+                   "tflops": 2 * 4096 ** 3 / (dur * 1e-9) / 1e12, "counted_units_per_mfma": busy / n_mfma,
+                   # one 16x16x32 bf16 MFMA occupies its SIMD's matrix pipe for 16 cycles (2.5 PFLOP/s = 1024 SIMDs x 2.4 GHz x 16384 FLOP / 16):
+                   "scale_to_simd_cycles": n_mfma * 16.0 / busy, "effective_clock_GHz": gui / (dur * 1e-9) / 1e9}
+            cal["mfma_util_of_calibration_launch"] = cal["scale_to_simd_cycles"] * busy / (gui * 1024.0)
+            print("mfma counter calibration:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cal.items()})
+        except Exception as exc:  # noqa: BLE001
+            print("mfma calibration failed:", exc)
     if "mfma" in got:
         fams = {}
         for f, cs in got["mfma"].items():
@@ -200,12 +221,14 @@ def main() -> None:
             gui = cs.get("GRBM_GUI_ACTIVE", {}).get("sum")
             row = {"dispatches": next(iter(cs.values()))["dispatches"], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sq, "SQ_WAVE_CYCLES": waves, "GRBM_GUI_ACTIVE": gui}
             if busy and gui:
-                # MFMA-busy cycles are summed over the chip's 1024 SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE = cycles the GPU was busy with the kernel
-                row["mfma_busy_per_simd_over_gpu_active"] = busy / (gui * 1024.0)
+                # fraction of SIMD-cycles (1024 SIMDs x cycles the GPU was busy with these kernels) with the matrix pipe busy; the raw counter is
+                # converted to SIMD-cycles with the calibration launch's factor (what one counted unit aggregates is profiler-build specific)
+                k = cal["scale_to_simd_cycles"] if cal else 1.0
+                row["mfma_util"] = k * busy / (gui * 1024.0)
             if busy and sq:
                 row["mfma_busy_over_sq_busy"] = busy / sq
             fams[f] = row
-        (OUT / f"{tag}_pmc_mfma.json").write_text(json.dumps({"how": how, "note": "mfma_busy_per_simd_over_gpu_active = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): fraction of SIMD-cycles with the matrix pipe busy", "families": fams}, indent=1))
+        (OUT / f"{tag}_pmc_mfma.json").write_text(json.dumps({"how": how, "note": "mfma_util = scale x SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): fraction of SIMD-cycles with the matrix pipe busy; scale from the calibration launch (known MFMA count x 16 cycles)", "calibration": cal, "families": fams}, indent=1))
         print({f: {k: (round(v, 4) if isinstance(v, float) and v < 10 else v) for k, v in r.items()} for f, r in fams.items()})
     if "sq" in got:
         fams = {}
