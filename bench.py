@@ -88,9 +88,11 @@ def pmc_mfma_util(family: str):
     `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...` run of this same command)."""
     try:
         f = sorted((ROOT / "profiles").glob("r*_pmc_mfma.json"))[-1]
-        fam = json.loads(f.read_text())["families"][family]
+        doc = json.loads(f.read_text())
+        fam = doc["families"][family]
         return {"mfma_util": round(fam["mfma_util"], 4), "SQ_VALU_MFMA_BUSY_CYCLES": fam["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": fam["GRBM_GUI_ACTIVE"],
-                "dispatches": fam["dispatches"], "source": f"profiles/{f.name}"}
+                "definition": "fraction of GPU-active time with the matrix pipes busy: counter ratio anchored on a calibration launch of known MFMA count (see the file)",
+                "source": f"profiles/{f.name}"}
     except Exception:  # noqa: BLE001 -- no committed pass
         return None
 

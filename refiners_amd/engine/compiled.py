@@ -39,20 +39,16 @@ def _ident(t: Optional[Tensor]) -> Any:
     return None if t is None else (id(t), t.data_ptr(), t._version, tuple(t.shape), t.dtype)
 
 
-_param_lists: dict[int, tuple[Any, list]] = {}
-
-
-def _weights_version(unet: Any, epoch: Any = None) -> int:
+def _weights_version(unet: Any, cache: Optional[dict] = None, epoch: Any = None) -> int:
     """Changes whenever a parameter is updated IN PLACE (load_state_dict / load_from_safetensors without assign,
-    parallel.broadcast_module, optimizer steps): converted, merged and K-blocked copies must then be rebuilt.  The
-    parameter list of a mirror tree is cached per tree epoch (the walk over ~2 900 modules costs more than the sum)."""
-    if epoch is None:
+    parallel.broadcast_module, optimizer steps): converted, merged and K-blocked copies must then be rebuilt.  `cache` (owned by
+    the CompiledUNet, so it dies with it) keeps the parameter list of a mirror tree per tree epoch: the walk over ~2 900 modules
+    costs more than the sum."""
+    if cache is None or epoch is None:
         return sum(p._version for p in unet.parameters())
-    got = _param_lists.get(id(unet))
-    if got is None or got[0] != epoch:
-        got = (epoch, list(unet.parameters()))
-        _param_lists[id(unet)] = got
-    return sum(p._version for p in got[1])
+    if cache.get("epoch") != epoch:
+        cache["epoch"], cache["params"] = epoch, list(unet.parameters())
+    return sum(p._version for p in cache["params"])
 
 
 class Program:
@@ -207,7 +203,7 @@ class CompiledUNet:
 
         if isinstance(self.unet, MirrorChain):
             ep = tree_epoch()
-            return (ep, _weights_version(self.unet, ep))
+            return (ep, _weights_version(self.unet, self.__dict__.setdefault("_params_cache", {}), ep))
         sig: list[Any] = [_weights_version(self.unet)]
         for m in self.unet.modules():
             sig.append(id(m))

@@ -206,11 +206,11 @@ def main() -> None:
             n_mfma = 4096 ** 3 * 2 / 16384
             con = sqlite3.connect(db)
             dur = con.execute("select avg(duration) from kernels where name like '%gemm_kernel%'").fetchone()[0]
-            cal = {"launch": "4096^3 bf16, 128x128 tile", "mfma_instructions": n_mfma, "counter_per_launch": busy, "gui_active_per_launch": gui, "avg_duration_us": dur / 1e3,
-                   "tflops": 2 * 4096 ** 3 / (dur * 1e-9) / 1e12, "counted_units_per_mfma": busy / n_mfma,
-                   # one 16x16x32 bf16 MFMA occupies its SIMD's matrix pipe for 16 cycles (2.5 PFLOP/s = 1024 SIMDs x 2.4 GHz x 16384 FLOP / 16):
-                   "scale_to_simd_cycles": n_mfma * 16.0 / busy, "effective_clock_GHz": gui / (dur * 1e-9) / 1e9}
-            cal["mfma_util_of_calibration_launch"] = cal["scale_to_simd_cycles"] * busy / (gui * 1024.0)
+            cal = {"launch": "4096^3 bf16, 128x128 tile", "mfma_instructions": n_mfma, "avg_duration_us": dur / 1e3, "tflops": 2 * 4096 ** 3 / (dur * 1e-9) / 1e12,
+                   "SQ_VALU_MFMA_BUSY_CYCLES_over_GRBM_GUI_ACTIVE": busy / gui}
+            cal["mfma_util_by_construction"] = cal["tflops"] / 2500.0  # known MFMA count, known duration
+            cal["note"] = ("pmc_events holds one row per XCD instance of a dispatch and GRBM_GUI_ACTIVE does not tick at the shader clock on this profiler build: "
+                           "only the RATIO of the two counters is used, anchored on this launch")
             print("mfma counter calibration:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cal.items()})
         except Exception as exc:  # noqa: BLE001
             print("mfma calibration failed:", exc)
@@ -221,14 +221,13 @@ def main() -> None:
             gui = cs.get("GRBM_GUI_ACTIVE", {}).get("sum")
             row = {"dispatches": next(iter(cs.values()))["dispatches"], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sq, "SQ_WAVE_CYCLES": waves, "GRBM_GUI_ACTIVE": gui}
             if busy and gui:
-                # fraction of SIMD-cycles (1024 SIMDs x cycles the GPU was busy with these kernels) with the matrix pipe busy; the raw counter is
-                # converted to SIMD-cycles with the calibration launch's factor (what one counted unit aggregates is profiler-build specific)
-                k = cal["scale_to_simd_cycles"] if cal else 1.0
-                row["mfma_util"] = k * busy / (gui * 1024.0)
+                row["busy_over_gui_active"] = busy / gui
+                if cal:  # fraction of GPU-active time with the matrix pipes busy, anchored on the calibration launch's known utilisation
+                    row["mfma_util"] = cal["mfma_util_by_construction"] * row["busy_over_gui_active"] / cal["SQ_VALU_MFMA_BUSY_CYCLES_over_GRBM_GUI_ACTIVE"]
             if busy and sq:
                 row["mfma_busy_over_sq_busy"] = busy / sq
             fams[f] = row
-        (OUT / f"{tag}_pmc_mfma.json").write_text(json.dumps({"how": how, "note": "mfma_util = scale x SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): fraction of SIMD-cycles with the matrix pipe busy; scale from the calibration launch (known MFMA count x 16 cycles)", "calibration": cal, "families": fams}, indent=1))
+        (OUT / f"{tag}_pmc_mfma.json").write_text(json.dumps({"how": how, "note": "mfma_util = (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the family) / (the same ratio of the calibration launch) x the calibration launch's known utilisation", "calibration": cal, "families": fams}, indent=1))
         print({f: {k: (round(v, 4) if isinstance(v, float) and v < 10 else v) for k, v in r.items()} for f, r in fams.items()})
     if "sq" in got:
         fams = {}
