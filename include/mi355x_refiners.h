@@ -112,7 +112,9 @@ typedef struct {
     const void* zeros;      /* >= 256 zero bytes in device memory; required when conv == 1 */
     int32_t tile;           /* 0 = let the library choose; 1: 128x128  2: 128x64  3: 64x128  4: 64x64  5: 256x128 (M x N);
                                6: 128x128 computed by 8 waves in two K groups (even / odd K blocks, summed through LDS in a fixed order):
-                               for launches with fewer output tiles than CUs */
+                               for launches with fewer output tiles than CUs;
+                               7: 256x128, 8 waves in two groups that run one barrier slot apart (one group's MFMA section overlaps the other's
+                               LDS-read / load-issue section), 3 LDS stages: for launches with many tiles */
     int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
                                partial sums into `ws`, a second launch adds them in a fixed order (deterministic) and
                                applies the epilogue.  Not combinable with geglu. */

@@ -18,6 +18,12 @@
 //     group with its own LDS ring; the two partial tiles are added through LDS in a fixed order.  For launches with fewer
 //     tiles than CUs this puts two waves on every SIMD (twice the bytes in flight, each wave's LDS / barrier stalls
 //     covered by the other) without the HBM round trip of a split-K across workgroups;
+//   * STAG ("tile 7": 256 x 128, 8 waves, 3 LDS stages): the two 4-wave groups (rows 0-127 / 128-255, sharing the weight tile) run ONE
+//     BARRIER SLOT APART.  Every wave alternates a memory section (8 ds_read_b128 of the half K block it multiplies next + half of its
+//     share of the global->LDS loads two blocks ahead) with a matrix section (16 MFMAs), sections separated by workgroup barriers; group 1
+//     executes one extra barrier up front, so at any time one group is in its matrix section while the other reads / issues loads on the
+//     same SIMDs (the 8-phase schedule of the vendor guide, section 5, on this kernel's loader and epilogue).  One workgroup per CU
+//     streams 25 % fewer bytes per FLOP through the L2 -> LDS path than two co-resident 128 x 128 workgroups;
 //   * conv mode gathers the activation rows straight from the NHWC image (zero padding comes from a zero page, nearest
 //     2x upsampling and stride 2 are address arithmetic), so no im2col buffer, no materialised upsample / concat;
 //   * LayerNorm folded in: a launch whose x is LN(r) reads r itself; the weights carry gamma (W' = W . diag(gamma)) and the
@@ -114,7 +120,7 @@ MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, flo
 
 constexpr int LORA_R = 32;  // stacked LoRA rank handled inside a launch (two rank-16 adapters, or anything that pads to 32)
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, bool STAG = false>
 __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     constexpr int NW = WM * WN;           // waves per K group
     constexpr int NTHR = NW * 64;         // threads per K group: the loader geometry
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     constexpr int XBYTES = BM * 128, WBYTES = BN * 128, ABYTES = LORA ? LORA_R * 128 : 0, STAGE = XBYTES + WBYTES + ABYTES;
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
     static_assert(!LORA || (!CONV && KG == 1 && NTHR == 256 && WN == 2), "in-launch LoRA: plain GEMM, 4 waves as 2 x 2");
+    static_assert(!STAG || (BM == 256 && BN == 128 && WM == 4 && WN == 2 && NSTAGE == 3 && KG == 1 && !LORA), "staggered schedule: 256 x 128, 8 waves, 3 stages");
     static_assert(KG == 1 || KG == 2, "one or two K groups");
     constexpr int WNE = 16 * NT;  // columns per wave
     constexpr int WME = 16 * MT;  // rows per wave
@@ -341,15 +348,43 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
         for (int a = 0; a < KG; ++a) advance();
     };
 
+    auto issue_half = [&](int buf, int half) __attribute__((always_inline)) {  // STAG: this thread's loads of one K block in two instalments
+        char* xs = smem_g + buf * STAGE;
+        char* ws = xs + XBYTES;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            if ((it * 2) / XI != half) continue;
+            const char* src;
+            if constexpr (CONV) src = xbase[it] ? xbase[it] + (int64_t)cb * 128 : p.zeros + xcoff[it];
+            else src = xbase[it] + xoff;
+            glds16(src, xs + (it * NTHR + wid * 64) * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < WI; ++it) {
+            if ((it * 2) / WI != half) continue;
+            glds16(wbase[it] + woff, ws + (it * NTHR + wid * 64) * 16);
+        }
+        if (half == 1) advance();
+    };
+
     // ---- software pipeline: NSTAGE LDS buffers, D = NSTAGE - 1 K blocks in flight -------------------------------------
     // per iteration: counted vmcnt (block t has landed, the D-1 younger ones stay in flight) -> raw barrier (no vmcnt(0)
     // drain, guide section 5 "pipelining across barriers") -> issue block t+D into the buffer block t-1 was computed from
     // -> MFMA on block t.  One barrier per K block.
     constexpr int D = NSTAGE - 1;
     constexpr int LPS = XI + WI + (LORA ? 1 : 0);  // global_load_lds instructions per thread per stage
+    if constexpr (STAG) {
 #pragma unroll
-    for (int s0 = 0; s0 < D; ++s0)
-        if (s0 < my_kb) issue(s0);
+        for (int s0 = 0; s0 < 2; ++s0)
+            if (s0 < total_kb) {
+                issue_half(s0, 0);
+                issue_half(s0, 1);
+            }
+    } else {
+#pragma unroll
+        for (int s0 = 0; s0 < D; ++s0)
+            if (s0 < my_kb) issue(s0);
+    }
 
     if (p.ln_stats) {
         // LayerNorm consumer: (mean, rstd) of the tile's BM rows from the producer's 32-column partials, TPR threads per row,
@@ -471,7 +506,87 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
             }
         }
     };
-    if constexpr (CONV) {
+    // ---- the staggered schedule (STAG): 4 barrier slots per K block; group 0 = waves 0-3 (wm 0, 1), group 1 = waves 4-7 one slot behind ---
+    //   slot     group 0                 group 1
+    //   4t       MEM_a(t)                MMA_b(t-1)          MEM_a(t): ds_read F0(t), issue first half of block t+2
+    //   4t+1     MMA_a(t)                MEM_a(t)            MEM_b(t): ds_read F1(t), issue second half of block t+2, vmcnt: block t+1 landed
+    //   4t+2     MEM_b(t)                MMA_a(t)
+    //   4t+3     MMA_b(t)                MEM_b(t)
+    // Block t+1 is first read in slot 4t+4; every wave has waited for its own part of it by the end of slot 4t+3.  Block t+2 goes into
+    // the buffer of block t-1, whose last reads (group 1's MEM_b(t-1), slot 4t-1) are retired by the lgkmcnt(0) in front of that slot's
+    // closing barrier.  Both groups execute the same number of barriers (group 1 one up front, group 0 one at the end).
+    auto stagloop = [&](auto trc) {
+        constexpr bool TR = decltype(trc)::value;
+        constexpr int HL = LPS / 2;  // loads per thread per half block
+        static_assert(XI % 2 == 0 && WI % 2 == 0, "loads split in two instalments");
+        frag_t xf[MT], wf[NT];
+        const int grp = wid / (NW / 2);
+        auto read_half = [&](int blk, int kk) {
+            const char* xs = smem_g + (blk % NSTAGE) * STAGE;
+            const char* ws = xs + XBYTES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
+        };
+        auto mma_half = [&]() {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (TR) mma_step<T>(acc[i][j], xf[i], wf[j]);
+                    else mma_step<T>(acc[i][j], wf[j], xf[i]);
+                }
+        };
+        auto slot_end = [&]() {  // retire this wave's LDS reads, meet the other group, pin the section boundary for the scheduler
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // blocks 0 and 1 were issued whole by the prologue below; block 0 must have landed before slot 0
+        if (total_kb > 1) wait_vm<LPS>();
+        else wait_vm0();
+        slot_end();
+        if (grp == 1) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < total_kb; ++t) {
+            const bool more = t + 2 < total_kb;
+            read_half(t, 0);  // MEM_a(t)
+            if (more) issue_half((t + 2) % NSTAGE, 0);
+            slot_end();
+            __builtin_amdgcn_s_setprio(1);
+            mma_half();       // MMA_a(t)
+            __builtin_amdgcn_s_setprio(0);
+            slot_end();
+            read_half(t, 1);  // MEM_b(t)
+            if (more) {
+                issue_half((t + 2) % NSTAGE, 1);
+                wait_vm<LPS>();  // this wave's part of block t+1 has landed (block t+2's loads stay in flight)
+            } else {
+                wait_vm0();
+            }
+            slot_end();
+            __builtin_amdgcn_s_setprio(1);
+            mma_half();       // MMA_b(t)
+            __builtin_amdgcn_s_setprio(0);
+            slot_end();
+        }
+        if (grp == 0) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        (void)HL;
+    };
+    if constexpr (STAG) {
+        if constexpr (CONV) {
+            stagloop(std::false_type{});
+        } else {
+            if (tr) stagloop(std::true_type{});
+            else stagloop(std::false_type{});
+        }
+    } else if constexpr (CONV) {
         mainloop(std::false_type{});
     } else {
         if (tr) mainloop(std::true_type{});
@@ -831,12 +946,12 @@ extern int g_pf_mode;    // 1 = plain loads, 2 = non-temporal
 extern int g_tile;       // 0 = heuristic / caller's hint, 1..6 = force a tile configuration (probing / A-B runs)
 extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS pipeline depth
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, bool STAG = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
     constexpr int LDS = KG * NSTAGE * ((BM + BN) * 128 + (LORA ? LORA_R * 128 : 0)) + BM * 8;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(KG == 1 || (BM / WM / 16) * (BN / WN / 16) * WM * WN * 1024 <= KG * NSTAGE * (BM + BN) * 128, "partial-tile exchange must fit the stage buffers");
-    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG, LORA>;
+    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG, LORA, STAG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -896,12 +1011,13 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
 
 // Tile configurations:  1: 128x128   2: 128x64   3: 64x128   4: 64x64   (4 waves, 2 x 2)
 //                       5: 256x128 (8 waves, 4 x 2)          6: 128x128 with two K groups (8 waves, intra-workgroup split-K)
+//                       7: 256x128, 8 waves in two groups one barrier slot apart (staggered memory / matrix sections), 3 LDS stages
 // The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
 // how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.  The engine
 // passes measured choices per shape (refiners_amd/engine/tuning.py); this heuristic is the fallback.
 inline int pick_tile(const GemmP& p, bool conv) {
-    if (g_tile >= 1 && g_tile <= 6) return g_tile;
-    if (p.tile_hint >= 1 && p.tile_hint <= 6) return p.tile_hint;
+    if (g_tile >= 1 && g_tile <= 7) return g_tile;
+    if (p.tile_hint >= 1 && p.tile_hint <= 7) return p.tile_hint;
     const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (conv) return 3;  // 64 x 128 wins for every conv shape of the UNet (r01_b probe: 339 / 540 / 570 TF at 32^2 / 64^2 / 128^2)
     if (p.geglu) return 1;
@@ -945,6 +1061,7 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
         case 3: return launch_stages<T, 64, 128, CONV>(p, st, stream);
         case 5: return st == 3 ? launch_cfg<T, 256, 128, 4, 2, CONV, 3>(p, stream) : launch_cfg<T, 256, 128, 4, 2, CONV, 2>(p, stream);
         case 6: return launch_cfg<T, 128, 128, 2, 2, CONV, 2, 2>(p, stream);
+        case 7: return launch_cfg<T, 256, 128, 4, 2, CONV, 3, 1, false, true>(p, stream);
         default: return launch_stages<T, 64, 64, CONV>(p, st, stream);
     }
 }

@@ -112,14 +112,14 @@ def gemm_lora_case(M, K, N, dtype, ranks=(16, 16), seed=10):
     return _cmp(out, ref, dtype)
 
 
-def gemm_geglu_case(M, K, n_out, dtype, seed=30):
+def gemm_geglu_case(M, K, n_out, dtype, seed=30, tile=0):
     x = _rand(M, K, dtype=dtype, seed=seed)
     w = _rand(2 * n_out, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
     b = _rand(2 * n_out, dtype=dtype, seed=seed + 2)
     idx = native.geglu_pack_index(n_out, device=DEV)
     wp, bp = w[idx].contiguous(), b[idx].contiguous()
     out = torch.empty(M, n_out, dtype=dtype, device=DEV)
-    native.gemm([(x, wp)], out, bias=bp, geglu=True)
+    native.gemm([(x, wp)], out, bias=bp, geglu=True, tile=tile)
     y = x.float() @ w.float().t() + b.float()
     a, g = y.chunk(2, dim=-1)
     ref = a * F.gelu(g, approximate="none")
@@ -790,10 +790,21 @@ def all_cases():
             (f"sinusoidal_{tag}_timestep", lambda dt=dt: sinusoidal_case(2, 320, 1, dt)),
             (f"sinusoidal_{tag}_time_ids", lambda dt=dt: sinusoidal_case(12, 256, 6, dt)),
         ]
-        for tile in (1, 2, 3, 4, 5, 6):
-            for st in ((2,) if tile == 6 else (2, 3) if tile == 5 else (2, 3, 4)):
+        for tile in (1, 2, 3, 4, 5, 6, 7):
+            for st in ((2,) if tile == 6 else (3,) if tile == 7 else (2, 3) if tile == 5 else (2, 3, 4)):
                 cases.append((f"gemm_{tag}_tile{tile}_s{st}_300x1472x328", lambda dt=dt, tile=tile, st=st: gemm_tile_case(300, 1472, 328, dt, tile, st)))
         cases += [
+            (f"gemm_{tag}_tile7_2048x10240x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 2560, dt, 7, 3, prefetch=True)),
+            (f"gemm_{tag}_tile7_oneblock", lambda dt=dt: gemm_tile_case(300, 128 // (4 if dt == torch.float32 else 2), 136, dt, 7, 3)),
+            (f"gemm_{tag}_tile7_twoblocks", lambda dt=dt: gemm_tile_case(520, 2 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 7, 3)),
+            (f"gemm_{tag}_tile7_threeblocks", lambda dt=dt: gemm_tile_case(520, 3 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 7, 3)),
+            (f"gemm_{tag}_tile7_splitk3", lambda dt=dt: gemm_splitk_case(600, 1920, 264, dt, 3, tile=7)),
+            (f"conv_{tag}_tile7", lambda dt=dt: conv_tile_case(2, 320, 320, 32, 32, dt, 7, 3)),
+            (f"conv_{tag}_tile7_splitk2", lambda dt=dt: conv_tile_case(1, 640, 256, 16, 16, dt, 7, 3, ksplit=2)),
+            (f"gemm_{tag}_qkv_tile7", lambda dt=dt: gemm_qkv_case(1024, 1280, 640, dt, tile=7)),
+            (f"gemm_{tag}_geglu_tile7", lambda dt=dt: gemm_geglu_case(520, 640, 2560, dt, tile=7)),
+            (f"gemm_{tag}_ln_chain_tiles_7_7", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=7, tile2=7)),
+            (f"gemm_{tag}_ln_chain_geglu_tile7", lambda dt=dt: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile2=7)),
             (f"gemm_{tag}_tile6_2048x1280x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 1280, dt, 6, 2, prefetch=True)),
             (f"gemm_{tag}_tile6_oneblock", lambda dt=dt: gemm_tile_case(200, 128 // (4 if dt == torch.float32 else 2), 136, dt, 6, 2)),
             (f"gemm_{tag}_tile1_s4_short_k", lambda dt=dt: gemm_tile_case(256, 2 * 128 // (4 if dt == torch.float32 else 2), 256, dt, 1, 4)),
