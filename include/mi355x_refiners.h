@@ -114,7 +114,8 @@ typedef struct {
                                6: 128x128 computed by 8 waves in two K groups (even / odd K blocks, summed through LDS in a fixed order):
                                for launches with fewer output tiles than CUs;
                                7: 256x128, 8 waves in two groups that run one barrier slot apart (one group's MFMA section overlaps the other's
-                               LDS-read / load-issue section), 3 LDS stages: for launches with many tiles */
+                               LDS-read / load-issue section), 3 LDS stages: for launches with many tiles;
+                               8: the same with two barrier slots per K block (32-MFMA sections) instead of four */
     int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
                                partial sums into `ws`, a second launch adds them in a fixed order (deterministic) and
                                applies the epilogue.  Not combinable with geglu. */

@@ -120,7 +120,7 @@ MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, flo
 
 constexpr int LORA_R = 32;  // stacked LoRA rank handled inside a launch (two rank-16 adapters, or anything that pads to 32)
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, bool STAG = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0>
 __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     constexpr int NW = WM * WN;           // waves per K group
     constexpr int NTHR = NW * 64;         // threads per K group: the loader geometry
@@ -579,7 +579,69 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
         }
         (void)HL;
     };
-    if constexpr (STAG) {
+    // The same with TWO slots per K block (STAG == 2): MEM(t) reads all 16 fragments of block t, issues this thread's 6 loads of block
+    // t+2 and waits for its part of block t+1; MMA(t) is 32 MFMAs.  Half the barriers, twice the fragment registers.
+    //   slot 2t: group 0 MEM(t), group 1 MMA(t-1);   slot 2t+1: group 0 MMA(t), group 1 MEM(t)
+    auto stagloop2 = [&](auto trc) {
+        constexpr bool TR = decltype(trc)::value;
+        frag_t xf[2][MT], wf[2][NT];
+        const int grp = wid / (NW / 2);
+        auto slot_end = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (total_kb > 1) wait_vm<LPS>();
+        else wait_vm0();
+        slot_end();
+        if (grp == 1) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < total_kb; ++t) {
+            const char* xs = smem_g + (t % NSTAGE) * STAGE;
+            const char* ws = xs + XBYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xf[kk][i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wf[kk][j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
+            }
+            if (t + 2 < total_kb) {
+                issue_half((t + 2) % NSTAGE, 0);
+                issue_half((t + 2) % NSTAGE, 1);
+                wait_vm<LPS>();
+            } else {
+                wait_vm0();
+            }
+            slot_end();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        if constexpr (TR) mma_step<T>(acc[i][j], xf[kk][i], wf[kk][j]);
+                        else mma_step<T>(acc[i][j], wf[kk][j], xf[kk][i]);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            slot_end();
+        }
+        if (grp == 0) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (STAG == 2) {
+        if constexpr (CONV) {
+            stagloop2(std::false_type{});
+        } else {
+            if (tr) stagloop2(std::true_type{});
+            else stagloop2(std::false_type{});
+        }
+    } else if constexpr (STAG == 1) {
         if constexpr (CONV) {
             stagloop(std::false_type{});
         } else {
@@ -946,7 +1008,7 @@ extern int g_pf_mode;    // 1 = plain loads, 2 = non-temporal
 extern int g_tile;       // 0 = heuristic / caller's hint, 1..6 = force a tile configuration (probing / A-B runs)
 extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS pipeline depth
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, bool STAG = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
     constexpr int LDS = KG * NSTAGE * ((BM + BN) * 128 + (LORA ? LORA_R * 128 : 0)) + BM * 8;
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -1016,8 +1078,8 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
 // how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.  The engine
 // passes measured choices per shape (refiners_amd/engine/tuning.py); this heuristic is the fallback.
 inline int pick_tile(const GemmP& p, bool conv) {
-    if (g_tile >= 1 && g_tile <= 7) return g_tile;
-    if (p.tile_hint >= 1 && p.tile_hint <= 7) return p.tile_hint;
+    if (g_tile >= 1 && g_tile <= 8) return g_tile;
+    if (p.tile_hint >= 1 && p.tile_hint <= 8) return p.tile_hint;
     const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (conv) return 3;  // 64 x 128 wins for every conv shape of the UNet (r01_b probe: 339 / 540 / 570 TF at 32^2 / 64^2 / 128^2)
     if (p.geglu) return 1;
@@ -1061,7 +1123,8 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
         case 3: return launch_stages<T, 64, 128, CONV>(p, st, stream);
         case 5: return st == 3 ? launch_cfg<T, 256, 128, 4, 2, CONV, 3>(p, stream) : launch_cfg<T, 256, 128, 4, 2, CONV, 2>(p, stream);
         case 6: return launch_cfg<T, 128, 128, 2, 2, CONV, 2, 2>(p, stream);
-        case 7: return launch_cfg<T, 256, 128, 4, 2, CONV, 3, 1, false, true>(p, stream);
+        case 7: return launch_cfg<T, 256, 128, 4, 2, CONV, 3, 1, false, 1>(p, stream);
+        case 8: return launch_cfg<T, 256, 128, 4, 2, CONV, 3, 1, false, 2>(p, stream);
         default: return launch_stages<T, 64, 64, CONV>(p, st, stream);
     }
 }

@@ -790,11 +790,19 @@ def all_cases():
             (f"sinusoidal_{tag}_timestep", lambda dt=dt: sinusoidal_case(2, 320, 1, dt)),
             (f"sinusoidal_{tag}_time_ids", lambda dt=dt: sinusoidal_case(12, 256, 6, dt)),
         ]
-        for tile in (1, 2, 3, 4, 5, 6, 7):
-            for st in ((2,) if tile == 6 else (3,) if tile == 7 else (2, 3) if tile == 5 else (2, 3, 4)):
+        for tile in (1, 2, 3, 4, 5, 6, 7, 8):
+            for st in ((2,) if tile == 6 else (3,) if tile in (7, 8) else (2, 3) if tile == 5 else (2, 3, 4)):
                 cases.append((f"gemm_{tag}_tile{tile}_s{st}_300x1472x328", lambda dt=dt, tile=tile, st=st: gemm_tile_case(300, 1472, 328, dt, tile, st)))
         cases += [
             (f"gemm_{tag}_tile7_2048x10240x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 2560, dt, 7, 3, prefetch=True)),
+            (f"gemm_{tag}_tile8_oneblock", lambda dt=dt: gemm_tile_case(300, 128 // (4 if dt == torch.float32 else 2), 136, dt, 8, 3)),
+            (f"gemm_{tag}_tile8_twoblocks", lambda dt=dt: gemm_tile_case(520, 2 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 8, 3)),
+            (f"gemm_{tag}_tile8_threeblocks", lambda dt=dt: gemm_tile_case(520, 3 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 8, 3)),
+            (f"gemm_{tag}_tile8_2048x2560x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 2560, dt, 8, 3, prefetch=True)),
+            (f"conv_{tag}_tile8_splitk2", lambda dt=dt: conv_tile_case(1, 640, 256, 16, 16, dt, 8, 3, ksplit=2)),
+            (f"conv_{tag}_tile8", lambda dt=dt: conv_tile_case(2, 320, 320, 32, 32, dt, 8, 3)),
+            (f"gemm_{tag}_qkv_tile8", lambda dt=dt: gemm_qkv_case(1024, 1280, 640, dt, tile=8)),
+            (f"gemm_{tag}_ln_chain_geglu_tile8", lambda dt=dt: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile1=8, tile2=8)),
             (f"gemm_{tag}_tile7_oneblock", lambda dt=dt: gemm_tile_case(300, 128 // (4 if dt == torch.float32 else 2), 136, dt, 7, 3)),
             (f"gemm_{tag}_tile7_twoblocks", lambda dt=dt: gemm_tile_case(520, 2 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 7, 3)),
             (f"gemm_{tag}_tile7_threeblocks", lambda dt=dt: gemm_tile_case(520, 3 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 7, 3)),

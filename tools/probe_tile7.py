@@ -26,7 +26,7 @@ for (M, K, N, geglu) in ((2048, 1280, 10240, True), (2048, 1280, 3840, False), (
     w = native.KBlocked((torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16())
     o = torch.empty(M, N // 2 if geglu else N, device="cuda", dtype=torch.bfloat16)
     line = f"M={M:5d} K={K:5d} N={N:5d} geglu={int(geglu)}:"
-    for tile, st in ((1, 2), (5, 2), (5, 3), (7, 3)):
+    for tile, st in ((1, 2), (5, 3), (7, 3), (8, 3)):
         t = min(timeit(lambda: native.gemm([(x, w)], o, geglu=geglu, tile=tile, stages=st)) for _ in range(3))
         line += f"  tile{tile}/s{st} {t * 1e6:7.1f} us {2 * M * K * N / t / 1e12:6.0f} TF"
     print(line, flush=True)
