@@ -12,13 +12,18 @@
 //     conflict-free reads, identical code for bf16 and f32 (no ds_read_tr needed);
 //   * the V^T tile rows are loaded in the permuted order R = 16j + 4a + b <-> d = 16a + 4j + b, so each lane ends up
 //     with 16 CONSECUTIVE head-dim outputs per query: the O store is 32/64 contiguous bytes per lane;
-//   * K and V^T tiles (64 keys) are staged with global_load_lds_dwordx4, source-swizzled, double buffered, one barrier
-//     per tile; Q, K, V are read in place from the (B, L, H*D) projection outputs: no head split / merge copies
-//     (reference: attentions.py:177-202).
+//   * K and V^T tiles (64 keys) go global -> registers -> LDS (double buffered, one barrier per tile) with the loads of the next TWO
+//     tiles in flight (two register sets, the compiler's counted vmcnt releases only the older one): a CFG pair's 1024-token
+//     self-attention is 320 workgroups on 256 CUs, one wave per SIMD, and with a single tile in flight its 16-tile loop ran at
+//     the latency of one Infinity-Cache round trip per tile.  (A global_load_lds variant with a 3-deep ring is kept for A/B.)
+//     Q, K, V are read in place from the (B, L, H*D) projection outputs: no head split / merge copies (reference: attentions.py:177-202).
+//   * the q-tiles of one (batch, head) are remapped onto ONE XCD (xcd_remap), so a head's K / V^T (256 KB at 1024 keys) is pulled
+//     into one private L2 instead of eight.
 //   * softmax in base 2 with the scale folded into one FMA; running max starts at -inf; keys beyond Lk are masked to
 //     -inf in the last tile only; deterministic (no atomics).
 #include "common.cuh"
 #include "../../include/mi355x_refiners.h"
+#include <type_traits>
 
 namespace {
 
@@ -40,10 +45,12 @@ struct AttnP {
     float c;  // scale * log2(e)
     KvP kv[2];
     int qtiles;
+    int xcd;  // 1 = XCD-aware block order
 };
 
-template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
+template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ, int RD = 2>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 2 : 1))) void attn_kernel(const AttnP p) {
+    // RD = register sets of the register-staged loader = K/V tiles in flight (1 or 2)
     // NJQ = 16-query groups per wave (2 = 32 queries; 1 = 16 queries: twice the waves per query, for launches too small to fill the chip)
     constexpr int D = 64, BKV = 64, BQW = 16 * NJQ;
     constexpr int ES = sizeof(T);
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
     const int g = lane >> 4, c16 = lane & 15;
     // grid: x = q tile (fastest), then head, then batch
-    int bid = blockIdx.x;
+    int bid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int qt = bid % p.qtiles;
     bid /= p.qtiles;
     const int h = bid % p.H;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
         vrowd[it] = 16 * a + 4 * j + bb;  // head-dim index stored in LDS row `row` of the V^T tile
     }
-    frag_t kr[LI], vr[LI];
+    frag_t kr[RD][LI], vr[RD][LI];
 
     f32x4 res[4][NJQ];
     if constexpr (NSTREAM > 1) {
@@ -110,7 +117,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         const char* kbase = kv.k + (int64_t)b * kv.kbsb + (int64_t)h * ROWB;
         const char* vbase = kv.vt + (int64_t)h * D * kv.ldvtb + (int64_t)b * kv.vtbsb;
 
-        auto issue = [&](int tile, int buf) {
+        auto issue = [&](int tile, int buf, auto rs) {  // rs = register set (register-staged loader only)
+            constexpr int RS = decltype(rs)::value;
             char* ks = smem + buf * STAGE;
             char* vs = ks + TILEB;
             const int kv0 = tile * BKV;
@@ -120,25 +128,28 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                 kr_ = kr_ < Lk ? kr_ : Lk - 1;
                 const char* src = kbase + (int64_t)kr_ * kv.ldkb + lcoff[it];
                 if constexpr (GLDS) glds16(src, ks + (it * NTHR + wid * 64) * 16);
-                else kr[it] = *reinterpret_cast<const frag_t*>(src);
+                else kr[RS][it] = *reinterpret_cast<const frag_t*>(src);
             }
 #pragma unroll
             for (int it = 0; it < LI; ++it) {
                 const char* src = vbase + (int64_t)vrowd[it] * kv.ldvtb + (int64_t)kv0 * ES + lcoff[it];
                 if constexpr (GLDS) glds16(src, vs + (it * NTHR + wid * 64) * 16);
-                else vr[it] = *reinterpret_cast<const frag_t*>(src);
+                else vr[RS][it] = *reinterpret_cast<const frag_t*>(src);
             }
         };
-        auto commit = [&](int buf) {
+        auto commit = [&](int buf, auto rs) {
+            constexpr int RS = decltype(rs)::value;
             if constexpr (!GLDS) {
                 char* ks = smem + buf * STAGE;
                 char* vs = ks + TILEB;
 #pragma unroll
-                for (int it = 0; it < LI; ++it) *reinterpret_cast<frag_t*>(ks + (it * NTHR + tid) * 16) = kr[it];
+                for (int it = 0; it < LI; ++it) *reinterpret_cast<frag_t*>(ks + (it * NTHR + tid) * 16) = kr[RS][it];
 #pragma unroll
-                for (int it = 0; it < LI; ++it) *reinterpret_cast<frag_t*>(vs + (it * NTHR + tid) * 16) = vr[it];
+                for (int it = 0; it < LI; ++it) *reinterpret_cast<frag_t*>(vs + (it * NTHR + tid) * 16) = vr[RS][it];
             }
         };
+        using rs0_t = std::integral_constant<int, 0>;
+        using rs1_t = std::integral_constant<int, RD - 1>;
 
         f32x4 o[4][NJQ];
 #pragma unroll
@@ -154,15 +165,24 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         if constexpr (GLDS) {
 #pragma unroll
             for (int s0 = 0; s0 < PD; ++s0)
-                if (s0 < ntile) issue(s0, s0);
+                if (s0 < ntile) issue(s0, s0, rs0_t{});
         } else {
-            issue(0, 0);
-            commit(0);
-            wait_vm0();
+            issue(0, 0, rs0_t{});
+            if constexpr (RD == 2) {
+                if (ntile > 1) issue(1, 1, rs1_t{});
+            }
+            commit(0, rs0_t{});  // waits for set 0 only
             __syncthreads();
         }
 
-        for (int tile = 0; tile < ntile; ++tile) {
+        // one K/V tile; `par` = tile & 1 as a type, so that the register set is a compile-time index
+        // `always` = the loop guarantees tile + 2 < ntile: the refill is then unconditional, which is what lets the compiler's vmcnt at the
+        // commit leave it in flight (behind a branch it has to assume the committed set is the youngest and drains everything)
+        auto tile_body = [&](int tile, auto par, auto always) {
+            constexpr int PAR = decltype(par)::value;
+            constexpr bool ALWAYS = decltype(always)::value;
+            using cur_set = std::integral_constant<int, (RD == 2 ? PAR : 0)>;      // free set: tile `tile` was committed from it
+            using nxt_set = std::integral_constant<int, (RD == 2 ? 1 - PAR : 0)>;  // holds tile + 1 (in flight) when RD == 2
             int cur;
             const bool more = tile + 1 < ntile;
             if constexpr (GLDS) {
@@ -171,11 +191,15 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                 else wait_vm0();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (tile + PD < ntile) issue(tile + PD, (tile + PD) % NST);
+                if (tile + PD < ntile) issue(tile + PD, (tile + PD) % NST, rs0_t{});
                 cur = tile % NST;
             } else {
-                cur = tile & 1;
-                if (more) issue(tile + 1, cur ^ 1);
+                cur = PAR;
+                if constexpr (RD == 2) {
+                    if (ALWAYS || tile + 2 < ntile) issue(tile + 2, cur, cur_set{});
+                } else {
+                    if (more) issue(tile + 1, cur ^ 1, cur_set{});
+                }
             }
             const char* ks = smem + cur * STAGE;
             const char* vs = ks + TILEB;
@@ -272,9 +296,23 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                 }
             }
             if constexpr (!GLDS) {
-                if (more) commit(cur ^ 1);
-                wait_vm0();
+                if (more) commit(cur ^ 1, nxt_set{});  // the compiler's vmcnt covers exactly this set: tile + 2 stays in flight
                 __syncthreads();
+            }
+        };
+        {
+            using P0 = std::integral_constant<int, 0>;
+            using P1 = std::integral_constant<int, 1>;
+            int tile = 0;
+            if constexpr (!GLDS && RD == 2) {
+                for (; tile + 3 < ntile; tile += 2) {
+                    tile_body(tile, P0{}, std::true_type{});
+                    tile_body(tile + 1, P1{}, std::true_type{});
+                }
+            }
+            for (; tile < ntile; tile += 2) {
+                tile_body(tile, P0{}, std::false_type{});
+                if (tile + 1 < ntile) tile_body(tile + 1, P1{}, std::false_type{});
             }
         }
 
@@ -315,12 +353,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     }
 }
 
-int g_attn_glds = 0;  // register-staged K/V loader by default: measured faster than glds for attention (probe_attn3)
+int g_attn_glds = 0;   // register-staged K/V loader by default: measured faster than glds for attention (probe_attn3)
+int g_attn_depth = 2;  // K/V tiles in flight in the register-staged loader (mi355x_attention_set_pipeline)
+int g_attn_xcd = 1;    // q-tiles of a head on one XCD
 
-template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ = 2>
+template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ = 2, int RD = 2>
 int launch_attn(const AttnP& p0, hipStream_t stream) {
     constexpr int LDS = (GLDS ? 3 : 2) * 2 * 64 * 64 * sizeof(T);
-    auto kfn = attn_kernel<T, NW, NSTREAM, GLDS, NJQ>;
+    auto kfn = attn_kernel<T, NW, NSTREAM, GLDS, NJQ, RD>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -328,6 +368,7 @@ int launch_attn(const AttnP& p0, hipStream_t stream) {
     }
     AttnP p = p0;
     p.qtiles = (p.Lq + 16 * NJQ * NW - 1) / (16 * NJQ * NW);
+    p.xcd = g_attn_xcd;
     const int grid = p.qtiles * p.H * p.B;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
@@ -340,6 +381,10 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
     if (g_attn_glds) {
         if (p.nstream == 2) return launch_attn<T, NW, 2, true>(p, stream);
         return launch_attn<T, NW, 1, true>(p, stream);
+    }
+    if (g_attn_depth == 1 || NW == 2) {  // the 2-wave workgroup stages twice the registers per lane: one set only
+        if (p.nstream == 2) return launch_attn<T, NW, 2, false, 2, 1>(p, stream);
+        return launch_attn<T, NW, 1, false, 2, 1>(p, stream);
     }
     if (p.nstream == 2) return launch_attn<T, NW, 2, false>(p, stream);
     return launch_attn<T, NW, 1, false>(p, stream);
@@ -365,6 +410,12 @@ extern "C" int mi355x_attention_set_nw(int v) {
 
 extern "C" int mi355x_attention_set_glds(int v) {
     g_attn_glds = v;
+    return MI355X_OK;
+}
+
+extern "C" int mi355x_attention_set_pipeline(int tiles_in_flight, int xcd_aware) {  // probing / A-B only, not part of the stable contract
+    if (tiles_in_flight == 1 || tiles_in_flight == 2) g_attn_depth = tiles_in_flight;
+    if (xcd_aware >= 0) g_attn_xcd = xcd_aware ? 1 : 0;
     return MI355X_OK;
 }
 

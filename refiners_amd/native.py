@@ -310,6 +310,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_groupnorm_set_fused.argtypes = [C.c_int, C.c_int64]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
+    lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
     if lib.mi355x_abi_version() != 3:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
@@ -317,7 +318,16 @@ def load(path: Optional[Path] = None) -> C.CDLL:
 
     if os.environ.get("REFINERS_AMD_GN_FUSED", "1") == "0":  # A/B: always the three-kernel GroupNorm
         lib.mi355x_groupnorm_set_fused(0, 0)
+    attention_pipeline_from_env()
     return lib
+
+
+def attention_pipeline_from_env() -> None:
+    """A/B: REFINERS_AMD_ATTN_PIPE="<K/V tiles in flight 1|2>,<XCD-aware block order 0|1>" (default 2,1); read at launch / capture time."""
+    import os
+
+    d, x = (os.environ.get("REFINERS_AMD_ATTN_PIPE", "2,1").replace("/", ",").split(",") + ["1"])[:2]
+    _lib.mi355x_attention_set_pipeline(int(d), int(x))
 
 
 def available() -> bool:

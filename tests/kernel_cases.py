@@ -257,7 +257,7 @@ def attention_case(B, H, Lq, Lk, dtype, *, ip_tokens=0, ip_scale=0.7, spike=Fals
     if ip_tokens:
         k2 = _rand(B, ip_tokens, Cc, dtype=dtype, seed=seed + 3)
         v2 = _rand(B, ip_tokens, Cc, dtype=dtype, seed=seed + 4)
-        streams.append((k2, _vt_from_v(v2, 64), ip_tokens, ip_scale))
+        streams.append((k2, _vt_from_v(v2, (ip_tokens + 63) // 64 * 64), ip_tokens, ip_scale))
         ref = ref + ip_scale * _sdpa_ref(q, k2, v2, H)
     out = torch.full((B, Lq, Cc), float("nan"), dtype=dtype, device=DEV)
     native.attention(q, out, H, streams)
@@ -752,6 +752,12 @@ def all_cases():
             (f"attn_{tag}_cross_77", lambda dt=dt: attention_case(2, 10, 1024, 77, dt)),
             (f"attn_{tag}_cross_77_ip4", lambda dt=dt: attention_case(2, 10, 512, 77, dt, ip_tokens=4)),
             (f"attn_{tag}_Lq_edge_200", lambda dt=dt: attention_case(1, 2, 200, 128, dt)),
+            # tile counts around the two-tiles-in-flight loop's peel points (1, 3, 4, 5 tiles, ragged last tile), and a second stream of 3 tiles
+            (f"attn_{tag}_1tile", lambda dt=dt: attention_case(1, 3, 160, 64, dt, seed=71)),
+            (f"attn_{tag}_3tiles", lambda dt=dt: attention_case(2, 2, 192, 192, dt, seed=72)),
+            (f"attn_{tag}_4tiles", lambda dt=dt: attention_case(1, 2, 256, 256, dt, seed=73)),
+            (f"attn_{tag}_5tiles_ragged", lambda dt=dt: attention_case(1, 2, 130, 257, dt, seed=74)),
+            (f"attn_{tag}_7tiles_ip130", lambda dt=dt: attention_case(1, 2, 128, 448, dt, ip_tokens=130, seed=75)),
             (f"attng_{tag}_d40_self", lambda dt=dt: attention_general_case(2, 8, 1024, 1024, 40, 40, dt)),
             (f"attng_{tag}_d40_cross77", lambda dt=dt: attention_general_case(2, 8, 320, 77, 40, 40, dt)),
             (f"attng_{tag}_d80_self", lambda dt=dt: attention_general_case(2, 8, 256, 256, 80, 80, dt, spike=True)),

@@ -88,7 +88,10 @@ def test_merged_lora_mode_adds_no_step_launch():
     io.tokens[("ip_adapter", "clip_image_embedding")] = (torch.zeros(128, 2048, device=dev, dtype=torch.bfloat16), 4)
     low = UNetLowering(dev, torch.bfloat16, None, "merged")
     low.lower(unet, io)
-    assert len(low.step) == 981 and low.stats["lora_sites"] == 722 and low.stats["ip_sites"] == 70
+    # 981 launches of the bare tree (LayerNorm folding / Q|K|V merging are device-only decisions, off on meta) minus the 17 per-ResidualBlock
+    # time projections, which ride in one batched launch
+    assert len(low.step) == 981 - 17 + 1 and low.stats["lora_sites"] == 722 and low.stats["ip_sites"] == 70
+    assert low.stats["time_bias_batched"] == 17
 
 
 def test_sd1_tree_lowers_onto_the_general_attention_kernel_for_its_head_dims():

@@ -1,6 +1,7 @@
 """A/B of the lowering switches on the SDXL step, one process, one set of weights: step time (HIP graph) per variant and the
 per-family replay of the last one.  Variants are given as name=ENV1:val,ENV2:val ...; flags read at lowering time
-(REFINERS_AMD_LN_FUSE, REFINERS_AMD_QKV_MERGE, REFINERS_AMD_TUNING, REFINERS_AMD_KBLOCK, REFINERS_AMD_WEIGHT_PREFETCH).
+(REFINERS_AMD_LN_FUSE, REFINERS_AMD_QKV_MERGE, REFINERS_AMD_TUNING, REFINERS_AMD_KBLOCK, REFINERS_AMD_WEIGHT_PREFETCH,
+REFINERS_AMD_TIME_BATCH, REFINERS_AMD_ATTN_PIPE).
 
     python tools/ab_step.py --workload lora_ip base=REFINERS_AMD_LN_FUSE:0,REFINERS_AMD_QKV_MERGE:0,REFINERS_AMD_TUNING:0 all=
 """
@@ -21,7 +22,7 @@ from refiners_amd import native  # noqa: E402
 from refiners_amd.engine import tuning  # noqa: E402
 from refiners_amd.engine.compiled import CompiledSDXL  # noqa: E402
 
-KEYS = ("REFINERS_AMD_GN_FUSED", "REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH")
+KEYS = ("REFINERS_AMD_GN_FUSED", "REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH", "REFINERS_AMD_TIME_BATCH", "REFINERS_AMD_ATTN_PIPE")
 
 
 def main() -> None:
@@ -47,6 +48,7 @@ def main() -> None:
             k, v = kv.split(":")
             os.environ[k] = v
         native.load().mi355x_groupnorm_set_fused(int(os.environ.get("REFINERS_AMD_GN_FUSED", "1") != "0"), 0)  # decided at launch / capture time
+        native.attention_pipeline_from_env()
         tuning.enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
         tuning._table = None
         p = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=True, lora_mode=args.lora_mode)

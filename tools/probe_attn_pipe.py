@@ -1,0 +1,62 @@
+"""Attention at the SDXL step's shapes: K/V tiles in flight (1 / 2 register sets) x XCD-aware block order (mi355x_attention_set_pipeline).
+
+Each configuration is timed over a rotation of 6 independent (q, k, v^T) sets (63-94 MB apiece at the large shapes), so that K / V come
+from the Infinity Cache or HBM as they do in the step, not from a hot L2.
+"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+from refiners_amd import native  # noqa: E402
+
+
+def time_us(fns, n=60):
+    for f in fns:
+        f()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(n):
+        fns[i % len(fns)]()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+def main():
+    lib = native.load()
+    lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
+    dt = torch.bfloat16
+    shapes = ((2, 20, 1024, 1024, 0), (2, 10, 4096, 4096, 0), (2, 20, 1024, 77, 4), (2, 10, 4096, 77, 4), (8, 20, 1024, 1024, 0), (8, 10, 4096, 4096, 0))
+    for (B, H, Lq, Lk, Lk2) in shapes:
+        Cc = H * 64
+        sets = []
+        for _ in range(6):
+            q = torch.randn(B, Lq, Cc, device="cuda", dtype=dt)
+            out = torch.empty(B, Lq, Cc, device="cuda", dtype=dt)
+            streams = []
+            for L in filter(None, (Lk, Lk2)):
+                k = torch.randn(B, L, Cc, device="cuda", dtype=dt)
+                vt = torch.randn(Cc, B, (L + 63) // 64 * 64, device="cuda", dtype=dt)
+                streams.append((k, vt, L, 1.0))
+            sets.append((q, out, streams))
+        fns = [(lambda s=s: native.attention(s[0], s[1], H, s[2])) for s in sets]
+        line = f"B={B} H={H} Lq={Lq} Lk={Lk}{'+%d' % Lk2 if Lk2 else ''}:"
+        ref = None
+        for depth, xcd in ((1, 0), (1, 1), (2, 0), (2, 1)):
+            lib.mi355x_attention_set_pipeline(depth, xcd)
+            us = time_us(fns)
+            o = sets[0][1].float().clone()
+            if ref is None:
+                ref = o
+            same = bool(torch.equal(ref, o))
+            line += f"  d{depth}x{xcd}: {us:7.1f} us {4.0 * B * H * Lq * (Lk + Lk2) * 64 / us / 1e6:6.0f} TF{'' if same else ' DIFF'}"
+        lib.mi355x_attention_set_pipeline(2, 1)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
