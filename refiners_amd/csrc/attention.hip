@@ -48,9 +48,48 @@ struct AttnP {
     int xcd;  // 1 = XCD-aware block order
 };
 
-template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ, int RD = 2>
+// lane <-> lane ^ 16 and lane <-> lane ^ 32 exchanges as row / half swaps (gfx950): after swap(a = x, b = x), a and b hold the two partners'
+// values in every lane.  Inline asm (the builtin form folds the combine of its two results away when both inputs are the same value);
+// s_nop 1 = the two wait states a VALU write of an operand needs before the swap reads it.
+MI_DEV void xswap16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+MI_DEV void xswap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+template <bool PL> MI_DEV float group_max(float x) {
+    if constexpr (PL) {
+        float a = x, b = x;
+        xswap16(a, b);
+        a = fmaxf(a, b), b = a;
+        xswap32(a, b);
+        return fmaxf(a, b);
+    } else {
+        x = fmaxf(x, __shfl_xor(x, 16));
+        return fmaxf(x, __shfl_xor(x, 32));
+    }
+}
+template <bool PL> MI_DEV float group_sum(float x) {
+    if constexpr (PL) {
+        float a = x, b = x;
+        xswap16(a, b);
+        a = a + b, b = a;
+        xswap32(a, b);
+        return a + b;
+    } else {
+        x += __shfl_xor(x, 16);
+        return x + __shfl_xor(x, 32);
+    }
+}
+
+template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ, int RD = 2, int OPT = 0, int ABL = 0, int KVS = 1>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 2 : 1))) void attn_kernel(const AttnP p) {
     // RD = register sets of the register-staged loader = K/V tiles in flight (1 or 2)
+    // OPT bit 0: the two cross-group reductions of the online softmax as v_permlane16/32_swap (VALU) instead of ds_bpermute round trips;
+    //     bit 1: all K fragments of a tile read before its first MFMA, all V^T fragments before the softmax (one exposed LDS latency per phase)
+    // ABL (probing only, results are wrong): 1 = no K/V traffic after the first tile, 2 = no softmax, 4 = no P V product, 8 = no Q K^T product,
+    //     16 = no output store, 32 = no Q load, 64 = no K/V load at all
+    // KVS = 2: key-split workgroup for grids that leave the SIMDs with one wave each (a CFG pair's 1024-token self-attention): the NW waves
+    //     are NW/2 query groups x 2 key groups; key group kg works on keys 32 kg .. 32 kg + 31 of every 64-key tile (half of the Q K^T, softmax
+    //     and P V chain per tile, its own running max / sum / O), and the two partial results are merged once at the end through LDS
+    //     (O = O0 2^(c (m0 - m)) + O1 2^(c (m1 - m)), same for the sums).  Twice the workgroups for the same queries, each wave's dependent
+    //     chain half as long; the price is that a workgroup stages the whole K / V^T for 64 queries instead of 128.
     // NJQ = 16-query groups per wave (2 = 32 queries; 1 = 16 queries: twice the waves per query, for launches too small to fill the chip)
     constexpr int D = 64, BKV = 64, BQW = 16 * NJQ;
     constexpr int ES = sizeof(T);
@@ -66,6 +105,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
     constexpr int NS = D / DT<T>::KSTEP;  // MMA steps over head dim
     constexpr bool IS_BF16 = (ES == 2);
     static_assert(64 * CPR % NTHR == 0, "loader mismatch");
+    static_assert(KVS == 1 || (KVS == 2 && NSTREAM == 1 && !GLDS && NW % 2 == 0), "key-split: one stream, register-staged loader");
+    constexpr int QW = NW / KVS;   // query groups (waves along the queries)
+    constexpr int TT = 4 / KVS;    // 16-key slices of a tile per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
@@ -76,7 +118,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
     bid /= p.qtiles;
     const int h = bid % p.H;
     const int b = bid / p.H;
-    const int q0 = qt * (BQW * NW) + wid * BQW;
+    const int qg = KVS == 1 ? wid : wid % QW, kg = KVS == 1 ? 0 : wid / QW;
+    const int q0 = qt * (BQW * QW) + qg * BQW;
 
     // ---- Q fragments (B operand), straight from global ----
     frag_t qf[NJQ][NS];
@@ -86,7 +129,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
         qr = qr < p.Lq ? qr : p.Lq - 1;
         const char* qp = p.q + (int64_t)b * p.qbsb + (int64_t)qr * p.ldqb + (int64_t)h * ROWB;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) qf[jq][s] = *reinterpret_cast<const frag_t*>(qp + (4 * s + g) * 16);
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (ABL & 32) qf[jq][s] = frag_t{lane, s, jq, 0x3c003c00};
+            else qf[jq][s] = *reinterpret_cast<const frag_t*>(qp + (4 * s + g) * 16);
+        }
     }
 
     // ---- loader coordinates ----
@@ -167,11 +213,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
             for (int s0 = 0; s0 < PD; ++s0)
                 if (s0 < ntile) issue(s0, s0, rs0_t{});
         } else {
-            issue(0, 0, rs0_t{});
+            if constexpr (!(ABL & 64)) issue(0, 0, rs0_t{});
             if constexpr (RD == 2) {
                 if (ntile > 1) issue(1, 1, rs1_t{});
             }
-            commit(0, rs0_t{});  // waits for set 0 only
+            if constexpr (!(ABL & 64)) commit(0, rs0_t{});  // waits for set 0 only
             __syncthreads();
         }
 
@@ -196,35 +242,73 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
             } else {
                 cur = PAR;
                 if constexpr (RD == 2) {
-                    if (ALWAYS || tile + 2 < ntile) issue(tile + 2, cur, cur_set{});
+                    if (!(ABL & 1) && (ALWAYS || tile + 2 < ntile)) issue(tile + 2, cur, cur_set{});
                 } else {
-                    if (more) issue(tile + 1, cur ^ 1, cur_set{});
+                    if (!(ABL & 1) && more) issue(tile + 1, cur ^ 1, cur_set{});
                 }
             }
-            const char* ks = smem + cur * STAGE;
+            const char* ks = smem + ((ABL & 1) ? 0 : cur) * STAGE;
             const char* vs = ks + TILEB;
 
             // ---- S^T = K Q^T ----
-            f32x4 st[4][NJQ];
+            f32x4 st[TT][NJQ];
+            if constexpr (ABL & 8) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < TT; ++t)
 #pragma unroll
-                for (int jq = 0; jq < NJQ; ++jq) st[t][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int jq = 0; jq < NJQ; ++jq) st[t][jq] = __builtin_bit_cast(f32x4, qf[jq][t % NS]);
+            } else if constexpr ((OPT & 2) && KVS == 1) {
+                frag_t kf[4][NS];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const frag_t kf = lds_read_frag(ks, tile_off<ROWB>(16 * t + c16, 4 * s + g));
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(st[t][jq], kf, qf[jq][s]);
+                    for (int s = 0; s < NS; ++s) kf[t][s] = lds_read_frag(ks, tile_off<ROWB>(16 * t + c16, 4 * s + g));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int jq = 0; jq < NJQ; ++jq) st[t][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(st[t][jq], kf[t][s], qf[jq][s]);
                 }
+            } else {
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+#pragma unroll
+                    for (int jq = 0; jq < NJQ; ++jq) st[t][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const frag_t kf = lds_read_frag(ks, tile_off<ROWB>(16 * (kg * TT + t) + c16, 4 * s + g));
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(st[t][jq], kf, qf[jq][s]);
+                    }
+                }
+            }
+            // V^T fragments of this tile, requested before the softmax so that they land under its VALU work (bf16, OPT bit 1)
+            constexpr bool VPRE = IS_BF16 && (OPT & 2) && !(ABL & 4) && KVS == 1;
+            frag_t vpre[VPRE ? 2 : 1][VPRE ? 4 : 1];
+            if constexpr (VPRE) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 16 * i + c16;
+                        const int chunk = 4 * s2 + (g >> 1);
+                        const int sw = swz<ROWB>(row);
+                        const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
+                        const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
+                        vpre[s2][i] = frag_t{va[0], va[1], vb[0], vb[1]};
+                    }
             }
             // ---- mask the tail tile ----
             const int kv0 = tile * BKV;
             if (kv0 + BKV > Lk) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < TT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (kv0 + 16 * t + 4 * g + r >= Lk) {
+                        if (kv0 + 16 * (kg * TT + t) + 4 * g + r >= Lk) {
 #pragma unroll
                             for (int jq = 0; jq < NJQ; ++jq) st[t][jq][r] = -INFINITY;
                         }
@@ -233,19 +317,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
             // ---- online softmax (per lane: one query column per jq) ----
 #pragma unroll
             for (int jq = 0; jq < NJQ; ++jq) {
+                if constexpr (ABL & 2) {
+                    float ps = 0.f;
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ps += st[t][jq][r];
+                    lsum[jq] += ps;
+                    continue;
+                }
                 float mx = st[0][jq][0];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < TT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][jq][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float mnew = fmaxf(mrun[jq], mx);
+                mx = group_max<(OPT & 1) != 0>(mx);
+                float mnew = fmaxf(mrun[jq], mx);
+                if constexpr (KVS == 2) mnew = fmaxf(mnew, -3.0e38f);  // a key group can see nothing but masked keys (Lk <= 32): keep the arithmetic finite
                 const float alpha = fast_exp2((mrun[jq] - mnew) * p.c);
                 const float mc = mnew * p.c;
                 float ps = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < TT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float e = fast_exp2(st[t][jq][r] * p.c - mc);
@@ -258,45 +351,56 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
             }
             // ---- O^T += V^T P^T ----
-            if constexpr (IS_BF16) {
+            if constexpr (ABL & 4) {
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jq = 0; jq < NJQ; ++jq) o[i][jq] += st[i % TT][jq];
+            } else if constexpr (IS_BF16) {
+#pragma unroll
+                for (int s2l = 0; s2l < 2 / KVS; ++s2l) {
+                    const int s2 = KVS == 1 ? s2l : kg;  // 32-key half of the tile (key-split: this wave's half)
                     frag_t pb[NJQ];
 #pragma unroll
                     for (int jq = 0; jq < NJQ; ++jq) {
                         bf16x8 pk;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            pk[r] = (bf16_t)st[2 * s2][jq][r];
-                            pk[4 + r] = (bf16_t)st[2 * s2 + 1][jq][r];
+                            pk[r] = (bf16_t)st[2 * s2l][jq][r];
+                            pk[4 + r] = (bf16_t)st[2 * s2l + 1][jq][r];
                         }
                         pb[jq] = __builtin_bit_cast(frag_t, pk);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int row = 16 * i + c16;
-                        const int chunk = 4 * s2 + (g >> 1);
-                        const int sw = swz<ROWB>(row);
-                        const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
-                        const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
-                        const frag_t vf = frag_t{va[0], va[1], vb[0], vb[1]};
+                        frag_t vf;
+                        if constexpr (VPRE) {
+                            vf = vpre[s2l][i];
+                        } else {
+                            const int row = 16 * i + c16;
+                            const int chunk = 4 * s2 + (g >> 1);
+                            const int sw = swz<ROWB>(row);
+                            const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
+                            const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
+                            vf = frag_t{va[0], va[1], vb[0], vb[1]};
+                        }
 #pragma unroll
                         for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, pb[jq]);
                     }
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < TT; ++t) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const frag_t vf = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * t + g));
+                        const frag_t vf = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * (kg * TT + t) + g));
 #pragma unroll
                         for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, __builtin_bit_cast(frag_t, st[t][jq]));
                     }
                 }
             }
             if constexpr (!GLDS) {
-                if (more) commit(cur ^ 1, nxt_set{});  // the compiler's vmcnt covers exactly this set: tile + 2 stays in flight
+                if (!(ABL & 1) && more) commit(cur ^ 1, nxt_set{});  // the compiler's vmcnt covers exactly this set: tile + 2 stays in flight
                 __syncthreads();
             }
         };
@@ -316,12 +420,41 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
             }
         }
 
+        // ---- key-split: fold key group 1's partial result into key group 0's (LDS is free: the loop ended on a barrier) ----
+        if constexpr (KVS == 2) {
+            constexpr int NV = 18 * NJQ;  // 16 O values + running max + running sum per 16-query group
+            float* mg = reinterpret_cast<float*>(smem) + (qg * NV) * 64 + lane;  // [query group][value][lane]: conflict-free
+            if (kg == 1) {
+#pragma unroll
+                for (int jq = 0; jq < NJQ; ++jq) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mg[(jq * 18 + 4 * i + r) * 64] = o[i][jq][r];
+                    mg[(jq * 18 + 16) * 64] = mrun[jq];
+                    mg[(jq * 18 + 17) * 64] = lsum[jq];
+                }
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int jq = 0; jq < NJQ; ++jq) {
+                    const float m1 = mg[(jq * 18 + 16) * 64], l1 = mg[(jq * 18 + 17) * 64];
+                    const float m = fmaxf(mrun[jq], m1);
+                    const float a0 = fast_exp2((mrun[jq] - m) * p.c), a1 = fast_exp2((m1 - m) * p.c);  // m1 = -inf (no tile seen): a1 = 0
+                    lsum[jq] = lsum[jq] * a0 + l1 * a1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[i][jq][r] = o[i][jq][r] * a0 + mg[(jq * 18 + 4 * i + r) * 64] * a1;
+                }
+            }
+        }
+
         // ---- finish this stream ----
 #pragma unroll
         for (int jq = 0; jq < NJQ; ++jq) {
-            float l = lsum[jq];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
+            const float l = group_sum<(OPT & 1) != 0>(lsum[jq]);
             const float inv = kv.out_scale / l;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -336,7 +469,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
 #pragma unroll
     for (int jq = 0; jq < NJQ; ++jq) {
         const int qr = q0 + 16 * jq + c16;
-        if (qr >= p.Lq) continue;
+        if (qr >= p.Lq || kg != 0) continue;
+        if constexpr (ABL & 16) {
+            if (res[0][jq][0] != 12345.678f) continue;
+        }
         T* op = reinterpret_cast<T*>(p.out + (int64_t)b * p.obsb + (int64_t)qr * p.ldob + (int64_t)h * ROWB) + 16 * g;
         float v[16];
 #pragma unroll
@@ -354,20 +490,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
 }
 
 int g_attn_glds = 0;   // register-staged K/V loader by default: measured faster than glds for attention (probe_attn3)
-int g_attn_depth = 2;  // K/V tiles in flight in the register-staged loader (mi355x_attention_set_pipeline)
+int g_attn_depth = 1;  // K/V tiles in flight in the register-staged loader (mi355x_attention_set_pipeline); 2 measured no better (r02_j_probe_attn.log)
 int g_attn_xcd = 1;    // q-tiles of a head on one XCD
+int g_attn_opt = 1;    // OPT bits of attn_kernel (permlane reductions: +1-4 % on every self-attention shape, r02_k / r02_m probes)
+int g_attn_abl = 0;    // ABL bits (probing)
+int g_attn_kvs = 0;    // key-split workgroups: 0 = where the grid is short (see launch_attn_nw), 1 = never, 2 = always (single-stream launches)
 
-template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ = 2, int RD = 2>
+template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ = 2, int RD = 2, int OPT = 0, int ABL = 0, int KVS = 1>
 int launch_attn(const AttnP& p0, hipStream_t stream) {
     constexpr int LDS = (GLDS ? 3 : 2) * 2 * 64 * 64 * sizeof(T);
-    auto kfn = attn_kernel<T, NW, NSTREAM, GLDS, NJQ, RD>;
+    auto kfn = attn_kernel<T, NW, NSTREAM, GLDS, NJQ, RD, OPT, ABL, KVS>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     AttnP p = p0;
-    p.qtiles = (p.Lq + 16 * NJQ * NW - 1) / (16 * NJQ * NW);
+    constexpr int BQ = 16 * NJQ * NW / KVS;  // queries per workgroup
+    p.qtiles = (p.Lq + BQ - 1) / BQ;
     p.xcd = g_attn_xcd;
     const int grid = p.qtiles * p.H * p.B;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), LDS, stream, p);
@@ -376,26 +516,65 @@ int launch_attn(const AttnP& p0, hipStream_t stream) {
 
 int g_attn_nw = 0;  // 0 = heuristic, 2 / 4 = force the number of waves (32 queries each) per workgroup
 
+template <typename T, int NW, int OPT>
+int launch_attn_opt(const AttnP& p, hipStream_t stream) {
+    if constexpr (NW != 2) {  // the 2-wave workgroup stages twice the registers per lane: one set only
+        if (g_attn_depth == 2) {
+            if constexpr (OPT != 2) {  // (two streams, two register sets, hoisted fragment reads) does not fit 256 registers
+                if (p.nstream == 2) return launch_attn<T, NW, 2, false, 2, 2, OPT>(p, stream);
+            }
+            if (p.nstream == 1) return launch_attn<T, NW, 1, false, 2, 2, OPT>(p, stream);
+        }
+    }
+    if (p.nstream == 2) return launch_attn<T, NW, 2, false, 2, 1, OPT>(p, stream);
+    return launch_attn<T, NW, 1, false, 2, 1, OPT>(p, stream);
+}
+
 template <typename T, int NW>
 int launch_attn_nw(const AttnP& p, hipStream_t stream) {
     if (g_attn_glds) {
         if (p.nstream == 2) return launch_attn<T, NW, 2, true>(p, stream);
         return launch_attn<T, NW, 1, true>(p, stream);
     }
-    if (g_attn_depth == 1 || NW == 2) {  // the 2-wave workgroup stages twice the registers per lane: one set only
-        if (p.nstream == 2) return launch_attn<T, NW, 2, false, 2, 1>(p, stream);
-        return launch_attn<T, NW, 1, false, 2, 1>(p, stream);
+    if constexpr (NW == 4 && sizeof(T) == 2) {
+        if (g_attn_abl && p.nstream == 1) {  // probing: where a tile's time goes (wrong results by construction)
+            switch (g_attn_abl) {
+                case 1: return launch_attn<T, 4, 1, false, 2, 1, 0, 1>(p, stream);
+                case 2: return launch_attn<T, 4, 1, false, 2, 1, 0, 2>(p, stream);
+                case 4: return launch_attn<T, 4, 1, false, 2, 1, 0, 4>(p, stream);
+                case 8: return launch_attn<T, 4, 1, false, 2, 1, 0, 8>(p, stream);
+                case 6: return launch_attn<T, 4, 1, false, 2, 1, 0, 6>(p, stream);
+                case 14: return launch_attn<T, 4, 1, false, 2, 1, 0, 14>(p, stream);
+                case 15: return launch_attn<T, 4, 1, false, 2, 1, 0, 15>(p, stream);
+                case 31: return launch_attn<T, 4, 1, false, 2, 1, 0, 31>(p, stream);
+                case 63: return launch_attn<T, 4, 1, false, 2, 1, 0, 63>(p, stream);
+                case 127: return launch_attn<T, 4, 1, false, 2, 1, 0, 127>(p, stream);
+                case 16: return launch_attn<T, 4, 1, false, 2, 1, 0, 16>(p, stream);
+                default: return MI355X_EARG;
+            }
+        }
     }
-    if (p.nstream == 2) return launch_attn<T, NW, 2, false>(p, stream);
-    return launch_attn<T, NW, 1, false>(p, stream);
+    if constexpr (NW == 4) {
+        // a grid of 128-query workgroups that leaves most SIMDs with a single wave (a CFG pair's 1024-token self-attention: 320 workgroups):
+        // 64-query key-split workgroups instead -- twice the waves, each with half the dependent chain per tile
+        const int64_t wg128 = (int64_t)((p.Lq + 127) / 128) * p.H * p.B;
+        const bool use = g_attn_kvs == 2 || (g_attn_kvs == 0 && wg128 <= 384 && p.kv[0].Lk >= 256);
+        if (p.nstream == 1 && use) return (g_attn_opt & 1) ? launch_attn<T, 4, 1, false, 2, 1, 1, 0, 2>(p, stream) : launch_attn<T, 4, 1, false, 2, 1, 0, 0, 2>(p, stream);
+    }
+    switch (g_attn_opt) {
+        case 1: return launch_attn_opt<T, NW, 1>(p, stream);
+        case 2: return launch_attn_opt<T, NW, 2>(p, stream);
+        case 3: return launch_attn_opt<T, NW, 3>(p, stream);
+        default: return launch_attn_opt<T, NW, 0>(p, stream);
+    }
 }
 
 template <typename T>
 int launch_attn_t(const AttnP& p, hipStream_t stream) {
     int nw = g_attn_nw;  // 2 / 4: waves of 32 queries; 14 / 18: 4 / 8 waves of 16 queries
     if (nw == 0) nw = 4;  // 2-wave workgroups never won on MI355X (profiles/r01_c_probe_attention.log)
-    if (nw == 14) return p.nstream == 2 ? launch_attn<T, 4, 2, false, 1>(p, stream) : launch_attn<T, 4, 1, false, 1>(p, stream);
-    if (nw == 18) return p.nstream == 2 ? launch_attn<T, 8, 2, false, 1>(p, stream) : launch_attn<T, 8, 1, false, 1>(p, stream);
+    if (nw == 14) return p.nstream == 2 ? launch_attn<T, 4, 2, false, 1, 1>(p, stream) : launch_attn<T, 4, 1, false, 1, 1>(p, stream);
+    if (nw == 18) return p.nstream == 2 ? launch_attn<T, 8, 2, false, 1, 1>(p, stream) : launch_attn<T, 8, 1, false, 1, 1>(p, stream);
     return nw == 2 ? launch_attn_nw<T, 2>(p, stream) : launch_attn_nw<T, 4>(p, stream);
 }
 
@@ -414,7 +593,13 @@ extern "C" int mi355x_attention_set_glds(int v) {
 }
 
 extern "C" int mi355x_attention_set_pipeline(int tiles_in_flight, int xcd_aware) {  // probing / A-B only, not part of the stable contract
-    if (tiles_in_flight == 1 || tiles_in_flight == 2) g_attn_depth = tiles_in_flight;
+    // tiles_in_flight: bits 0-3 = 1 | 2, bits 4-7 = OPT bits of attn_kernel, bits 8-15 = ABL bits (timing probes, wrong results),
+    // bits 16-17 = key-split workgroups: 0 auto, 1 never, 2 always
+    const int d = tiles_in_flight & 15;
+    if (d == 1 || d == 2) g_attn_depth = d;
+    g_attn_opt = (tiles_in_flight >> 4) & 15;
+    g_attn_abl = (tiles_in_flight >> 8) & 255;
+    g_attn_kvs = (tiles_in_flight >> 16) & 3;
     if (xcd_aware >= 0) g_attn_xcd = xcd_aware ? 1 : 0;
     return MI355X_OK;
 }

@@ -323,11 +323,12 @@ def load(path: Optional[Path] = None) -> C.CDLL:
 
 
 def attention_pipeline_from_env() -> None:
-    """A/B: REFINERS_AMD_ATTN_PIPE="<K/V tiles in flight 1|2>,<XCD-aware block order 0|1>" (default 2,1); read at launch / capture time."""
+    """A/B: REFINERS_AMD_ATTN_PIPE="<K/V tiles in flight 1|2>,<XCD-aware block order 0|1>,<OPT bits of attn_kernel>,<key-split 0 auto|1 never|2 always>"
+    (default 1,1,1,0); read at launch / capture time."""
     import os
 
-    d, x = (os.environ.get("REFINERS_AMD_ATTN_PIPE", "2,1").replace("/", ",").split(",") + ["1"])[:2]
-    _lib.mi355x_attention_set_pipeline(int(d), int(x))
+    d, x, o, k = (os.environ.get("REFINERS_AMD_ATTN_PIPE", "").replace("/", ",").split(",") + ["", "", "", ""])[:4]
+    _lib.mi355x_attention_set_pipeline(int(d or 1) | (int(o or 1) << 4) | (int(k or 0) << 16), int(x or 1))
 
 
 def available() -> bool:

@@ -242,7 +242,8 @@ def _sdpa_ref(q, k, v, H):
     return (att @ vh).transpose(1, 2).reshape(B, Lq, Cc)
 
 
-def attention_case(B, H, Lq, Lk, dtype, *, ip_tokens=0, ip_scale=0.7, spike=False, seed=70):
+def attention_case(B, H, Lq, Lk, dtype, *, ip_tokens=0, ip_scale=0.7, spike=False, seed=70, pipe=None):
+    """pipe = mi355x_attention_set_pipeline code (K/V tiles in flight | OPT bits << 4) of a non-default kernel variant to run."""
     D = 64
     Cc = H * D
     q = _rand(B, Lq, Cc, dtype=dtype, seed=seed)
@@ -260,7 +261,13 @@ def attention_case(B, H, Lq, Lk, dtype, *, ip_tokens=0, ip_scale=0.7, spike=Fals
         streams.append((k2, _vt_from_v(v2, (ip_tokens + 63) // 64 * 64), ip_tokens, ip_scale))
         ref = ref + ip_scale * _sdpa_ref(q, k2, v2, H)
     out = torch.full((B, Lq, Cc), float("nan"), dtype=dtype, device=DEV)
-    native.attention(q, out, H, streams)
+    if pipe is not None:
+        native.load().mi355x_attention_set_pipeline(pipe, -1)
+    try:
+        native.attention(q, out, H, streams)
+    finally:
+        if pipe is not None:
+            native.attention_pipeline_from_env()
     return _cmp(out, ref, dtype)
 
 
@@ -758,6 +765,21 @@ def all_cases():
             (f"attn_{tag}_4tiles", lambda dt=dt: attention_case(1, 2, 256, 256, dt, seed=73)),
             (f"attn_{tag}_5tiles_ragged", lambda dt=dt: attention_case(1, 2, 130, 257, dt, seed=74)),
             (f"attn_{tag}_7tiles_ip130", lambda dt=dt: attention_case(1, 2, 128, 448, dt, ip_tokens=130, seed=75)),
+        ]
+        # the non-default variants of the tile loop: two K/V tiles in flight (2), permlane reductions (0x10), hoisted fragment reads (0x20)
+        # key-split workgroups (0x20000 = forced): tile counts 1..16, ragged tails that leave key group 1 (or both halves of the last tile) masked
+        for nm, args, kw in (("self_1024", (2, 4, 1024, 1024), {}), ("spike", (1, 2, 256, 512), {"spike": True}), ("Lk20", (1, 2, 96, 20), {"seed": 76}),
+                             ("Lk33", (1, 2, 70, 33), {"seed": 77}), ("Lk257", (1, 2, 130, 257), {"seed": 74}), ("Lk300_Lq200", (2, 3, 200, 300), {"seed": 78}),
+                             ("3tiles", (2, 2, 192, 192), {"seed": 72})):
+            for code in (0x20001, 0x20011):
+                cases.append((f"attn_{tag}_kvsplit{code & 0xff:02x}_{nm}", lambda dt=dt, args=args, kw=kw, code=code: attention_case(*args, dt, pipe=code, **kw)))
+        for code in (0x02, 0x11, 0x21, 0x31, 0x32):
+            cases += [
+                (f"attn_{tag}_pipe{code:02x}_self_1024", lambda dt=dt, code=code: attention_case(2, 4, 1024, 1024, dt, pipe=code)),
+                (f"attn_{tag}_pipe{code:02x}_5tiles_ragged", lambda dt=dt, code=code: attention_case(1, 2, 130, 257, dt, seed=74, pipe=code)),
+                (f"attn_{tag}_pipe{code:02x}_cross_77_ip4", lambda dt=dt, code=code: attention_case(2, 10, 512, 77, dt, ip_tokens=4, spike=True, pipe=code)),
+            ]
+        cases += [
             (f"attng_{tag}_d40_self", lambda dt=dt: attention_general_case(2, 8, 1024, 1024, 40, 40, dt)),
             (f"attng_{tag}_d40_cross77", lambda dt=dt: attention_general_case(2, 8, 320, 77, 40, 40, dt)),
             (f"attng_{tag}_d80_self", lambda dt=dt: attention_general_case(2, 8, 256, 256, 80, 80, dt, spike=True)),
