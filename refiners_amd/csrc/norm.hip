@@ -6,7 +6,7 @@
 //                   channel's value at pixel 0, which removes the E[x^2]-E[x]^2 cancellation), fixed order;
 //   2. gn_finalize: per sample, channel partials -> (mean_c, M2_c) -> Chan merge into the 32 groups -> per-channel
 //                   (mean_g, rstd_g * gamma_c) table;
-//   3. gn_apply   : y = (x - mean) * a + beta, optional SiLU, one read + one write of the activation.
+//   3. gn_apply   : y = x * a + (beta - mean * a), optional SiLU, one read + one write of the activation, (a, shift) held in registers.
 #include "common.cuh"
 #include "../../include/mi355x_refiners.h"
 
@@ -98,8 +98,20 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
             Vec16<T> pv = load16<T>(xb + v * EPC);  // pixel 0 of this sample = pivot
 #pragma unroll
             for (int e = 0; e < EPC; ++e) piv[e] = pv.get(e);
-            for (int px = p0 + pl; px < p1; px += PL) {
-                Vec16<T> t = load16<T>(xb + (int64_t)px * ldx + v * EPC);
+            const T* xv = xb + v * EPC;
+            int px = p0 + pl;
+            for (; px + 3 * PL < p1; px += 4 * PL) {  // four independent 16-byte loads in flight (a one-load loop runs at one memory round trip per pixel)
+                Vec16<T> t0 = load16<T>(xv + (int64_t)px * ldx), t1 = load16<T>(xv + (int64_t)(px + PL) * ldx), t2 = load16<T>(xv + (int64_t)(px + 2 * PL) * ldx),
+                         t3 = load16<T>(xv + (int64_t)(px + 3 * PL) * ldx);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float d0 = t0.get(e) - piv[e], d1 = t1.get(e) - piv[e], d2 = t2.get(e) - piv[e], d3 = t3.get(e) - piv[e];
+                    s1[e] += (d0 + d1) + (d2 + d3);
+                    s2[e] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+            for (; px < p1; px += PL) {
+                Vec16<T> t = load16<T>(xv + (int64_t)px * ldx);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float d = t.get(e) - piv[e];
@@ -161,10 +173,19 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
     const float n = (float)HW;
     float s1 = 0.f, s2 = 0.f;
     if (on) {
-        const float* pp = part + ((int64_t)b * nchunk * C + c) * 2;
-        for (int k = j; k < nchunk; k += L) {
-            s1 += pp[(int64_t)k * C * 2 + 0];
-            s2 += pp[(int64_t)k * C * 2 + 1];
+        const f32x2* pp = reinterpret_cast<const f32x2*>(part) + ((int64_t)b * nchunk * C + c);
+        int k = j;
+        for (; k + 7 * L < nchunk; k += 8 * L) {  // eight independent loads in flight, summed in a fixed tree
+            f32x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(k + u * L) * C];
+            s1 += ((v[0][0] + v[1][0]) + (v[2][0] + v[3][0])) + ((v[4][0] + v[5][0]) + (v[6][0] + v[7][0]));
+            s2 += ((v[0][1] + v[1][1]) + (v[2][1] + v[3][1])) + ((v[4][1] + v[5][1]) + (v[6][1] + v[7][1]));
+        }
+        for (; k < nchunk; k += L) {
+            const f32x2 v = pp[(int64_t)k * C];
+            s1 += v[0];
+            s2 += v[1];
         }
     }
     red[t * 2 + 0] = s1;
@@ -201,25 +222,56 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
     }
 }
 
+// One workgroup per pixel chunk of one sample (the chunks of gn_partial): a thread keeps the (scale, shift) of its 8 / 4 channels in registers
+// and streams its pixels with four loads in flight -- per element one FMA (+ SiLU), no per-element table reads.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
-                                                        int HW, int C, const float* __restrict__ tab,
-                                                        const T* __restrict__ beta, int silu, int64_t nvec_total) {
+                                                        int HW, int C, int ppc, const float* __restrict__ tab,
+                                                        const T* __restrict__ beta, int silu) {
     constexpr int EPC = DT<T>::EPC;
+    const int chunk = blockIdx.x, b = blockIdx.y;
     const int NV = C / EPC;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec_total; i += (int64_t)gridDim.x * 256) {
-        const int64_t pix = i / NV;  // global pixel index over B*HW
-        const int v = (int)(i - pix * NV);
-        const int b = (int)(pix / HW);
-        Vec16<T> t = load16<T>(x + pix * ldx + v * EPC), bt = load16<T>(beta + v * EPC), o;
-        const float* tb = tab + ((int64_t)b * C + v * EPC) * 2;
+    const int tid = threadIdx.x;
+    const int PL = NV >= 256 ? 1 : 256 / NV;
+    const int VPT = NV >= 256 ? (NV + 255) / 256 : 1;
+    const int pl = NV >= 256 ? 0 : tid / NV;
+    const int v0 = NV >= 256 ? tid : tid % NV;
+    if (pl >= PL) return;
+    const int p0 = chunk * ppc;
+    const int p1 = min(p0 + ppc, HW);
+    for (int k = 0; k < VPT; ++k) {
+        const int v = v0 + 256 * k;
+        if (v >= NV) break;
+        float sc[EPC], sh[EPC];
+        {
+            const f32x2* tb = reinterpret_cast<const f32x2*>(tab) + ((int64_t)b * C + v * EPC);
+            Vec16<T> bt = load16<T>(beta + v * EPC);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            float y = (t.get(e) - tb[e * 2]) * tb[e * 2 + 1] + bt.get(e);
-            if (silu) y = silu_f(y);
-            o.set(e, y);
+            for (int e = 0; e < EPC; ++e) {
+                const f32x2 ma = tb[e];
+                sc[e] = ma[1];
+                sh[e] = bt.get(e) - ma[0] * ma[1];
+            }
         }
-        store16<T>(out + pix * ldo + v * EPC, o);
+        const T* xv = x + (int64_t)b * HW * ldx + v * EPC;
+        T* ov = out + (int64_t)b * HW * ldo + v * EPC;
+        auto emit = [&](const Vec16<T>& t, int px) {
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float y = t.get(e) * sc[e] + sh[e];
+                if (silu) y = silu_f(y);
+                o.set(e, y);
+            }
+            store16<T>(ov + (int64_t)px * ldo, o);
+        };
+        int px = p0 + pl;
+        for (; px + 3 * PL < p1; px += 4 * PL) {
+            Vec16<T> t0 = load16<T>(xv + (int64_t)px * ldx), t1 = load16<T>(xv + (int64_t)(px + PL) * ldx), t2 = load16<T>(xv + (int64_t)(px + 2 * PL) * ldx),
+                     t3 = load16<T>(xv + (int64_t)(px + 3 * PL) * ldx);
+            emit(t0, px), emit(t1, px + PL), emit(t2, px + 2 * PL), emit(t3, px + 3 * PL);
+        }
+        for (; px < p1; px += PL) emit(load16<T>(xv + (int64_t)px * ldx), px);
     }
 }
 
@@ -327,9 +379,9 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, 
     }
 }
 
-int g_gn_fused = 1;                       // A/B switch (mi355x_groupnorm_set_fused)
-int64_t g_gn_fused_max_bytes = 160 << 10;  // slab size up to which one workgroup per group set beats the three-kernel path (tools/probe_gn.py,
-                                           // profiles/r02_c_probe_gn.log: 29.6 -> 20.6 us at 80 KB, 49.9 -> 34.8 at 160 KB, a loss from 240 KB up)
+int g_gn_fused = 0;                       // single-launch kernel OFF: once the three kernels keep several loads in flight per thread they beat it on every
+                                          // SDXL shape when timed inside a HIP graph (tools/probe_gn.py, profiles/r02_p_probe_gn.log); mi355x_groupnorm_set_fused switches
+int64_t g_gn_fused_max_bytes = 160 << 10;  // largest slab the single-launch kernel is used for when it is switched on
 
 inline int gn_ppc(int B, int HW, int C, int es) {
     const int nv = C * es / 16;
@@ -391,11 +443,8 @@ int run_groupnorm(const mi355x_groupnorm_args* a, hipStream_t st) {
     hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, ppc, nchunk, part);
     hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, a->G,
                        nchunk, part, static_cast<const T*>(a->gamma), a->eps, tab);
-    const int64_t nvec_total = (int64_t)a->B * a->HW * (a->C / EPC);
-    int64_t blocks = (nvec_total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3((int)blocks), dim3(256), 0, st, x, a->ldx, static_cast<T*>(a->out), a->ldo, a->HW,
-                       a->C, tab, static_cast<const T*>(a->beta), a->silu, nvec_total);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, static_cast<T*>(a->out), a->ldo, a->HW,
+                       a->C, ppc, tab, static_cast<const T*>(a->beta), a->silu);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
 

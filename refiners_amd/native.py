@@ -316,8 +316,8 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     _lib = lib
     import os
 
-    if os.environ.get("REFINERS_AMD_GN_FUSED", "1") == "0":  # A/B: always the three-kernel GroupNorm
-        lib.mi355x_groupnorm_set_fused(0, 0)
+    if os.environ.get("REFINERS_AMD_GN_FUSED", "0") == "1":  # A/B: the single-launch GroupNorm for slabs up to 160 KB
+        lib.mi355x_groupnorm_set_fused(1, 0)
     attention_pipeline_from_env()
     return lib
 

@@ -338,12 +338,19 @@ def layernorm_case(M, Cc, dtype, seed=80):
     return _cmp(out, ref, dtype)
 
 
-def groupnorm_case(B, Cc, HW, dtype, silu=True, eps=1e-5, seed=90):
+def groupnorm_case(B, Cc, HW, dtype, silu=True, eps=1e-5, seed=90, single_launch=False):
+    """single_launch: the one-workgroup-per-group-set kernel (off by default) instead of partial / finalize / apply."""
     x = _rand(B, HW, Cc, dtype=dtype, seed=seed) * 1.5 + 3.0  # large mean: stresses the variance computation
     g = (1 + 0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 1)).to(dtype)
     b = (0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 2)).to(dtype)
     out = torch.empty_like(x)
-    native.groupnorm_nhwc(x, g, b, 32, eps, silu, out)
+    if single_launch:
+        native.load().mi355x_groupnorm_set_fused(1, 1 << 30)
+    try:
+        native.groupnorm_nhwc(x, g, b, 32, eps, silu, out)
+    finally:
+        if single_launch:
+            native.load().mi355x_groupnorm_set_fused(0, 160 << 10)
     xr = x.float().permute(0, 2, 1)  # [B, C, HW]
     ref = F.group_norm(xr, 32, g.float(), b.float(), eps)
     if silu:
@@ -798,6 +805,10 @@ def all_cases():
             (f"groupnorm_{tag}_1280_1024", lambda dt=dt: groupnorm_case(2, 1280, 1024, dt, eps=1e-6, silu=False)),
             (f"groupnorm_{tag}_2560_1024", lambda dt=dt: groupnorm_case(2, 2560, 1024, dt)),
             (f"groupnorm_{tag}_960_4096", lambda dt=dt: groupnorm_case(1, 960, 4096, dt)),
+            (f"groupnorm_{tag}_640_333_ragged", lambda dt=dt: groupnorm_case(3, 640, 333, dt, seed=91)),  # pixel counts that are no multiple of the 4-deep unroll
+            (f"groupnorm_{tag}_320_16384", lambda dt=dt: groupnorm_case(2, 320, 16384, dt, seed=92)),
+            (f"groupnorm_{tag}_1280_1024_single_launch", lambda dt=dt: groupnorm_case(2, 1280, 1024, dt, single_launch=True)),
+            (f"groupnorm_{tag}_320_1024_single_launch", lambda dt=dt: groupnorm_case(2, 320, 1024, dt, silu=False, single_launch=True)),
             (f"layout_{tag}", lambda dt=dt: layout_case(2, 4, 32, 32, dt)),
             (f"layout_{tag}_320", lambda dt=dt: layout_case(1, 320, 16, 24, dt)),
             (f"concat_axpby_{tag}", lambda dt=dt: concat_axpby_case(1000, 640, 320, dt)),

@@ -47,7 +47,7 @@ def main() -> None:
         for kv in filter(None, envs.split(",")):
             k, v = kv.split(":")
             os.environ[k] = v
-        native.load().mi355x_groupnorm_set_fused(int(os.environ.get("REFINERS_AMD_GN_FUSED", "1") != "0"), 0)  # decided at launch / capture time
+        native.load().mi355x_groupnorm_set_fused(int(os.environ.get("REFINERS_AMD_GN_FUSED", "0") == "1"), 0)  # decided at launch / capture time
         native.attention_pipeline_from_env()
         tuning.enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
         tuning._table = None
