@@ -489,6 +489,248 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- short K/V
+// Cross-attention of the UNet step: 77 text keys (+ 4 image-prompt keys as a second stream) = at most THREE 64-key tiles in total.  The general
+// kernel walks them as a chain of load -> barrier -> compute -> barrier per tile and per stream (seven barriers and three dependent memory
+// round trips for a few hundred MFMAs); here every tile of every stream is requested up front, lands in its own LDS slot behind ONE barrier,
+// and the tiles are then consumed back to back.  Same arithmetic, same order of operations per stream as attn_kernel.
+template <typename T, int NSTREAM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 2 : 1))) void attn_short_kernel(const AttnP p) {
+    constexpr int D = 64, BKV = 64, NJQ = 2, NW = 4, BQW = 16 * NJQ, SLOTS = 3;
+    constexpr int ES = sizeof(T);
+    constexpr int ROWB = D * ES;
+    constexpr int CPR = ROWB / 16;
+    constexpr int NTHR = NW * 64;
+    constexpr int TILEB = 64 * ROWB;
+    constexpr int STAGE = 2 * TILEB;
+    constexpr int LI = 64 * CPR / NTHR;
+    constexpr int NS = D / DT<T>::KSTEP;
+    constexpr bool IS_BF16 = (ES == 2);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    const int g = lane >> 4, c16 = lane & 15;
+    int bid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int qt = bid % p.qtiles;
+    bid /= p.qtiles;
+    const int h = bid % p.H;
+    const int b = bid / p.H;
+    const int q0 = qt * (BQW * NW) + wid * BQW;
+
+    frag_t qf[NJQ][NS];
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) {
+        int qr = q0 + 16 * jq + c16;
+        qr = qr < p.Lq ? qr : p.Lq - 1;
+        const char* qp = p.q + (int64_t)b * p.qbsb + (int64_t)qr * p.ldqb + (int64_t)h * ROWB;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[jq][s] = *reinterpret_cast<const frag_t*>(qp + (4 * s + g) * 16);
+    }
+
+    const int nt0 = (p.kv[0].Lk + BKV - 1) / BKV;
+    const int nt1 = NSTREAM > 1 ? (p.kv[1].Lk + BKV - 1) / BKV : 0;
+    const int ntot = nt0 + nt1;  // <= SLOTS (checked by the host)
+
+    // ---- every tile of every stream: global -> registers -> its own LDS slot, one barrier ----
+    {
+        frag_t kr[SLOTS][LI], vr[SLOTS][LI];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (sl < ntot) {
+                const int sidx = (NSTREAM > 1 && sl >= nt0) ? 1 : 0;
+                const KvP& kv = p.kv[sidx];
+                const int kv0 = (sidx ? sl - nt0 : sl) * BKV;
+                const char* kbase = kv.k + (int64_t)b * kv.kbsb + (int64_t)h * ROWB;
+                const char* vbase = kv.vt + (int64_t)h * D * kv.ldvtb + (int64_t)b * kv.vtbsb;
+#pragma unroll
+                for (int it = 0; it < LI; ++it) {
+                    const int q = it * NTHR + tid, row = q / CPR, pch = q % CPR;
+                    const int coff = (pch ^ swz<ROWB>(row)) << 4;
+                    int kr_ = kv0 + row;
+                    kr_ = kr_ < kv.Lk ? kr_ : kv.Lk - 1;
+                    kr[sl][it] = *reinterpret_cast<const frag_t*>(kbase + (int64_t)kr_ * kv.ldkb + coff);
+                    const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
+                    const int vrow = 16 * a + 4 * j + bb;  // head-dim index stored in LDS row `row` of the V^T tile (see attn_kernel)
+                    vr[sl][it] = *reinterpret_cast<const frag_t*>(vbase + (int64_t)vrow * kv.ldvtb + (int64_t)kv0 * ES + coff);
+                }
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (sl < ntot) {
+                char* ks = smem + sl * STAGE;
+#pragma unroll
+                for (int it = 0; it < LI; ++it) {
+                    *reinterpret_cast<frag_t*>(ks + (it * NTHR + tid) * 16) = kr[sl][it];
+                    *reinterpret_cast<frag_t*>(ks + TILEB + (it * NTHR + tid) * 16) = vr[sl][it];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 res[4][NJQ], o[4][NJQ];
+    float mrun[NJQ], lsum[NJQ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) res[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f}, o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) mrun[jq] = -INFINITY, lsum[jq] = 0.f;
+
+    auto finish = [&](float out_scale) {
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) {
+            const float l = group_sum<true>(lsum[jq]);
+            const float inv = out_scale / l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                res[i][jq] += o[i][jq] * inv;
+                o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            mrun[jq] = -INFINITY, lsum[jq] = 0.f;
+        }
+    };
+
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        if (sl < ntot) {
+            const int sidx = (NSTREAM > 1 && sl >= nt0) ? 1 : 0;
+            if (NSTREAM > 1 && sl == nt0) finish(p.kv[0].out_scale);  // first tile of the second stream: close the first
+            const int Lk = p.kv[sidx].Lk;
+            const int kv0 = (sidx ? sl - nt0 : sl) * BKV;
+            const char* ks = smem + sl * STAGE;
+            const char* vs = ks + TILEB;
+            // ---- S^T = K Q^T ----
+            f32x4 st[4][NJQ];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int jq = 0; jq < NJQ; ++jq) st[t][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const frag_t kf = lds_read_frag(ks, tile_off<ROWB>(16 * t + c16, 4 * s + g));
+#pragma unroll
+                    for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(st[t][jq], kf, qf[jq][s]);
+                }
+            }
+            if (kv0 + BKV > Lk) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (kv0 + 16 * t + 4 * g + r >= Lk) {
+#pragma unroll
+                            for (int jq = 0; jq < NJQ; ++jq) st[t][jq][r] = -INFINITY;
+                        }
+                    }
+            }
+            // ---- online softmax ----
+#pragma unroll
+            for (int jq = 0; jq < NJQ; ++jq) {
+                float mx = st[0][jq][0];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][jq][r]);
+                mx = group_max<true>(mx);
+                const float mnew = fmaxf(mrun[jq], mx);
+                const float alpha = fast_exp2((mrun[jq] - mnew) * p.c);
+                const float mc = mnew * p.c;
+                float ps = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = fast_exp2(st[t][jq][r] * p.c - mc);
+                        st[t][jq][r] = e;
+                        ps += e;
+                    }
+                lsum[jq] = lsum[jq] * alpha + ps;
+                mrun[jq] = mnew;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
+            }
+            // ---- O^T += V^T P^T ----
+            if constexpr (IS_BF16) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    frag_t pb[NJQ];
+#pragma unroll
+                    for (int jq = 0; jq < NJQ; ++jq) {
+                        bf16x8 pk;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pk[r] = (bf16_t)st[2 * s2][jq][r];
+                            pk[4 + r] = (bf16_t)st[2 * s2 + 1][jq][r];
+                        }
+                        pb[jq] = __builtin_bit_cast(frag_t, pk);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 16 * i + c16;
+                        const int chunk = 4 * s2 + (g >> 1);
+                        const int sw = swz<ROWB>(row);
+                        const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
+                        const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
+                        const frag_t vf = frag_t{va[0], va[1], vb[0], vb[1]};
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, pb[jq]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const frag_t vf = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * t + g));
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, __builtin_bit_cast(frag_t, st[t][jq]));
+                    }
+                }
+            }
+        }
+    }
+    finish(p.kv[NSTREAM - 1].out_scale);
+
+    // ---- store: lane owns d = 16g + 4i + r (16 consecutive) of query 16jq + c16 ----
+    constexpr int EPC = DT<T>::EPC;
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) {
+        const int qr = q0 + 16 * jq + c16;
+        if (qr >= p.Lq) continue;
+        T* op = reinterpret_cast<T*>(p.out + (int64_t)b * p.obsb + (int64_t)qr * p.ldob + (int64_t)h * ROWB) + 16 * g;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * i + r] = res[i][jq][r];
+#pragma unroll
+        for (int c = 0; c < 16 / EPC; ++c) {
+            Vec16<T> ov;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
+            store16<T>(op + c * EPC, ov);
+        }
+    }
+}
+
+template <typename T, int NSTREAM>
+int launch_attn_short(const AttnP& p0, int xcd, hipStream_t stream) {
+    constexpr int LDS = 3 * 2 * 64 * 64 * sizeof(T);
+    auto kfn = attn_short_kernel<T, NSTREAM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    AttnP p = p0;
+    p.qtiles = (p.Lq + 127) / 128;
+    p.xcd = xcd;
+    hipLaunchKernelGGL(kfn, dim3(p.qtiles * p.H * p.B), dim3(256), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
+}
+
 int g_attn_glds = 0;   // register-staged K/V loader by default: measured faster than glds for attention (probe_attn3)
 int g_attn_depth = 1;  // K/V tiles in flight in the register-staged loader (mi355x_attention_set_pipeline); 2 measured no better (r02_j_probe_attn.log)
 int g_attn_xcd = 1;    // q-tiles of a head on one XCD
@@ -569,8 +811,15 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
     }
 }
 
+int g_attn_short = 1;  // all-tiles-up-front kernel for launches of at most three K/V tiles in total (the step's cross-attentions)
+
 template <typename T>
 int launch_attn_t(const AttnP& p, hipStream_t stream) {
+    if (g_attn_short && !g_attn_glds && g_attn_nw == 0 && g_attn_abl == 0 && g_attn_kvs != 2) {
+        int tiles = 0;
+        for (int s = 0; s < p.nstream; ++s) tiles += (p.kv[s].Lk + 63) / 64;
+        if (tiles <= 3) return p.nstream == 2 ? launch_attn_short<T, 2>(p, g_attn_xcd, stream) : launch_attn_short<T, 1>(p, g_attn_xcd, stream);
+    }
     int nw = g_attn_nw;  // 2 / 4: waves of 32 queries; 14 / 18: 4 / 8 waves of 16 queries
     if (nw == 0) nw = 4;  // 2-wave workgroups never won on MI355X (profiles/r01_c_probe_attention.log)
     if (nw == 14) return p.nstream == 2 ? launch_attn<T, 4, 2, false, 1, 1>(p, stream) : launch_attn<T, 4, 1, false, 1, 1>(p, stream);
@@ -594,12 +843,13 @@ extern "C" int mi355x_attention_set_glds(int v) {
 
 extern "C" int mi355x_attention_set_pipeline(int tiles_in_flight, int xcd_aware) {  // probing / A-B only, not part of the stable contract
     // tiles_in_flight: bits 0-3 = 1 | 2, bits 4-7 = OPT bits of attn_kernel, bits 8-15 = ABL bits (timing probes, wrong results),
-    // bits 16-17 = key-split workgroups: 0 auto, 1 never, 2 always
+    // bits 16-17 = key-split workgroups: 0 auto, 1 never, 2 always; bit 18 = 1: no short-K/V kernel
     const int d = tiles_in_flight & 15;
     if (d == 1 || d == 2) g_attn_depth = d;
     g_attn_opt = (tiles_in_flight >> 4) & 15;
     g_attn_abl = (tiles_in_flight >> 8) & 255;
     g_attn_kvs = (tiles_in_flight >> 16) & 3;
+    g_attn_short = ((tiles_in_flight >> 18) & 1) ? 0 : 1;
     if (xcd_aware >= 0) g_attn_xcd = xcd_aware ? 1 : 0;
     return MI355X_OK;
 }

@@ -780,11 +780,21 @@ def all_cases():
                              ("3tiles", (2, 2, 192, 192), {"seed": 72})):
             for code in (0x20001, 0x20011):
                 cases.append((f"attn_{tag}_kvsplit{code & 0xff:02x}_{nm}", lambda dt=dt, args=args, kw=kw, code=code: attention_case(*args, dt, pipe=code, **kw)))
+        # launches of at most three K/V tiles take the all-tiles-up-front kernel by default (the cases above: cross_77, cross_77_ip4, 1tile, 3tiles,
+        # Lq_edge_200); 0x40000 switches it off, so the same shapes also run through the general tile loop; and its remaining slot layouts
+        cases += [
+            (f"attn_{tag}_general_cross_77", lambda dt=dt: attention_case(2, 10, 1024, 77, dt, pipe=0x40011)),
+            (f"attn_{tag}_general_cross_77_ip4", lambda dt=dt: attention_case(2, 10, 512, 77, dt, ip_tokens=4, pipe=0x40011)),
+            (f"attn_{tag}_general_1tile", lambda dt=dt: attention_case(1, 3, 160, 64, dt, seed=71, pipe=0x40011)),
+            (f"attn_{tag}_short_1plus2tiles", lambda dt=dt: attention_case(1, 2, 100, 40, dt, ip_tokens=100, seed=79)),
+            (f"attn_{tag}_short_1plus1_spike", lambda dt=dt: attention_case(2, 3, 300, 17, dt, ip_tokens=1, spike=True, seed=80)),
+            (f"attn_{tag}_short_Lk1", lambda dt=dt: attention_case(1, 2, 64, 1, dt, seed=81)),
+        ]
         for code in (0x02, 0x11, 0x21, 0x31, 0x32):
             cases += [
                 (f"attn_{tag}_pipe{code:02x}_self_1024", lambda dt=dt, code=code: attention_case(2, 4, 1024, 1024, dt, pipe=code)),
                 (f"attn_{tag}_pipe{code:02x}_5tiles_ragged", lambda dt=dt, code=code: attention_case(1, 2, 130, 257, dt, seed=74, pipe=code)),
-                (f"attn_{tag}_pipe{code:02x}_cross_77_ip4", lambda dt=dt, code=code: attention_case(2, 10, 512, 77, dt, ip_tokens=4, spike=True, pipe=code)),
+                (f"attn_{tag}_pipe{code:02x}_cross_77_ip4", lambda dt=dt, code=code: attention_case(2, 10, 512, 77, dt, ip_tokens=4, spike=True, pipe=code | 0x40000)),
             ]
         cases += [
             (f"attng_{tag}_d40_self", lambda dt=dt: attention_general_case(2, 8, 1024, 1024, 40, 40, dt)),
