@@ -94,6 +94,19 @@ def test_merged_lora_mode_adds_no_step_launch():
     assert low.stats["time_bias_batched"] == 17
 
 
+def test_time_projection_batching_can_be_switched_off(monkeypatch):
+    """REFINERS_AMD_TIME_BATCH=0: one 2-row GEMM per ResidualBlock again (the A/B lever of tools/ab_step.py); same program otherwise."""
+    monkeypatch.setenv("REFINERS_AMD_TIME_BATCH", "0")
+    dev = torch.device("meta")
+    unet = SDXLUNet(4, device="meta", dtype=torch.bfloat16)
+    io = UNetIO(x=torch.empty(2, 4, 32, 32, device=dev, dtype=torch.bfloat16), timestep=torch.empty(2, device=dev), out=torch.empty(2, 4, 32, 32, device=dev, dtype=torch.bfloat16))
+    io.pooled, io.time_ids = torch.empty(2, 1280, device=dev, dtype=torch.bfloat16), torch.empty(2, 6, device=dev)
+    io.tokens[("cross_attention_block", "clip_text_embedding")] = (torch.zeros(256, 2048, device=dev, dtype=torch.bfloat16), 77)
+    low = UNetLowering(dev, torch.bfloat16, None, "merged")
+    low.lower(unet, io)
+    assert len(low.step) == 981 and "time_bias_batched" not in low.stats
+
+
 def test_sd1_tree_lowers_onto_the_general_attention_kernel_for_its_head_dims():
     low = _dry(SD1UNet(4, device="meta"), 1, 32, 32, torch.float32, {("cross_attention_block", "clip_text_embedding"): (77, 768)}, pooled=False)
     assert low.stats["fallback_nodes"] == []
