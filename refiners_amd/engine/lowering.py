@@ -241,6 +241,9 @@ class Lowering:
         # lora_mode="fused": the LoRA down / up projections run INSIDE the parent GEMM's launch (stacked rank <= 32); 0 = the older
         # skinny-GEMM + extra-K-segment pair of launches
         self.lora_inlaunch = os.environ.get("REFINERS_AMD_LORA_INLAUNCH", "1") != "0"
+        # extra elements per row of a self-attention's V^T buffer [C][B L (+ pad)]: with a row stride of exactly B L elements (4 / 16 KB at 1024 / 4096
+        # tokens) the 64 rows of a V^T tile sit a power of two apart in memory
+        self.vt_pad = int(os.environ.get("REFINERS_AMD_VT_PAD", "0"))
         self.device, self.dtype = device, dtype
         self.es = 4 if dtype == torch.float32 else 2
         self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
@@ -650,7 +653,8 @@ class Lowering:
             for k, vt, Lk, osc in streams:
                 lkp = k.shape[0] // B
                 kv = k.as_strided((B, lkp, C), (lkp * k.stride(0), k.stride(0), 1))  # k may be a column slice of a packed [Q|K] buffer
-                st.append((kv, vt.view(C, B, vt.shape[1] // B), Lk, osc))
+                lv = vt.shape[1] // B
+                st.append((kv, vt.as_strided((C, B, lv), (vt.stride(0), lv, 1)), Lk, osc))  # vt rows may be padded (stride > B lv)
             if kind == "flash64":
                 native.attention(q3, out.view(B, Lq, C), heads, st)
                 return out
@@ -767,12 +771,13 @@ class Lowering:
         h = x if fold else self.layernorm(x, ln)
         no_lora = qs.lora is None and ks.lora is None and vs.lora is None
         all_inlaunch = self.lora_inlaunch and all(sp.lora is not None and sp.lora.a32 is not None for sp in (qs, ks, vs))
-        qk = q = k = vt = None
+        qk = q = k = vt = vt_full = None
         if (no_lora or all_inlaunch) and native_path and self.qkv_merge and L % 64 == 0 and C % 128 == 0 and self.device.type != "meta":
             # ONE launch for the three projections: [Wq; Wk; Wv] stacked, Q | K row-major, V stored transposed
             wqkv = LinSpec(self.cache.get(("qkv",) + PackCache.ident(qs.w, ks.w, vs.w), lambda: torch.cat([qs.w, ks.w, vs.w], 0).contiguous()), None)
             qk = self.pool.get(M, 2 * C)
-            vt = self.pool.get(C, M)
+            vt_full = self.pool.get(C, M + self.vt_pad)
+            vt = vt_full[:, :M] if self.vt_pad else vt_full
             if fold:
                 wl, ls, lc = self.ln_fold(wqkv, ln)
                 lo = None
@@ -820,7 +825,7 @@ class Lowering:
         if native_path:
             o = self.sdpa(q, B, heads, [(k, vt, L, 1.0)])
             if L % 64 == 0:
-                self.pool.put(vt)
+                self.pool.put(vt_full if vt_full is not None else vt)
         else:
             v = self.linear(h, vs)
             o = self.sdpa(q, B, heads, [(k, v, M // B, 1.0)], v_plain=[v])

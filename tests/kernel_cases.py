@@ -537,18 +537,21 @@ def conv_tile_case(B, Cin, Cout, H, W, dtype, tile, stages, ksplit=1, seed=220):
     return _cmp(out, ref, dtype)
 
 
-def gemm_qkv_case(M, K, Cc, dtype, tile=0, bias=False, seed=230):
-    """One launch over [Wq; Wk; Wv]: Q | K row-major into `out`, V transposed into `out_t` (transposed column group)."""
+def gemm_qkv_case(M, K, Cc, dtype, tile=0, bias=False, seed=230, pad=0):
+    """One launch over [Wq; Wk; Wv]: Q | K row-major into `out`, V transposed into `out_t` (transposed column group);
+    pad = extra elements per V^T row (a row stride that is not the row count; the padding must stay untouched)."""
     x = _rand(M, K, dtype=dtype, seed=seed)
     w = _rand(3 * Cc, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
     b = _rand(3 * Cc, dtype=dtype, seed=seed + 2) if bias else None
     qk = torch.full((M, 2 * Cc), float("nan"), dtype=dtype, device=DEV)
-    vt = torch.full((Cc, M), float("nan"), dtype=dtype, device=DEV)
+    vt_full = torch.full((Cc, M + pad), 7.0, dtype=dtype, device=DEV)
+    vt = vt_full[:, :M]
     native.gemm([(x, native.KBlocked(w))], qk, bias=b, out_t=vt, nt_begin=2 * Cc, tile=tile)
     ref = x.float() @ w.float().t() + (b.float() if bias else 0)
     e1 = _cmp(qk, ref[:, : 2 * Cc], dtype)
     e2 = _cmp(vt, ref[:, 2 * Cc :].t(), dtype)
-    return max(e1[0], e2[0]), max(e1[1], e2[1]), e1[2]
+    spill = float((vt_full[:, M:].float() - 7.0).abs().max().item()) if pad else 0.0
+    return max(e1[0], e2[0]) + spill, max(e1[1], e2[1]), e1[2]
 
 
 def gemm_t_only_case(M, K, Cc, dtype, tile=0, seed=235):
@@ -871,6 +874,8 @@ def all_cases():
             (f"conv_{tag}_tile1_s3", lambda dt=dt: conv_tile_case(2, 320, 384, 16, 24, dt, 1, 3)),
             (f"conv_{tag}_tile5_s3", lambda dt=dt: conv_tile_case(2, 320, 320, 32, 32, dt, 5, 3)),
             (f"gemm_{tag}_qkv_2048x1280", lambda dt=dt: gemm_qkv_case(2048, 1280, 1280, dt)),
+            (f"gemm_{tag}_qkv_2048x1280_padded_vt", lambda dt=dt: gemm_qkv_case(2048, 1280, 1280, dt, pad=64)),
+            (f"gemm_{tag}_qkv_1000x640_padded_vt_tile4", lambda dt=dt: gemm_qkv_case(1000, 640, 640, dt, tile=4, bias=True, pad=32, seed=231)),
             (f"gemm_{tag}_qkv_1000x640_bias_tile4", lambda dt=dt: gemm_qkv_case(1000, 640, 640, dt, tile=4, bias=True)),
             (f"gemm_{tag}_qkv_tile6", lambda dt=dt: gemm_qkv_case(512, 640, 384, dt, tile=6)),
             (f"gemm_{tag}_qkv_tile5", lambda dt=dt: gemm_qkv_case(520, 640, 256, dt, tile=5)),
