@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 3
+#define MI355X_ABI_VERSION 4
 
 enum { MI355X_F32 = 0, MI355X_BF16 = 1 };
 
@@ -171,6 +171,20 @@ typedef struct {
     const void* lora_b;
     const void* lora_ls;
     const void* lora_lc;
+    /* Cross-attention in the epilogue of its q-projection (ABI 4) -- the second Residual of CrossAttentionBlock,
+       src/refiners/foundationals/latent_diffusion/cross_attention.py:25-73: Attention(Linear_q(LayerNorm(x)), K, V) with the text keys
+       (and, with the IP-Adapter, Sum(SDPA, ImageCrossAttention), image_prompt.py:237-309) -- for K / V that are constant over the
+       sampling loop and SHORT: at most 80 keys per stream and 96 in total (rounded up to 16 per stream).  The launch computes
+       Q = x W^T (+ bias | LayerNorm correction), rounds it to `dtype` like the reference's Linear output, and writes
+         out[m][h*64 + :] = sum_s out_scale_s * softmax_k(xattn_scale * Q[m, h] . K_s[b, k, h]) V_s[b, k, h],     b = m / xattn_lq
+       instead of Q: a 128 x 128 output tile is 128 queries x 2 heads, Q never reaches memory and the separate attention launch is gone.
+       xattn_kv: `const mi355x_kv_stream[xattn_nstream]` (declared below; same K / V^T layouts and padding rule as mi355x_attention, head
+       dim 64), NULL = off.  M and xattn_lq multiples of 128, N a multiple of 128; one segment; no conv / ksplit / geglu / rowbias / res /
+       out_t / stats_out / out_f32 / in-launch LoRA.  `tile` / `stages` are ignored (the 128 x 128 tile is the only one that fits). */
+    const void* xattn_kv;
+    int32_t xattn_nstream;
+    int32_t xattn_lq;
+    float xattn_scale;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

@@ -105,6 +105,16 @@ struct GemmP {
     int pf_blocks, pf_mode;  // pf_mode: 1 = plain loads, 2 = non-temporal loads (L2 evict-first)
     int pn, hm, hn;          // XCD rasterisation: the 8 XCDs own a pm x pn grid of hm x hn-tile regions
     int vec_ok;
+    // cross-attention in the epilogue (XATT kernels): the tile's 128 rows x 2 heads of Q never reach memory
+    struct Xatt {
+        const char* k[2];
+        const char* vt[2];
+        int64_t ldkb[2], kbsb[2], ldvtb[2], vtbsb[2];  // bytes
+        int Lk[2];
+        float out_scale[2];
+        int nstream, Lq;
+        float c;  // scale * log2(e)
+    } xa;
 };
 
 // Chan's pairwise update of (count, mean, M2); exact for empty operands.
@@ -118,10 +128,276 @@ MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, flo
     }
 }
 
+// lane <-> lane ^ 16 / lane ^ 32 exchanges as row / half swaps (see attention.hip): after the call a and b hold the two partners' values
+MI_DEV void xa_swap16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+MI_DEV void xa_swap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+MI_DEV float xa_group_max(float x) {
+    float a = x, b = x;
+    xa_swap16(a, b);
+    a = fmaxf(a, b), b = a;
+    xa_swap32(a, b);
+    return fmaxf(a, b);
+}
+MI_DEV float xa_group_sum(float x) {
+    float a = x, b = x;
+    xa_swap16(a, b);
+    a = a + b, b = a;
+    xa_swap32(a, b);
+    return a + b;
+}
+
+// ---- cross-attention in the epilogue of its q-projection -------------------------------------------------------------------------
+// CrossAttentionBlock's second Residual (cross_attention.py:25-73): Q = Linear(LayerNorm(x)); out = SDPA(Q, K_text, V_text) (+ scale * SDPA(Q,
+// K_ip, V_ip), image_prompt.py:237-309) with 77 (+ 4 / 16) keys that are constant over the sampling loop.  A 128 x 128 output tile of the
+// projection IS 128 queries x 2 heads of 64, one head per wave column, and in the A = weights / B = activations orientation a lane owns, per
+// 16-query block i, the 16 consecutive head-dim values 16 g .. 16 g + 15 of query c16: MMA step s takes elements 16 g + EPC s .. as the B
+// fragment, and the key row's 16-byte chunk (16 / EPC) g + s as the A fragment (the same head-dim permutation on both sides of the dot
+// product).  K / V^T of the two heads are staged into the drained K-loop ring in 16-key blocks (at most 5 per stream, 6 in total); a
+// stream's scores fit in registers, so its softmax is a plain (not online) one.  The S^T = K Q^T orientation, the P -> B-operand packing, the
+// permuted V^T rows and the store mapping are those of attn_kernel (attention.hip).
+constexpr int XA_MAXB = 6;  // key blocks of 16 per workgroup head: e.g. 5 (77 text keys) + 1 (4 or 16 image-prompt keys)
+constexpr int XA_SB = 5;    // key blocks of one stream
+
+template <typename T> constexpr int xa_head_bytes() { return XA_MAXB * 16 * 64 * (int)sizeof(T) + XA_MAXB * 64 * 16 * (int)sizeof(T); }
+
+template <typename T, int MT, int NT>
+MI_DEV void xatt_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], char* smem, const float* rowstat, int m0, int n0, int wm, int wn, int tid) {
+    static_assert(MT == 4 && NT == 4, "cross-attention epilogue: 64 x 64 per wave");
+    constexpr int EPC = DT<T>::EPC, ES = sizeof(T), NS = 16 / EPC;
+    constexpr int ROWB = 64 * ES, CPR = ROWB / 16;
+    constexpr int KHEAD = XA_MAXB * 16 * ROWB;  // K rows of one head: [key block][16 keys][64 d], rows swizzled like every K tile
+    constexpr int VROWB = 16 * ES;              // one V^T row of one key block: 16 keys
+    constexpr int VBLK = 64 * VROWB;            // [64 d (permuted row order)][16 keys]
+    constexpr int HEADB = KHEAD + XA_MAXB * VBLK;
+    constexpr bool IS_BF16 = (ES == 2);
+    const int lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+    const GemmP::Xatt& xa = p.xa;
+    const int nb0 = (xa.Lk[0] + 15) >> 4, nb1 = xa.nstream > 1 ? (xa.Lk[1] + 15) >> 4 : 0, nbt = nb0 + nb1;
+    const int b = m0 / xa.Lq;  // sample of this row tile
+    const int h0 = n0 >> 6;    // first of the tile's two heads
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+
+    // ---- Q: bias / LayerNorm correction, rounded to T (the reference's Linear output), kept as B-operand fragments ----
+    frag_t qf[MT][NS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int mrow = wm * 64 + 16 * i + c16;
+        const int n = n0 + wn * 64 + 16 * g;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
+        if (p.ln_stats) {
+            const float mean = rowstat[2 * mrow], rstd = rowstat[2 * mrow + 1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4 * c), cv = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * c + e] = rstd * (v[4 * c + e] - mean * sv[e]) + cv[e];
+            }
+        } else if (bias) {
+#pragma unroll
+            for (int c = 0; c < 16 / EPC; ++c) {
+                Vec16<T> bv = load16<T>(bias + n + c * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            Vec16<T> qv;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) qv.set(e, v[EPC * s + e]);
+            qf[i][s] = __builtin_bit_cast(frag_t, qv.v);
+        }
+    }
+
+    __syncthreads();  // every wave has left the K loop (and read rowstat): the ring can be overwritten
+
+    // ---- K and V^T of the tile's two heads -> LDS (global -> registers -> LDS, all loads of a pass in flight) ----
+    {
+        constexpr int KIT = 2 * XA_MAXB * 16 * CPR / 256;  // K chunks per thread at full occupancy of the 6 blocks
+        const int krows = nbt * 16, ktot = 2 * krows * CPR;
+        frag_t kr[KIT];
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < ktot) {
+                const int hh = idx / (krows * CPR), r2 = idx - hh * (krows * CPR);
+                const int row = r2 / CPR, pch = r2 - row * CPR;
+                const int blk = row >> 4, sidx = blk >= nb0 ? 1 : 0;
+                int key = 16 * (sidx ? blk - nb0 : blk) + (row & 15);
+                key = key < xa.Lk[sidx] ? key : xa.Lk[sidx] - 1;
+                kr[it] = *reinterpret_cast<const frag_t*>(xa.k[sidx] + (int64_t)b * xa.kbsb[sidx] + (int64_t)key * xa.ldkb[sidx] + (int64_t)(h0 + hh) * ROWB + pch * 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < ktot) {
+                const int hh = idx / (krows * CPR), r2 = idx - hh * (krows * CPR);
+                const int row = r2 / CPR, pch = r2 - row * CPR;
+                *reinterpret_cast<frag_t*>(smem + hh * HEADB + tile_off<ROWB>(row, pch)) = kr[it];
+            }
+        }
+        constexpr int VCH = VROWB / 16;                     // 16-byte chunks per V^T row of one key block
+        constexpr int VIT = 2 * XA_MAXB * 64 * VCH / 256;
+        const int vper = nbt * 64 * VCH, vtot = 2 * vper;
+        frag_t vr[VIT];
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < vtot) {
+                const int hh = idx / vper, r2 = idx - hh * vper;
+                const int blk = r2 / (64 * VCH), r3 = r2 - blk * (64 * VCH);
+                const int row = r3 / VCH, ch = r3 - row * VCH;
+                const int sidx = blk >= nb0 ? 1 : 0, lb = sidx ? blk - nb0 : blk;
+                const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
+                const int d = 16 * a + 4 * j + bb;  // head-dim index stored in LDS row `row` (attn_kernel's permutation: 16 consecutive outputs per lane)
+                vr[it] = *reinterpret_cast<const frag_t*>(xa.vt[sidx] + ((int64_t)(h0 + hh) * 64 + d) * xa.ldvtb[sidx] + (int64_t)b * xa.vtbsb[sidx] + (int64_t)(16 * lb) * ES + ch * 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < vtot) {
+                const int hh = idx / vper, r2 = idx - hh * vper;
+                const int blk = r2 / (64 * VCH), r3 = r2 - blk * (64 * VCH);
+                const int row = r3 / VCH, ch = r3 - row * VCH;
+                *reinterpret_cast<frag_t*>(smem + hh * HEADB + KHEAD + blk * VBLK + row * VROWB + ch * 16) = vr[it];
+            }
+        }
+    }
+    __syncthreads();
+
+    const char* kb = smem + wn * HEADB;
+    const char* vb = kb + KHEAD;
+    T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {  // the wave's four 16-query blocks, two at a time (registers)
+        f32x4 res[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) res[i][0] = res[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            if (sidx < xa.nstream) {
+                const int nb = sidx ? nb1 : nb0, boff = sidx ? nb0 : 0, Lk = xa.Lk[sidx];
+                // ---- S^T = K Q^T for every key block of the stream ----
+                f32x4 st[XA_SB + 1][2];  // + 1: the zero partner of an odd last block in the P V product
+#pragma unroll
+                for (int t = 0; t <= XA_SB; ++t) {
+                    st[t][0] = st[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (t < nb) {  // wave-uniform: absent blocks cost nothing (their P stays 0)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            const frag_t kf = lds_read_frag(kb, tile_off<ROWB>(16 * (boff + t) + c16, NS * g + s));
+#pragma unroll
+                            for (int jq = 0; jq < 2; ++jq) mma_step<T>(st[t][jq], kf, qf[2 * pr + jq][s]);
+                        }
+                        if (16 * t + 16 > Lk) {  // the stream's ragged last block
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (16 * t + 4 * g + r >= Lk) st[t][0][r] = st[t][1][r] = -INFINITY;
+                        }
+                    }
+                }
+                // ---- softmax over the stream's keys (base 2, scale folded), P left in st ----
+                float inv[2];
+#pragma unroll
+                for (int jq = 0; jq < 2; ++jq) {
+                    float mx = st[0][jq][0];
+#pragma unroll
+                    for (int t = 0; t < XA_SB; ++t)
+                        if (t < nb) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][jq][r]);
+                        }
+                    mx = xa_group_max(mx);
+                    const float mc = mx * xa.c;
+                    float ps = 0.f;
+#pragma unroll
+                    for (int t = 0; t < XA_SB; ++t)
+                        if (t < nb) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float e = fast_exp2(st[t][jq][r] * xa.c - mc);
+                                st[t][jq][r] = e;
+                                ps += e;
+                            }
+                        }
+                    inv[jq] = xa.out_scale[sidx] / xa_group_sum(ps);
+                }
+                // ---- O^T = V^T P^T ----
+                f32x4 o[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i][0] = o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (IS_BF16) {
+#pragma unroll
+                    for (int u = 0; u < (XA_SB + 1) / 2; ++u) {
+                        if (2 * u < nb) {
+                            frag_t pb[2];
+#pragma unroll
+                            for (int jq = 0; jq < 2; ++jq) {
+                                bf16x8 pk;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    pk[r] = (bf16_t)st[2 * u][jq][r];
+                                    pk[4 + r] = (bf16_t)st[2 * u + 1][jq][r];
+                                }
+                                pb[jq] = __builtin_bit_cast(frag_t, pk);
+                            }
+                            const int ba = boff + 2 * u, bc = boff + (2 * u + 1 < nb ? 2 * u + 1 : nb - 1);  // a missing partner block: P = 0, any finite V^T
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int row = 16 * i + c16;
+                                const half_frag_t va = lds_read_half(vb, ba * VBLK + row * VROWB + 8 * g);
+                                const half_frag_t vc = lds_read_half(vb, bc * VBLK + row * VROWB + 8 * g);
+                                const frag_t vf = frag_t{va[0], va[1], vc[0], vc[1]};
+#pragma unroll
+                                for (int jq = 0; jq < 2; ++jq) mma_step<T>(o[i][jq], vf, pb[jq]);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < XA_SB; ++t) {
+                        if (t < nb) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const frag_t vf = lds_read_frag(vb, (boff + t) * VBLK + (16 * i + c16) * VROWB + 16 * g);
+#pragma unroll
+                                for (int jq = 0; jq < 2; ++jq) mma_step<T>(o[i][jq], vf, __builtin_bit_cast(frag_t, st[t][jq]));
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jq = 0; jq < 2; ++jq) res[i][jq] += o[i][jq] * inv[jq];
+            }
+        }
+        // ---- store: lane owns d = 16 g + 4 i + r (16 consecutive) of query 16 (2 pr + jq) + c16 ----
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+            const int m = m0 + wm * 64 + 16 * (2 * pr + jq) + c16;
+            T* op = out + (int64_t)m * p.ldo + n0 + wn * 64 + 16 * g;
+#pragma unroll
+            for (int c = 0; c < 16 / EPC; ++c) {
+                Vec16<T> ov;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) ov.set(e, res[(c * EPC + e) >> 2][jq][(c * EPC + e) & 3]);
+                store16<T>(op + c * EPC, ov);
+            }
+        }
+    }
+}
+
 constexpr int LORA_R = 32;  // stacked LoRA rank handled inside a launch (two rank-16 adapters, or anything that pads to 32)
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0>
-__global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
+__global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_eu(XATT ? 2 : 1))) void gemm_kernel(const GemmP p) {
     constexpr int NW = WM * WN;           // waves per K group
     constexpr int NTHR = NW * 64;         // threads per K group: the loader geometry
     constexpr int NTHR_ALL = NTHR * KG;   // threads per workgroup
@@ -132,6 +408,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
     static_assert(!LORA || (!CONV && KG == 1 && NTHR == 256 && WN == 2), "in-launch LoRA: plain GEMM, 4 waves as 2 x 2");
     static_assert(!STAG || (BM == 256 && BN == 128 && WM == 4 && WN == 2 && NSTAGE == 3 && KG == 1 && !LORA), "staggered schedule: 256 x 128, 8 waves, 3 stages");
     static_assert(KG == 1 || KG == 2, "one or two K groups");
+    static_assert(!XATT || (BM == 128 && BN == 128 && WM == 2 && WN == 2 && !CONV && KG == 1 && !LORA && !STAG), "cross-attention epilogue: the 128 x 128 tile, 2 x 2 waves");
     constexpr int WNE = 16 * NT;  // columns per wave
     constexpr int WME = 16 * MT;  // rows per wave
     static_assert(BM * 8 % NTHR == 0 && BN * 8 % NTHR == 0, "tile/thread mismatch");
@@ -796,6 +1073,11 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) void gemm_kernel(const GemmP p) {
         }
     }
 
+    if constexpr (XATT) {
+        xatt_epilogue<T, MT, NT>(p, acc, smem, rowstat, m0, n0, wm, wn, tid);
+        return;
+    }
+
     // every lane owns RUN = 4*NT consecutive columns of MT rows
     constexpr int RUN = 4 * NT;
     const int nl = wn * WNE + RUN * g;
@@ -1008,12 +1290,13 @@ extern int g_pf_mode;    // 1 = plain loads, 2 = non-temporal
 extern int g_tile;       // 0 = heuristic / caller's hint, 1..6 = force a tile configuration (probing / A-B runs)
 extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS pipeline depth
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
-    constexpr int LDS = KG * NSTAGE * ((BM + BN) * 128 + (LORA ? LORA_R * 128 : 0)) + BM * 8;
+    constexpr int LDS0 = KG * NSTAGE * ((BM + BN) * 128 + (LORA ? LORA_R * 128 : 0)) + BM * 8;
+    constexpr int LDS = XATT && 2 * xa_head_bytes<T>() > LDS0 ? 2 * xa_head_bytes<T>() : LDS0;  // the epilogue's K / V^T of two heads reuse the ring
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(KG == 1 || (BM / WM / 16) * (BN / WN / 16) * WM * WN * 1024 <= KG * NSTAGE * (BM + BN) * 128, "partial-tile exchange must fit the stage buffers");
-    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG, LORA, STAG>;
+    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG, LORA, STAG, XATT>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1061,7 +1344,7 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     q.pf_mode = g_pf_mode;
     const int grid = q.pf_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), q.ln_stats ? LDS : LDS - BM * 8, stream, q);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), (q.ln_stats || XATT) ? LDS : LDS - BM * 8, stream, q);
     if (q.ksplit > 1) {
         const int64_t work = (int64_t)q.M * ((q.N + 3) / 4);
         int64_t rb = (work + 255) / 256;
@@ -1108,6 +1391,7 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
     if (p.geglu && (tile == 2 || tile == 4)) tile = 3;  // the GEGLU epilogue needs 64 packed columns per wave
     const int st = pick_stages(p);
     if constexpr (!CONV) {
+        if (p.xa.nstream) return launch_cfg<T, 128, 128, 2, 2, false, 2, 1, false, 0, true>(p, stream);  // cross-attention epilogue: the tile that holds 128 queries x 2 heads
         if (p.lora_b) {  // in-launch LoRA: the 4-wave tiles, two LDS stages
             switch (tile) {
                 case 2: return launch_cfg<T, 128, 64, 2, 2, false, 2, 1, true>(p, stream);

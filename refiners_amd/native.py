@@ -139,6 +139,10 @@ class GemmArgs(C.Structure):
         ("lora_b", C.c_void_p),
         ("lora_ls", C.c_void_p),
         ("lora_lc", C.c_void_p),
+        ("xattn_kv", C.c_void_p),
+        ("xattn_nstream", C.c_int32),
+        ("xattn_lq", C.c_int32),
+        ("xattn_scale", C.c_float),
     ]
 
 
@@ -311,7 +315,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_groupnorm_set_fused.argtypes = [C.c_int, C.c_int64]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
-    if lib.mi355x_abi_version() != 3:
+    if lib.mi355x_abi_version() != 4:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
     import os
@@ -554,8 +558,11 @@ def gemm(
     stats_out: Optional[Tensor] = None,
     out_f32: bool = False,
     lora: Optional[tuple[Sequence[tuple[int, "KBlocked"]], Tensor]] = None,
+    xattn: Optional[tuple[Sequence[tuple[Tensor, Tensor, int, float]], int, Optional[float]]] = None,
 ) -> Optional[Tensor]:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
+    xattn = (streams, queries per sample, scale | None): cross-attention in the epilogue (see the header): `out` receives
+    sum_s out_scale_s softmax(scale Q K_s^T) V_s instead of Q; streams as for attention(): (k [B, Lk(+), N] view, vt [N, B, Lkp] view, Lk, out_scale).
     weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch.
     out_t / nt_begin: columns >= nt_begin are written transposed, out_t[n - nt_begin][m] (`out` then has nt_begin columns).
     ln = (stats [parts, M, 2] float32, s [N] float32, c [N] float32, eps): LayerNorm of x folded into this launch (see the header);
@@ -615,6 +622,18 @@ def gemm(
         assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= (a.N // 32) * a.M * 2 and a.N % 64 == 0
         a.stats_out = stats_out.data_ptr()
         keep.append(stats_out)
+    if xattn is not None:
+        streams, lq, scale = xattn
+        kvs = (KvStream * 2)()
+        for s, (k, vt, Lk, osc) in enumerate(streams):
+            assert k.dim() == 3 and vt.dim() == 3 and k.stride(2) == 1 and vt.stride(2) == 1 and k.shape[2] == a.N and vt.shape[0] == a.N
+            kv = kvs[s]
+            kv.k, kv.ldk, kv.k_batch_stride = k.data_ptr(), k.stride(1), k.stride(0)
+            kv.vt, kv.ldvt, kv.vt_batch_stride = vt.data_ptr(), vt.stride(0), vt.stride(1)
+            kv.Lk, kv.out_scale = Lk, osc
+        a.xattn_kv, a.xattn_nstream, a.xattn_lq = C.addressof(kvs), len(streams), lq
+        a.xattn_scale = scale if scale is not None else 64 ** -0.5
+        keep.append((kvs, streams))
     _fill_split(a, tile, ksplit, ws, stages)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm", keep=tuple(keep))
     return out

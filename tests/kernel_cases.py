@@ -224,6 +224,47 @@ def conv_first_case(B, H, W, dtype, seed=60):
     return _cmp(got, ref, dtype)
 
 
+# ------------------------------------------------------------------------------------------------ q-projection + cross-attention in one launch
+def gemm_xattn_case(B, Lq, K, H, Lk, dtype, *, ip_tokens=0, ip_scale=0.6, ln=False, bias=True, seed=300):
+    """out = SDPA(Linear_q(x) [or Linear_q(LayerNorm(x))], K_text, V_text) (+ ip_scale SDPA(., K_ip, V_ip)) as ONE mi355x_gemm launch
+    (xattn epilogue) vs the two-step float32 reference on the same (rounded) operands."""
+    Cc, M = 64 * H, B * Lq
+    x = _rand(M, K, dtype=dtype, seed=seed) * (1.5 if ln else 1.0) + (0.7 if ln else 0.0)
+    w = _rand(Cc, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(Cc, dtype=dtype, seed=seed + 2) if bias and not ln else None
+    k = _rand(B, Lk, Cc, dtype=dtype, seed=seed + 3)
+    v = _rand(B, Lk, Cc, dtype=dtype, seed=seed + 4)
+    streams = [(k, _vt_from_v(v, (Lk + 63) // 64 * 64), Lk, 1.0)]
+    kvs = [(k, v, 1.0)]
+    if ip_tokens:
+        k2 = _rand(B, ip_tokens, Cc, dtype=dtype, seed=seed + 5)
+        v2 = _rand(B, ip_tokens, Cc, dtype=dtype, seed=seed + 6)
+        streams.append((k2, _vt_from_v(v2, (ip_tokens + 63) // 64 * 64), ip_tokens, ip_scale))
+        kvs.append((k2, v2, ip_scale))
+    out = torch.full((M, Cc), float("nan"), dtype=dtype, device=DEV)
+    if ln:
+        eps = 1e-5
+        gamma = (1 + 0.1 * _rand(K, dtype=torch.float32, seed=seed + 7)).to(dtype)
+        beta = (0.1 * _rand(K, dtype=torch.float32, seed=seed + 8)).to(dtype)
+        bq = _rand(Cc, dtype=dtype, seed=seed + 2)
+        xf = x.float()
+        xc = xf.reshape(M, K // 32, 32)  # the producer-side format: (mean, M2) of every 32-column chunk of the row
+        cm = xc.mean(dim=2)
+        stats = torch.stack([cm, ((xc - cm[:, :, None]) ** 2).sum(dim=2)], dim=2).permute(1, 0, 2).contiguous()  # [K / 32, M, 2]
+        wl = (w.float() * gamma.float()[None, :]).to(dtype).contiguous()
+        ls = wl.float().sum(dim=1).contiguous()
+        lc = (w.float() @ beta.float() + bq.float()).contiguous()
+        native.gemm([(x, native.KBlocked(wl))], out, ln=(stats, ls, lc, eps), xattn=(streams, Lq, None))
+        xn = torch.nn.functional.layer_norm(xf, (K,), gamma.float(), beta.float(), eps)
+        q = xn @ w.float().t() + bq.float()
+    else:
+        native.gemm([(x, native.KBlocked(w))], out, bias=b, xattn=(streams, Lq, None))
+        q = x.float() @ w.float().t() + (b.float() if b is not None else 0)
+    q = q.to(dtype).reshape(B, Lq, Cc)  # the reference's Linear output is a tensor of the compute dtype
+    ref = sum(sc * _sdpa_ref(q, kk, vv, H) for kk, vv, sc in kvs)
+    return _cmp(out.reshape(B, Lq, Cc), ref, dtype)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _vt_from_v(v: torch.Tensor, Lkp: int) -> torch.Tensor:
     B, Lk, Cc = v.shape
@@ -783,6 +824,14 @@ def all_cases():
                              ("3tiles", (2, 2, 192, 192), {"seed": 72})):
             for code in (0x20001, 0x20011):
                 cases.append((f"attn_{tag}_kvsplit{code & 0xff:02x}_{nm}", lambda dt=dt, args=args, kw=kw, code=code: attention_case(*args, dt, pipe=code, **kw)))
+        cases += [
+            (f"xattn_{tag}_77_bias", lambda dt=dt: gemm_xattn_case(2, 128, 640, 4, 77, dt)),
+            (f"xattn_{tag}_77_ip4_bias", lambda dt=dt: gemm_xattn_case(2, 256, 1280, 6, 77, dt, ip_tokens=4, seed=301)),
+            (f"xattn_{tag}_77_ip16_ln", lambda dt=dt: gemm_xattn_case(1, 384, 640, 10, 77, dt, ip_tokens=16, ln=True, seed=302)),
+            (f"xattn_{tag}_Lk80_nobias", lambda dt=dt: gemm_xattn_case(2, 128, 320, 2, 80, dt, bias=False, seed=303)),
+            (f"xattn_{tag}_Lk1_ip1", lambda dt=dt: gemm_xattn_case(1, 128, 320, 2, 1, dt, ip_tokens=1, seed=304)),
+            (f"xattn_{tag}_Lk33_ln", lambda dt=dt: gemm_xattn_case(1, 128, 1280, 20, 33, dt, ln=True, seed=305)),
+        ]
         # launches of at most three K/V tiles take the all-tiles-up-front kernel by default (the cases above: cross_77, cross_77_ip4, 1tile, 3tiles,
         # Lq_edge_200); 0x40000 switches it off, so the same shapes also run through the general tile loop; and its remaining slot layouts
         cases += [
