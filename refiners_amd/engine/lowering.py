@@ -244,6 +244,10 @@ class Lowering:
         # extra elements per row of a self-attention's V^T buffer [C][B L (+ pad)]: with a row stride of exactly B L elements (4 / 16 KB at 1024 / 4096
         # tokens) the 64 rows of a V^T tile sit a power of two apart in memory
         self.vt_pad = int(os.environ.get("REFINERS_AMD_VT_PAD", "0"))
+        # EXPERIMENTAL, off: a cross-attention's q-projection and its SDPA over the (short, prologue-resident) text / image keys as ONE launch
+        # (mi355x_gemm's xattn epilogue).  Kernel-level parity is tested (tests/kernel_cases.py: xattn_*); measured level with the two launches
+        # at a CFG pair and 8 % ahead at 4 images (profiles/r02_w_probe_xattn.log); this switch has not been through the engine tests yet
+        self.xattn_fuse = os.environ.get("REFINERS_AMD_XATTN_FUSE", "0") == "1"
         self.device, self.dtype = device, dtype
         self.es = 4 if dtype == torch.float32 else 2
         self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
@@ -892,6 +896,25 @@ class Lowering:
             plains.append(vp2)
             self.stats["ip_sites"] += 1
         qspec = self.linear_spec(qn)
+        M, C = x.shape[0], qspec.N
+        if (self.xattn_fuse and self.device.type != "meta" and qspec.lora is None and plains[0] is None and self.head_kernel(C // heads) == "flash64"
+                and (M // B) % 128 == 0 and C % 128 == 0 and all(lk <= 80 for (_k, _v, lk, _s) in streams) and sum((lk + 15) // 16 for (_k, _v, lk, _s) in streams) <= 6):
+            st = []
+            for kk, vt, lk, osc in streams:  # the views mi355x_attention takes (see sdpa)
+                lkp, lv = kk.shape[0] // B, vt.shape[1] // B
+                st.append((kk.as_strided((B, lkp, C), (lkp * kk.stride(0), kk.stride(0), 1)), vt.as_strided((C, B, lv), (vt.stride(0), lv, 1)), lk, osc))
+            o = self.pool.get(M, C)
+            if self.ln_fusable(stats, qspec):
+                wl, ls, lc = self.ln_fold(qspec, ln)
+                native.gemm([(x, self.kblocked(wl))], o, ln=(stats, ls, lc, float(ln.eps)), xattn=(st, M // B, None))
+            else:
+                h = self.layernorm(x, ln)
+                native.gemm([(h, self.kblocked(qspec.w))], o, bias=qspec.b, xattn=(st, M // B, None))
+                self.pool.put(h)
+            self.stats["xattn_fused"] = self.stats.get("xattn_fused", 0) + 1
+            self.linear(o, self.linear_spec(on), res=x, out=x, stats_out=stats_out)
+            self.pool.put(o)
+            return x
         if self.ln_fusable(stats, qspec):
             q = self.linear(x, qspec, ln=(stats, ln))
         else:

@@ -734,7 +734,7 @@ def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 1
 def gemm_signature(a: GemmArgs) -> str:
     """Shape class of a GEMM / conv launch: the key of the measured tile table (refiners_amd/engine/tuning.py)."""
     k = sum(int(a.seg[s].k) * (int(a.seg[s].ksize) ** 2 if a.conv else 1) for s in range(a.nseg))
-    flags = ("geglu" if a.geglu == 1 else "") + ("T%d" % a.nt_begin if a.out_t else "") + ("ln" if a.ln_stats else "") + ("st" if a.stats_out else "") + ("lora" if a.lora_b else "")
+    flags = ("geglu" if a.geglu == 1 else "") + ("T%d" % a.nt_begin if a.out_t else "") + ("ln" if a.ln_stats else "") + ("st" if a.stats_out else "") + ("lora" if a.lora_b else "") + ("xa" if a.xattn_kv else "")
     return f"{'conv' if a.conv else 'gemm'}:{'f32' if a.dtype == 0 else 'bf16'}:{a.M}x{a.N}x{k}:s{a.nseg}:{flags}"
 
 
