@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 4
+#define MI355X_ABI_VERSION 5
 
 enum { MI355X_F32 = 0, MI355X_BF16 = 1 };
 
@@ -157,21 +157,33 @@ typedef struct {
     int32_t out_f32;        /* 1 = `out` is float32 whatever `dtype` says (ldo in float elements; 16-byte aligned rows): raw scores for
                                mi355x_softmax_rows.  Not combinable with geglu / stats_out / out_t / ksplit. */
     /* LoRA inside the parent launch -- LoraAdapter = Sum(target, *loras), src/refiners/fluxion/adapters/lora.py:383-397, with
-       Lora = Chain(down, up, Multiply(scale)) (:14-60) -- for a stacked rank of at most 32 (zero-padded to 32):
+       Lora = Chain(down, up, Multiply(scale)) (:14-60; LinearLora :269-322, Conv2dLora :325-380) -- for a stacked rank lora_r that is a
+       multiple of 32 and at most 128 (zero-padded):
          out += T( x . A_g^T ) . lora_b[n]^T      g = column group of n (lora_nb[g] <= n, groups start on multiples of 128)
-       lora_a[g]: the 32 stacked down-projection rows of group g, K-BLOCKED: [K*sizeof/128][32][128 bytes]; lora_b: [N][32] row-major,
-       the up-projections already multiplied by their scales (rows follow the same N-packing as w).  x A^T is accumulated in the
-       same K loop as x W^T and rounded to `dtype` (the reference's intermediate tensor) before the up-projection step.
-       One segment, no conv / ksplit.  lora_b == NULL: off.
+       lora_a[g]: the lora_r stacked down-projection rows of group g, K-BLOCKED: [K*sizeof/128][lora_r][128 bytes] (conv == 1: the down
+       convolutions' weights packed like w, same kernel size / stride / padding as segment 0; the up convolutions must be 1x1);
+       lora_b: [N][lora_r] row-major, the up-projections already multiplied by their scales (rows follow the same N-packing as w).
+       The LoRAs adapt segment 0.  x A^T is computed ONCE per row block, by extra workgroups at the head of the launch's grid (no column
+       tile recomputes it), rounded to `dtype` (the reference's intermediate tensor), handed to the output tiles through
+         lora_t     scratch, >= groups * M * lora_r elements of `dtype`, 16-byte aligned,
+         lora_flags int32[groups * ceil(M / 64)], zeroed once by the caller and private to this call site (they keep the last epoch),
+         lora_epoch device pointer to an int32 whose value differs from every value left in lora_flags: increment it (mi355x_epoch_bump)
+                    before each launch, or once per replay of a recorded program whose LoRA launches each own their flags,
+       and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with xattn_kv, out_f32 or the 8-wave tiles;
+       with ksplit the first split carries the LoRA term.
        With ln_stats (x un-normalised): lora_a carries gamma like w does (A' = A . diag(gamma)) and the caller adds
-         lora_ls[g][r] = sum_k A'_g[r][k],   lora_lc[g][r] = sum_k beta[k] A_g[r][k]        (float32, [groups][32]). */
+         lora_ls[g][r] = sum_k A'_g[r][k],   lora_lc[g][r] = sum_k beta[k] A_g[r][k]        (float32, [groups][lora_r]). */
     const void* lora_a[3];
     int32_t lora_nb[3];
     int32_t lora_groups;
+    int32_t lora_r;
     const void* lora_b;
     const void* lora_ls;
     const void* lora_lc;
-    /* Cross-attention in the epilogue of its q-projection (ABI 4) -- the second Residual of CrossAttentionBlock,
+    void* lora_t;
+    int32_t* lora_flags;
+    const int32_t* lora_epoch;
+    /* Cross-attention in the epilogue of its q-projection (since ABI 4) -- the second Residual of CrossAttentionBlock,
        src/refiners/foundationals/latent_diffusion/cross_attention.py:25-73: Attention(Linear_q(LayerNorm(x)), K, V) with the text keys
        (and, with the IP-Adapter, Sum(SDPA, ImageCrossAttention), image_prompt.py:237-309) -- for K / V that are constant over the
        sampling loop and SHORT: at most 80 keys per stream and 96 in total (rounded up to 16 per stream).  The launch computes
@@ -188,6 +200,8 @@ typedef struct {
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);
+/* *epoch += 1 (skipping 0) on `stream`: the hand-off generation of mi355x_gemm's in-launch LoRA (see lora_epoch). */
+int mi355x_epoch_bump(int32_t* epoch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * mi355x_attention -- out = sum_s out_scale_s * softmax(scale * Q K_s^T) V_s      (flash style, no mask, non causal)

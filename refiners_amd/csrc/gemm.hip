@@ -39,6 +39,19 @@ extern "C" int mi355x_set_option(const char* name, int value) {
     return MI355X_EARG;
 }
 
+namespace {
+__global__ void epoch_bump_kernel(int* e) {
+    const int v = *e + 1;
+    *e = v == 0 ? 1 : v;  // 0 is what freshly zeroed flags hold: never a valid epoch
+}
+}  // namespace
+
+extern "C" int mi355x_epoch_bump(int32_t* epoch, void* stream) {
+    if (!epoch) return MI355X_EARG;
+    hipLaunchKernelGGL(epoch_bump_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), epoch);
+    return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
+}
+
 extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     if (!a) return MI355X_EARG;
     const bool has_t = a->out_t != nullptr;
@@ -132,7 +145,10 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         p.ln_c = static_cast<const float*>(a->ln_c);
     }
     if (a->lora_b) {
-        if (a->conv || a->nseg != 1 || a->ksplit > 1 || (a->ln_stats && (!a->lora_ls || !a->lora_lc)) || a->out_f32 || a->lora_groups < 1 || a->lora_groups > 3 || a->lora_nb[0] != 0 || !aligned16(a->lora_b))
+        if (a->ksplit > 1 && a->geglu) return MI355X_ESHAPE;
+        if ((a->ln_stats && (!a->lora_ls || !a->lora_lc)) || a->out_f32 || a->xattn_kv || a->lora_groups < 1 || a->lora_groups > 3 || a->lora_nb[0] != 0 ||
+            !aligned16(a->lora_b) || a->lora_r < 32 || a->lora_r > mi355x::LORA_RMAX || a->lora_r % 32 || !a->lora_t || !aligned16(a->lora_t) || !a->lora_flags ||
+            !a->lora_epoch || (a->conv && a->lora_groups != 1))
             return MI355X_ESHAPE;
         for (int g = 0; g < a->lora_groups; ++g) {
             if (!a->lora_a[g] || !aligned16(a->lora_a[g]) || a->lora_nb[g] % 128 || (g && a->lora_nb[g] <= a->lora_nb[g - 1])) return MI355X_ESHAPE;
@@ -140,9 +156,13 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
             p.lora_nb[g] = a->lora_nb[g];
         }
         p.lora_groups = a->lora_groups;
+        p.lora_r = a->lora_r;
         p.lora_b = static_cast<const char*>(a->lora_b);
         p.lora_ls = static_cast<const float*>(a->lora_ls);
         p.lora_lc = static_cast<const float*>(a->lora_lc);
+        p.lora_t = static_cast<char*>(a->lora_t);
+        p.lora_flags = a->lora_flags;
+        p.lora_epoch = a->lora_epoch;
     }
     if (a->out_f32) {
         if (a->conv || a->ksplit > 1 || a->geglu == 1 || has_t || a->stats_out || !a->out) return MI355X_ESHAPE;

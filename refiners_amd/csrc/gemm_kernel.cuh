@@ -30,12 +30,18 @@
 //     epilogue applies y = rstd[m] * (acc - mean[m] * s[n]) + c[n] with s = W' 1, c = W beta + bias.  mean / rstd come from
 //     per-row (mean, M2) partials over 32-column chunks that the launch PRODUCING r wrote from its epilogue (Chan-merged
 //     in a fixed order: deterministic, no atomics);
-//   * LoRA inside the parent launch (LORA = true): the stacked down-projection rows A_cat [32][K] ride in the K loop as 32 extra
-//     weight rows of every stage (t = x A_cat^T accumulates next to the main product, the two waves that share a row block
-//     compute one half each), and after the loop t -- rounded to the storage type like the reference's intermediate tensor --
-//     goes through LDS as one more K step against the stacked, pre-scaled up-projections (s B_cat) [N][32]:
-//     y = x W^T + b + sum_i s_i (x A_i^T) B_i^T from ONE kernel (fluxion/adapters/lora.py:383-397), per-column-group A so that a
-//     merged Q|K|V launch keeps its three LoRA sets;
+//   * LoRA inside the parent launch (LORA = true): y = x W^T + b + sum_i s_i (x A_i^T) B_i^T from ONE kernel
+//     (fluxion/adapters/lora.py:383-397) without any column tile recomputing the down-projection.  tiles_m x groups extra workgroups at
+//     the head of the grid (the "producers", one per row block and column group) compute t = x A_cat^T for their BM rows with this
+//     kernel's own loader (plain rows or conv taps) against the stacked down rows A_cat [R][K] (R <= 128), round t to the storage type
+//     like the reference's intermediate tensor, store it write-through (sc1) to a scratch [groups][M][R] and publish a per-row-block
+//     flag (= the launch's epoch, read from device memory).  Every output tile runs its K loop exactly like an un-adapted launch, then
+//     waits for its row block's flag (set long before: the producers' K loop carries R / BN of a tile's MFMAs), pulls its t rows
+//     (sc1 loads) and multiplies them, 32 ranks per step, against the pre-scaled up rows (s B_cat) [N][R]; the first 32 ranks of those
+//     were staged into LDS by the prologue.  Producers have the lowest workgroup ids of the launch, so they are dispatched before any
+//     tile that waits for them (the spin is bounded by the wall clock and traps rather than hangs).  Per-column-group A so that a
+//     merged Q|K|V launch keeps its three LoRA sets; Conv2dLora = the same with the conv loader (down conv of the parent's kernel
+//     size / stride, 1x1 up conv);
 //   * bf16 -> v_mfma_f32_16x16x32_bf16, f32 (parity mode) -> v_mfma_f32_16x16x4_f32; identical LDS image.
 #pragma once
 #include <type_traits>
@@ -90,14 +96,19 @@ struct GemmP {
     const float* ln_c;  // [N]: sum_k beta[k] W[n][k] (+ bias[n])
     float* stats_out;   // [N / 32][M][2], or NULL
     int out_f32;        // store `out` as float32 (scores for mi355x_softmax_rows)
-    // LoRA inside the launch: per column group g (columns >= lora_nb[g]) the K-blocked stacked down rows, [K blocks][32][128 B];
-    // lora_b: [N][32] pre-scaled up-projections (row n = output column n), row-major
+    // LoRA inside the launch: per column group g (columns >= lora_nb[g]) the K-blocked stacked down rows, [K blocks][lora_r][128 B];
+    // lora_b: [N][lora_r] pre-scaled up-projections (row n = output column n), row-major
     const char* lora_a[3];
     int lora_nb[3];
     int lora_groups;
+    int lora_r;            // stacked rank, a multiple of 32, <= 128
     const char* lora_b;
-    const float* lora_ls;  // LayerNorm folded into this launch AND LoRA: [groups][32] sum_k A'[r][k] and
-    const float* lora_lc;  //                                            [groups][32] sum_k beta[k] A[r][k]
+    const float* lora_ls;  // LayerNorm folded into this launch AND LoRA: [groups][lora_r] sum_k A'[r][k] and
+    const float* lora_lc;  //                                            [groups][lora_r] sum_k beta[k] A[r][k]
+    char* lora_t;          // [groups][M][lora_r] of T: the producers' t = x A^T (already divided by rstd when LayerNorm is folded in)
+    int* lora_flags;       // [groups][tiles_m]: == *lora_epoch once that row block's t is complete
+    const int* lora_epoch;
+    int lp_blocks;         // producer workgroups at the head of the grid (tiles_m * groups rounded up to a multiple of 8)
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
     const char* pf_ptr[MI355X_MAX_PREFETCH];
@@ -394,7 +405,13 @@ MI_DEV void xatt_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], char* smem, cons
     }
 }
 
-constexpr int LORA_R = 32;  // stacked LoRA rank handled inside a launch (two rank-16 adapters, or anything that pads to 32)
+constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
+constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch (control-lora-*-rank128)
+
+// 8-byte relaxed agent-scope accesses: sc1 (write-through / L1-bypassing) on gfx950, the form the microarchitecture guide lists as valid
+// for an inter-workgroup hand-off without fences ("8-B agent atomics both sides")
+MI_DEV void st_agent8(void* p, uint64_t v) { __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+MI_DEV uint64_t ld_agent8(const void* p) { return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
 __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_eu(XATT ? 2 : 1))) void gemm_kernel(const GemmP p) {
@@ -403,9 +420,9 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     constexpr int NTHR_ALL = NTHR * KG;   // threads per workgroup
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
     constexpr int XI = BM * 8 / NTHR, WI = BN * 8 / NTHR;
-    constexpr int XBYTES = BM * 128, WBYTES = BN * 128, ABYTES = LORA ? LORA_R * 128 : 0, STAGE = XBYTES + WBYTES + ABYTES;
+    constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
-    static_assert(!LORA || (!CONV && KG == 1 && NTHR == 256 && WN == 2), "in-launch LoRA: plain GEMM, 4 waves as 2 x 2");
+    static_assert(!LORA || (KG == 1 && NTHR == 256 && WN == 2 && !STAG && !XATT), "in-launch LoRA: 4 waves as 2 x 2");
     static_assert(!STAG || (BM == 256 && BN == 128 && WM == 4 && WN == 2 && NSTAGE == 3 && KG == 1 && !LORA), "staggered schedule: 256 x 128, 8 waves, 3 stages");
     static_assert(KG == 1 || KG == 2, "one or two K groups");
     static_assert(!XATT || (BM == 128 && BN == 128 && WM == 2 && WN == 2 && !CONV && KG == 1 && !LORA && !STAG), "cross-attention epilogue: the 128 x 128 tile, 2 x 2 waves");
@@ -414,6 +431,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     static_assert(BM * 8 % NTHR == 0 && BN * 8 % NTHR == 0, "tile/thread mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* rowstat = reinterpret_cast<float*>(smem + KG * NSTAGE * STAGE);  // [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer)
+    char* const lora_b0 = smem + KG * NSTAGE * STAGE + BM * 8;               // LORA: [BN][32 ranks] of T, the first up-projection chunk (staged by the prologue)
 
     const int tid_all = threadIdx.x, wid_all = wave_id();
     const int kg = KG > 1 ? wid_all / NW : 0;
@@ -446,10 +464,22 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         if (acc == 0x5a5a1234 && p.pf_bytes[0] < 0) *reinterpret_cast<int*>(p.out) = acc;  // never taken: keeps the loads alive
         return;
     }
-    const int bid = (int)blockIdx.x - p.pf_blocks;
-    const int split = p.ksplit > 1 ? bid / p.grid0 : 0;
+    // LoRA producer role (see the header): workgroup q = (column group, row block) computes t = x A^T for its BM rows
+    bool prod = false;
+    int pgi = 0, split = 0, tm = 0, tn = 0;
+    int bid = (int)blockIdx.x - p.pf_blocks;
+    if constexpr (LORA) {
+        if (bid < p.lp_blocks) {
+            if (bid >= p.tiles_m * p.lora_groups) return;  // padding up to a multiple of 8 (keeps compute block b on XCD b % 8)
+            prod = true;
+            pgi = bid / p.tiles_m;
+            tm = bid - pgi * p.tiles_m;
+        }
+        bid -= p.lp_blocks;
+    }
+    if (!prod) {
+    split = p.ksplit > 1 ? bid / p.grid0 : 0;
     const int bx = bid - split * p.grid0;
-    int tm, tn;
     if (p.pn > 0) {  // rectangular regions (exact split of the tile grid, grid0 = 8 * hm * hn)
         const int xcd = bx & 7, idx = bx >> 3;
         const int rm = xcd / p.pn, rn = xcd - rm * p.pn;
@@ -467,8 +497,12 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         }
     }
     if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
-    const bool tr = !CONV && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
+    const bool tr = !CONV && !prod && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
+    const int Nw = prod ? p.lora_r : p.N;                // rows of the weight operand this workgroup streams
+    const int nseg = prod ? 1 : p.nseg;                  // the LoRAs adapt segment 0 (the conv / Linear itself, not a fused shortcut)
+    const int lora_tag = LORA ? *p.lora_epoch : 0;
 
     // ---- per-thread loader coordinates (fixed for the whole K loop) ----
     // Exactly one operand's rows are permuted inside each wave's 16*T-row span (see the header): the weights' normally, the
@@ -503,8 +537,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         const int q = it * NTHR + tid, row = q >> 3, pch = q & 7;
         wcoff[it] = (pch ^ swz<128>(row)) << 4;
         const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
-        const int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
-        wnrow[it] = n < p.N ? n : p.N - 1;
+        const int n = n0 + (tr || prod ? row : (row - rl) + 4 * NT * a + 4 * j + b);  // producer: rank r = LDS row r
+        wnrow[it] = n < Nw ? n : Nw - 1;
     }
 
     f32x4 acc[MT][NT];
@@ -512,27 +546,19 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // in-launch LoRA: t[rows of this wave][16 of the 32 stacked ranks: half wn] = x A_cat^T, accumulated next to the main product
-    f32x4 tacc[LORA ? MT : 1];
-#pragma unroll
-    for (int i = 0; i < (LORA ? MT : 1); ++i) tacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const char* abase = nullptr;  // this thread's 16 bytes of the A_cat K block (K-blocked: [K block][32 rows][128 B])
-    int64_t aoff = 0;
-    if constexpr (LORA) {
-        const int gi = (p.lora_groups > 1 && n0 >= p.lora_nb[1] ? 1 : 0) + (p.lora_groups > 2 && n0 >= p.lora_nb[2] ? 1 : 0);
-        const int row = tid >> 3, pch = tid & 7;
-        abase = p.lora_a[gi] + row * 128 + ((pch ^ swz<128>(row)) << 4);
-    }
+    // in-launch LoRA: column group of this tile, and whether this workgroup adds the LoRA term (split-K: the first split only)
+    const int lgi = LORA ? (p.lora_groups > 1 && n0 >= p.lora_nb[1] ? 1 : 0) + (p.lora_groups > 2 && n0 >= p.lora_nb[2] ? 1 : 0) : 0;
+    const bool lora_tail = LORA && !prod && split == 0;
 
     // ---- K-block iteration state ----
     int seg = 0, kb = 0;  // kb = block index inside the current segment
     int total_kb = 0;
-    for (int s = 0; s < p.nseg; ++s) total_kb += p.seg[s].nkb;
-    if (p.ksplit > 1) {  // this workgroup's share of the K blocks: [first, first + total_kb)
+    for (int s = 0; s < nseg; ++s) total_kb += p.seg[s].nkb;
+    if (p.ksplit > 1 && !prod) {  // this workgroup's share of the K blocks: [first, first + total_kb)
         const int first = split * p.kb_per_split;
         total_kb = min(p.kb_per_split, total_kb - first);
         kb = first;
-        while (seg < p.nseg - 1 && kb >= p.seg[seg].nkb) {
+        while (seg < nseg - 1 && kb >= p.seg[seg].nkb) {
             kb -= p.seg[seg].nkb;
             ++seg;
         }
@@ -568,10 +594,12 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         const SegP& sp = p.seg[s];
         cur_nkb = sp.nkb;
         cur_cpb = sp.cpb;
-        wstep = sp.wkb ? (int64_t)p.N * 128 : 128;
+        const char* wsrc = prod ? p.lora_a[pgi] : sp.w;  // producer: the stacked down rows, always K-blocked
+        const bool wkb = prod || sp.wkb;
+        wstep = wkb ? (int64_t)Nw * 128 : 128;
         woff = (int64_t)kb0 * wstep;
 #pragma unroll
-        for (int it = 0; it < WI; ++it) wbase[it] = sp.w + (sp.wkb ? (int64_t)wnrow[it] * 128 : (int64_t)wnrow[it] * sp.ldwb) + wcoff[it];
+        for (int it = 0; it < WI; ++it) wbase[it] = wsrc + (wkb ? (int64_t)wnrow[it] * 128 : (int64_t)wnrow[it] * sp.ldwb) + wcoff[it];
         if constexpr (CONV) {
             tap = kb0 / sp.cpb;
             cb = kb0 - tap * sp.cpb;
@@ -584,10 +612,9 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         }
     };
     auto advance = [&]() __attribute__((always_inline)) {  // one K block forward; cross into the next tap / segment when this one is exhausted
-        if (seg >= p.nseg) return;
+        if (seg >= nseg) return;
         ++kb;
         woff += wstep;
-        if constexpr (LORA) aoff += LORA_R * 128;
         if constexpr (CONV) {
             if (++cb == cur_cpb) {
                 cb = 0;
@@ -600,7 +627,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         if (kb == cur_nkb) {
             kb = 0;
             ++seg;
-            if (seg < p.nseg) enter(seg, 0);
+            if (seg < nseg) enter(seg, 0);
         }
     };
     enter(seg, kb);
@@ -620,7 +647,6 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         }
 #pragma unroll
         for (int it = 0; it < WI; ++it) glds16(wbase[it] + woff, ws + (it * NTHR + wid * 64) * 16);
-        if constexpr (LORA) glds16(abase + aoff, ws + WBYTES + wid * 64 * 16);
 #pragma unroll
         for (int a = 0; a < KG; ++a) advance();
     };
@@ -649,7 +675,23 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     // drain, guide section 5 "pipelining across barriers") -> issue block t+D into the buffer block t-1 was computed from
     // -> MFMA on block t.  One barrier per K block.
     constexpr int D = NSTAGE - 1;
-    constexpr int LPS = XI + WI + (LORA ? 1 : 0);  // global_load_lds instructions per thread per stage
+    constexpr int LPS = XI + WI;  // global_load_lds instructions per thread per stage
+    if constexpr (LORA) {
+        // the first 32 ranks of this tile's pre-scaled up rows go to LDS now (static weights): by the time the K loop is over they have
+        // long landed.  Issued BEFORE the stages, so every counted vmcnt wait of the loop covers them.
+        if (lora_tail) {
+            constexpr int RB = LORA_RC * (int)sizeof(T), CPRB = RB / 16, BI = BN * CPRB / NTHR;
+            static_assert(BN * CPRB % NTHR == 0, "up-projection tile / thread mismatch");
+#pragma unroll
+            for (int it = 0; it < BI; ++it) {
+                const int q = it * NTHR + tid, row = q / CPRB, ch = q % CPRB;
+                const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
+                int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
+                n = n < p.N ? n : p.N - 1;
+                glds16(p.lora_b + ((int64_t)n * p.lora_r) * (int)sizeof(T) + ch * 16, lora_b0 + (it * NTHR + wid * 64) * 16);
+            }
+        }
+    }
     if constexpr (STAG) {
 #pragma unroll
         for (int s0 = 0; s0 < 2; ++s0)
@@ -722,19 +764,18 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     // machine scheduler otherwise sinks every ds_read to just before its first use and waits lgkmcnt(0) eight times per block).
     auto mainloop = [&](auto trc) {
         constexpr bool TR = decltype(trc)::value;
-        constexpr int RR = MT + NT + (LORA ? 1 : 0);                              // ds_read_b128 per phase
-        constexpr int MM = (MT * NT + (LORA ? MT : 0)) * (sizeof(T) == 4 ? 4 : 1);  // MFMA instructions per phase
-        frag_t xf0[MT], wf0[NT], xf1[MT], wf1[NT], af0 = frag_t{0, 0, 0, 0}, af1 = frag_t{0, 0, 0, 0};
-        auto read_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT], frag_t& af, int blk, int kk) {
+        constexpr int RR = MT + NT;                                // ds_read_b128 per phase
+        constexpr int MM = MT * NT * (sizeof(T) == 4 ? 4 : 1);      // MFMA instructions per phase
+        frag_t xf0[MT], wf0[NT], xf1[MT], wf1[NT];
+        auto read_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT], int blk, int kk) {
             const char* xs = smem_g + (blk % NSTAGE) * STAGE;
             const char* ws = xs + XBYTES;
-            if constexpr (LORA) af = lds_read_frag(ws + WBYTES, tile_off<128>(16 * wn + c16, 4 * kk + g));
 #pragma unroll
             for (int i = 0; i < MT; ++i) xf[i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
 #pragma unroll
             for (int j = 0; j < NT; ++j) wf[j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
         };
-        auto mma_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT], frag_t af) {
+        auto mma_half = [&](frag_t(&xf)[MT], frag_t(&wf)[NT]) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -742,7 +783,6 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                     if constexpr (TR) mma_step<T>(acc[i][j], xf[i], wf[j]);
                     else mma_step<T>(acc[i][j], wf[j], xf[i]);
                 }
-                if constexpr (LORA) mma_step<T>(tacc[i], af, xf[i]);  // t^T tile: rank rows x this wave's activation rows (both orientations)
             }
         };
         auto pin = [&]() {  // the phase's LDS reads go out early, one per MFMA, so that the last one is >= MM - RR MFMAs old at the phase end
@@ -761,12 +801,12 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (D < my_kb) issue(D % NSTAGE);
-        if (my_kb > 0) read_half(xf0, wf0, af0, 0, 0);
+        if (my_kb > 0) read_half(xf0, wf0, 0, 0);
         for (int t = 0; t < max_kb; ++t) {
             const bool active = KG == 1 || t < my_kb;  // the odd group of an odd block count idles through the last trip
             if (active) {  // phase A
-                read_half(xf1, wf1, af1, t, 1);
-                mma_half(xf0, wf0, af0);
+                read_half(xf1, wf1, t, 1);
+                mma_half(xf0, wf0);
                 pin();
             }
             if (t + 1 < max_kb) {
@@ -777,8 +817,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 if (t + 1 + D < my_kb) issue((t + 1 + D) % NSTAGE);
             }
             if (active) {  // phase B
-                read_half(xf0, wf0, af0, t + 1, 0);  // (past the last block: a harmless read of a stale stage; keeps the phase one basic block)
-                mma_half(xf1, wf1, af1);
+                read_half(xf0, wf0, t + 1, 0);  // (past the last block: a harmless read of a stale stage; keeps the phase one basic block)
+                mma_half(xf1, wf1);
                 pin();
             }
         }
@@ -911,6 +951,86 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    if constexpr (LORA) {
+        if (prod) {
+            // ---- LoRA producer: t[m0 .. m0 + BM)[0 .. R) = x A_g^T.  Wave (wm, wn) takes its MT row blocks x rpw = R / (16 WN) rank blocks
+            // (weight rows unpermuted: LDS row r = rank r); same LDS ring and counted waits as the main loop, no register pipelining
+            // (the loop is latency-bound: R / BN of a tile's MFMAs).
+            const int rpw = p.lora_r / (16 * WN);
+            f32x4 ta[MT][LORA_RMAX / (16 * WN)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < LORA_RMAX / (16 * WN); ++j) ta[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (D <= my_kb) wait_vm<(D - 1) * LPS>();
+            else wait_vm0();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (D < my_kb) issue(D % NSTAGE);
+            for (int t = 0; t < my_kb; ++t) {
+                const char* xs = smem_g + (t % NSTAGE) * STAGE;
+                const char* ws = xs + XBYTES;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    frag_t xf[MT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) xf[i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
+#pragma unroll
+                    for (int j = 0; j < LORA_RMAX / (16 * WN); ++j)
+                        if (j < rpw) {  // wave-uniform
+                            const frag_t af = lds_read_frag(ws, tile_off<128>((wn * rpw + j) * 16 + c16, 4 * kk + g));
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) mma_step<T>(ta[i][j], af, xf[i]);  // D[rank 16 j' + 4 g + r][row 16 i + c16]
+                        }
+                }
+                if (t + 1 < my_kb) {
+                    if (t + 1 + D <= my_kb) wait_vm<(D - 1) * LPS>();
+                    else wait_vm0();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (t + 1 + D < my_kb) issue((t + 1 + D) % NSTAGE);
+                }
+            }
+            // epilogue: LayerNorm folded in -> what is published is t / rstd = (x A'^T - mean sA) + cA / rstd, the tile epilogue's
+            // rstd * (acc - mean s) + c then scales the up-projected product back (one rounding of t, as in the reference); rounded to T;
+            // written through to L2 (8-byte agent-scope stores), then the row block's flag
+            char* tg = p.lora_t + (int64_t)pgi * p.M * p.lora_r * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int mrow = wm * WME + 16 * i + c16, m = m0 + mrow;
+                float mean = 0.f, inv = 1.f;
+                if (p.ln_stats) {
+                    mean = rowstat[2 * mrow];
+                    inv = 1.0f / rowstat[2 * mrow + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < LORA_RMAX / (16 * WN); ++j)
+                    if (j < rpw) {
+                        const int r0 = (wn * rpw + j) * 16 + 4 * g;
+                        f32x4 v = ta[i][j];
+                        if (p.ln_stats) {
+                            const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + pgi * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + pgi * p.lora_r + r0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean * sa[e]) + ca[e] * inv;
+                        }
+                        if (m < p.M) {
+                            char* dst = tg + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
+                            if constexpr (sizeof(T) == 4) {
+                                st_agent8(dst, __builtin_bit_cast(uint64_t, f32x2{v[0], v[1]}));
+                                st_agent8(dst + 8, __builtin_bit_cast(uint64_t, f32x2{v[2], v[3]}));
+                            } else {
+                                const bf16x4 b4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                                st_agent8(dst, __builtin_bit_cast(uint64_t, b4));
+                            }
+                        }
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.lora_flags + pgi * p.tiles_m + tm, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     if constexpr (STAG == 2) {
         if constexpr (CONV) {
             stagloop2(std::false_type{});
@@ -933,65 +1053,81 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     }
 
     if constexpr (LORA) {
-        // ---- up-projection: acc += T(t) . (s B_cat)^T, one more K step of LORA_R ranks through LDS -------------------------
-        constexpr int RB = LORA_R * (int)sizeof(T);  // bytes per row of both LDS images (64 / 128)
-        constexpr int CPRB = RB / 16;                // 16-byte chunks per row
-        constexpr int KS = LORA_R / DT<T>::KSTEP;    // MMA steps (bf16: 1, f32: 2)
-        char* tl = smem;                // [BM rows in LDS order][LORA_R] of T
-        char* bl = smem + BM * RB;      // [BN rows in LDS order][LORA_R] of T
-        __syncthreads();                // every wave is done with the stage buffers
-        float lsa[4] = {0.f, 0.f, 0.f, 0.f}, lca[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.ln_stats) {  // x is un-normalised: t = rstd (x A'^T - mean sA) + cA; what goes through LDS is t / rstd, the epilogue's
-                           // rstd * (acc - mean s) + c then scales the up-projected product back (one rounding of t, as in the reference)
-            const int gi = (p.lora_groups > 1 && n0 >= p.lora_nb[1] ? 1 : 0) + (p.lora_groups > 2 && n0 >= p.lora_nb[2] ? 1 : 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                lsa[e] = p.lora_ls[gi * LORA_R + 16 * wn + 4 * g + e];
-                lca[e] = p.lora_lc[gi * LORA_R + 16 * wn + 4 * g + e];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {  // lane holds t[LDS row wm*WME + 16 i + c16][rank 16 wn + 4 g + 0..3]
-            if (p.ln_stats) {
-                const int R = wm * WME + 16 * i + c16, rl = R % WME;
-                const int row = tr ? (R - rl) + 4 * MT * ((rl >> 2) & 3) + 4 * (rl >> 4) + (rl & 3) : R;  // tile row in m order (rowstat's index)
-                const float mean = rowstat[2 * row], inv = 1.0f / rowstat[2 * row + 1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tacc[i][e] = (tacc[i][e] - mean * lsa[e]) + lca[e] * inv;
-            }
-            char* dst = tl + (wm * WME + 16 * i + c16) * RB + (16 * wn + 4 * g) * (int)sizeof(T);
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<f32x4*>(dst) = tacc[i];
-            } else {
-                bf16x4 v = {(bf16_t)tacc[i][0], (bf16_t)tacc[i][1], (bf16_t)tacc[i][2], (bf16_t)tacc[i][3]};
-                *reinterpret_cast<bf16x4*>(dst) = v;
-            }
-        }
-        constexpr int BI = BN * CPRB / NTHR;
-        static_assert(BN * CPRB % NTHR == 0, "up-projection tile / thread mismatch");
-#pragma unroll
-        for (int it = 0; it < BI; ++it) {
-            const int q = it * NTHR + tid, row = q / CPRB, ch = q % CPRB;
-            const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
-            int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
-            n = n < p.N ? n : p.N - 1;
-            *reinterpret_cast<frag_t*>(bl + row * RB + ch * 16) = *reinterpret_cast<const frag_t*>(p.lora_b + (int64_t)n * RB + ch * 16);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            frag_t tf[MT], bf[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) tf[i] = lds_read_frag(tl, (wm * WME + 16 * i + c16) * RB + (4 * ks + g) * 16);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = lds_read_frag(bl, (wn * WNE + 16 * j + c16) * RB + (4 * ks + g) * 16);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (tr) mma_step<T>(acc[i][j], tf[i], bf[j]);
-                    else mma_step<T>(acc[i][j], bf[j], tf[i]);
+        // ---- up-projection: acc += T(t) . (s B_cat)^T, 32 ranks per step through LDS; t comes from this row block's producer -------------
+        if (lora_tail) {
+            constexpr int RB = LORA_RC * (int)sizeof(T);  // bytes per row of both LDS images (64 / 128)
+            constexpr int CPRB = RB / 16;                 // 16-byte chunks per row
+            constexpr int KS = LORA_RC / DT<T>::KSTEP;    // MMA steps per chunk (bf16: 1, f32: 2)
+            constexpr int TI = BM * CPRB / NTHR, BI = BN * CPRB / NTHR;
+            static_assert(BM * CPRB % NTHR == 0, "t tile / thread mismatch");
+            char* tl = smem;             // [BM rows in LDS order][32 ranks] of T
+            char* bl = smem + BM * RB;   // [BN rows in LDS order][32 ranks] of T: chunks after the first (the first sits in lora_b0)
+            const int nch = p.lora_r / LORA_RC;
+            const char* tg = p.lora_t + (int64_t)lgi * p.M * p.lora_r * (int)sizeof(T);
+            if (tid == 0) {  // the producer finished long ago unless the whole launch is one wave of tiles; bounded by the wall clock
+                const int* fp = p.lora_flags + lgi * p.tiles_m + tm;
+                const uint64_t t0 = wall_clock64();
+                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lora_tag) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > 200000000ull) __builtin_trap();  // 2 s of the 100 MHz clock: a lost producer must not hang the GPU
                 }
+            }
+            __syncthreads();  // every wave is done with the stage buffers; the flag has been seen
+            for (int c = 0; c < nch; ++c) {
+                if (c) __syncthreads();  // the previous chunk's fragments have been read
+                uint64_t tv[TI][2];
+#pragma unroll
+                for (int it = 0; it < TI; ++it) {  // L1-bypassing loads: this CU may hold stale lines of the scratch from an earlier launch
+                    const int q = it * NTHR + tid, row = q / CPRB, ch = q % CPRB;
+                    int mr = row;
+                    if (tr) {
+                        const int rl = row % WME;
+                        mr = (row - rl) + 4 * MT * ((rl >> 2) & 3) + 4 * (rl >> 4) + (rl & 3);
+                    }
+                    const int m = min(m0 + mr, p.M - 1);
+                    const char* src = tg + ((int64_t)m * p.lora_r + c * LORA_RC) * (int)sizeof(T) + ch * 16;
+                    tv[it][0] = ld_agent8(src);
+                    tv[it][1] = ld_agent8(src + 8);
+                }
+                frag_t bv[BI];
+                if (c) {
+#pragma unroll
+                    for (int it = 0; it < BI; ++it) {
+                        const int q = it * NTHR + tid, row = q / CPRB, ch = q % CPRB;
+                        const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
+                        int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
+                        n = n < p.N ? n : p.N - 1;
+                        bv[it] = *reinterpret_cast<const frag_t*>(p.lora_b + ((int64_t)n * p.lora_r + c * LORA_RC) * (int)sizeof(T) + ch * 16);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < TI; ++it) {
+                    const int q = it * NTHR + tid;
+                    *reinterpret_cast<uint64_t*>(tl + q * 16) = tv[it][0];
+                    *reinterpret_cast<uint64_t*>(tl + q * 16 + 8) = tv[it][1];
+                }
+                if (c) {
+#pragma unroll
+                    for (int it = 0; it < BI; ++it) *reinterpret_cast<frag_t*>(bl + (it * NTHR + tid) * 16) = bv[it];
+                }
+                __syncthreads();
+                const char* bs = c ? bl : lora_b0;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    frag_t tf[MT], bf[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) tf[i] = lds_read_frag(tl, (wm * WME + 16 * i + c16) * RB + (4 * ks + g) * 16);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bf[j] = lds_read_frag(bs, (wn * WNE + 16 * j + c16) * RB + (4 * ks + g) * 16);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            if (tr) mma_step<T>(acc[i][j], tf[i], bf[j]);
+                            else mma_step<T>(acc[i][j], bf[j], tf[i]);
+                        }
+                }
+            }
         }
     }
 
@@ -1292,15 +1428,17 @@ extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS 
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
-    constexpr int LDS0 = KG * NSTAGE * ((BM + BN) * 128 + (LORA ? LORA_R * 128 : 0)) + BM * 8;
+    constexpr int LDS0 = KG * NSTAGE * (BM + BN) * 128 + BM * 8 + (LORA ? BN * LORA_RC * (int)sizeof(T) : 0);
     constexpr int LDS = XATT && 2 * xa_head_bytes<T>() > LDS0 ? 2 * xa_head_bytes<T>() : LDS0;  // the epilogue's K / V^T of two heads reuse the ring
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(KG == 1 || (BM / WM / 16) * (BN / WN / 16) * WM * WN * 1024 <= KG * NSTAGE * (BM + BN) * 128, "partial-tile exchange must fit the stage buffers");
     auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG, LORA, STAG, XATT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the device's copy of the code object
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     GemmP q = p;
     q.tiles_n = (p.N + BN - 1) / BN;
@@ -1342,9 +1480,10 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     q.pf_blocks = (q.pf_blocks + 7) / 8 * 8;  // a multiple of 8: compute block b still lands on XCD b % 8
     if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
     q.pf_mode = g_pf_mode;
-    const int grid = q.pf_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
+    q.lp_blocks = LORA ? (q.tiles_m * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
+    const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), (q.ln_stats || XATT) ? LDS : LDS - BM * 8, stream, q);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), (q.ln_stats || XATT || LORA) ? LDS : LDS - BM * 8, stream, q);
     if (q.ksplit > 1) {
         const int64_t work = (int64_t)q.M * ((q.N + 3) / 4);
         int64_t rb = (work + 255) / 256;
@@ -1392,7 +1531,12 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
     const int st = pick_stages(p);
     if constexpr (!CONV) {
         if (p.xa.nstream) return launch_cfg<T, 128, 128, 2, 2, false, 2, 1, false, 0, true>(p, stream);  // cross-attention epilogue: the tile that holds 128 queries x 2 heads
-        if (p.lora_b) {  // in-launch LoRA: the 4-wave tiles, two LDS stages
+    }
+    if (p.lora_b) {  // in-launch LoRA: the 4-wave tiles, two LDS stages; a stacked rank above 64 needs the 128-column tiles (the producers stage R weight rows)
+        if (p.lora_r > 64 && (tile == 2 || tile == 4)) tile = tile == 2 ? 1 : 3;
+        if constexpr (CONV) {
+            return tile == 1 ? launch_cfg<T, 128, 128, 2, 2, true, 2, 1, true>(p, stream) : launch_cfg<T, 64, 128, 2, 2, true, 2, 1, true>(p, stream);
+        } else {
             switch (tile) {
                 case 2: return launch_cfg<T, 128, 64, 2, 2, false, 2, 1, true>(p, stream);
                 case 3: return launch_cfg<T, 64, 128, 2, 2, false, 2, 1, true>(p, stream);

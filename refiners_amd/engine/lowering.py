@@ -100,8 +100,12 @@ class LoraPack:
     a_cat: Tensor  # [rpad, K(...)] stacked down weights, zero padded rows
     bs_cat: Tensor  # [N, rpad] stacked (scale * up) columns
     conv: Optional[tuple[int, int, int]] = None  # (down ksize, up ksize, stride) for Conv2dLora
-    a32: Any = None  # native.KBlocked of the first 32 rows of a_cat, when the stacked rank fits the in-launch path
-    bs32: Optional[Tensor] = None  # [N, 32]
+    a_kb: Any = None  # native.KBlocked of the first R rows of a_cat (R = stacked rank rounded up to 32), when R fits the in-launch path (<= 128)
+    bs_r: Optional[Tensor] = None  # [N, R]: for a Conv2dLora with a 1x1 up convolution, the up weights as a matrix
+
+    @property
+    def R(self) -> int:
+        return 0 if self.bs_r is None else int(self.bs_r.shape[1])
 
 
 @dataclass
@@ -238,9 +242,11 @@ class Lowering:
         # them off (A/B runs; the unfused kernels stay in the library)
         self.ln_fuse = os.environ.get("REFINERS_AMD_LN_FUSE", "1") != "0"
         self.qkv_merge = os.environ.get("REFINERS_AMD_QKV_MERGE", "1") != "0"
-        # lora_mode="fused": the LoRA down / up projections run INSIDE the parent GEMM's launch (stacked rank <= 32); 0 = the older
-        # skinny-GEMM + extra-K-segment pair of launches
+        # lora_mode="fused": the LoRA down / up projections run INSIDE the parent GEMM's / conv's launch (stacked rank <= 128: producer
+        # workgroups at the head of the grid, see gemm_kernel.cuh); 0 = the older skinny-GEMM + extra-K-segment pair of launches
         self.lora_inlaunch = os.environ.get("REFINERS_AMD_LORA_INLAUNCH", "1") != "0"
+        self._lsync: Any = None          # native.LoraSync: the epoch word every program of this lowering bumps once per replay
+        self._bumped: set[int] = set()   # id() of the op lists that already start with the bump
         # extra elements per row of a self-attention's V^T buffer [C][B L (+ pad)]: with a row stride of exactly B L elements (4 / 16 KB at 1024 / 4096
         # tokens) the 64 rows of a V^T tile sit a power of two apart in memory
         self.vt_pad = int(os.environ.get("REFINERS_AMD_VT_PAD", "0"))
@@ -334,9 +340,14 @@ class Lowering:
             if row_perm is not None:
                 bs = bs[row_perm].contiguous()
             pack = LoraPack(a, bs)
-            if rt <= native.LORA_R and self.device.type != "meta":  # fits mi355x_gemm's in-launch LoRA: ONE kernel per adapted Linear
-                pack.a32 = native.KBlocked(a[: native.LORA_R].contiguous())
-                pack.bs32 = bs[:, : native.LORA_R].contiguous()
+            R = (rt + native.LORA_R - 1) // native.LORA_R * native.LORA_R
+            if R <= native.LORA_RMAX and self.device.type != "meta":  # fits mi355x_gemm's in-launch LoRA: ONE kernel per adapted Linear
+                ar = torch.zeros(R, k_in, device=self.device, dtype=self.dtype)
+                ar[: min(R, rpad)] = a[: min(R, rpad)]
+                br = torch.zeros(n_out, R, device=self.device, dtype=self.dtype)
+                br[:, : min(R, rpad)] = bs[:, : min(R, rpad)]
+                pack.a_kb = native.KBlocked(ar)
+                pack.bs_r = br
             return pack
 
         self.stats["lora_sites"] += 1
@@ -445,13 +456,33 @@ class Lowering:
                     a[off : off + r] = native.pack_conv_weight(d.weight.detach().to(device=self.device, dtype=self.dtype))
                     bs4[:, off : off + r] = u.weight.detach().to(device=self.device, dtype=torch.float32) * s
                     off += r
-                return LoraPack(a, native.pack_conv_weight(bs4.to(self.dtype)), conv=(kd, ku, leaf.stride[0]))
+                pack = LoraPack(a, native.pack_conv_weight(bs4.to(self.dtype)), conv=(kd, ku, leaf.stride[0]))
+                R = (rt + native.LORA_R - 1) // native.LORA_R * native.LORA_R
+                if ku == 1 and kd == kh and R <= native.LORA_RMAX and self.device.type != "meta" and all(_pad2(d) == _pad2(leaf) for d in downs):
+                    # Conv2dLora inside the parent conv's launch: down conv = the parent's kernel size / stride / padding, 1x1 up conv
+                    ar = torch.zeros(R, kd * kd * i, device=self.device, dtype=self.dtype)
+                    ar[: min(R, rpad)] = a[: min(R, rpad)]
+                    br = torch.zeros(o, R, device=self.device, dtype=self.dtype)
+                    br[:, : min(R, rpad)] = bs4[:, : min(R, rpad), 0, 0].to(self.dtype)
+                    pack.a_kb = native.KBlocked(ar)
+                    pack.bs_r = br
+                return pack
 
             lora = self.cache.get(key, make)
             self.stats["lora_sites"] += 1
         return ConvSpec(wp, self._w(leaf.bias), i, o, kh, leaf.stride[0], lora, time, asym)
 
     # -- emitters: GEMM family -------------------------------------------------------------------------------
+    def lora_sync(self, groups: int, M: int, R: int) -> tuple:
+        """(t scratch, flags, LoraSync) of one in-launch LoRA site (native._lora_fill); the first site of a program puts the epoch bump at
+        the program's head.  The scratch comes from the pool (give it back with pool.put once the launch is recorded); flags are the site's own."""
+        if self._lsync is None:
+            self._lsync = native.LoraSync(self.device)
+        if id(self._target) not in self._bumped:
+            self._target.insert(0, self._lsync.bump_op())
+            self._bumped.add(id(self._target))
+        return self.pool.get(groups * M, R), self._lsync.flags(groups, M), self._lsync
+
     def lora_down(self, x: Tensor, lora: LoraPack) -> Tensor:
         t = self.pool.get(x.shape[0], lora.a_cat.shape[0])
         native.gemm([(x, lora.a_cat)], t)
@@ -479,17 +510,22 @@ class Lowering:
         if ln is not None:
             stats, node = ln
             wl, ls, lc = self.ln_fold(spec, node)
-            lo = None
+            lo = sy = None
             if spec.lora is not None:  # LayerNorm AND the LoRAs inside the parent launch
                 al, als, alc = self.ln_fold_lora(spec.lora, node)
-                lo = ([(0, al)], spec.lora.bs32, als, alc)
+                lo = ([(0, al)], spec.lora.bs_r, als, alc)
+                sy = self.lora_sync(1, M, spec.lora.R)
             native.gemm([(x, self.kblocked(wl))], out, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, ln=(stats, ls, lc, float(node.eps)),
-                        stats_out=stats_out, lora=lo)
+                        stats_out=stats_out, lora=lo, lora_sync=sy)
+            if sy is not None:
+                self.pool.put(sy[0])
             return out
-        if spec.lora is not None and spec.lora.a32 is not None and self.lora_inlaunch and not isinstance(x, native.KBlocked):
-            # LoraAdapter = Sum(target, loras) as ONE launch: x A_cat^T rides in the parent's K loop, the up-projections are its last K step
+        if spec.lora is not None and spec.lora.a_kb is not None and self.lora_inlaunch:
+            # LoraAdapter = Sum(target, loras) as ONE launch: producer workgroups compute x A_cat^T once per row block, the up-projections are the tiles' last K steps
+            sy = self.lora_sync(1, M, spec.lora.R)
             native.gemm([(x, self.kblocked(spec.w))], out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, stats_out=stats_out,
-                        lora=([(0, spec.lora.a32)], spec.lora.bs32))
+                        lora=([(0, spec.lora.a_kb)], spec.lora.bs_r), lora_sync=sy)
+            self.pool.put(sy[0])
             return out
         segs = [(x, self.kblocked(spec.w))]
         t = None
@@ -525,12 +561,12 @@ class Lowering:
 
     def ln_fusable(self, stats: Optional[Tensor], *specs: LinSpec) -> bool:
         """LayerNorm can ride in the consumer launch when every consumer is a plain Linear or carries its LoRAs in-launch."""
-        ok_lora = lambda sp: sp.lora is None or (sp.lora.a32 is not None and self.lora_inlaunch)  # noqa: E731
+        ok_lora = lambda sp: sp.lora is None or (sp.lora.a_kb is not None and self.lora_inlaunch)  # noqa: E731
         return (stats is not None and self.ln_fuse and self.device.type != "meta" and all(ok_lora(sp) and sp.N % 64 == 0 and sp.K % 64 == 0 for sp in specs))
 
     def ln_fold_lora(self, lora: LoraPack, node: Any) -> tuple[Any, Tensor, Tensor]:
-        """(A' K-blocked, sA [32], cA [32]) of the stacked down-projections behind a folded LayerNorm (see ln_fold)."""
-        a = lora.a32.dense()
+        """(A' K-blocked, sA [R], cA [R]) of the stacked down-projections behind a folded LayerNorm (see ln_fold)."""
+        a = lora.a_kb.dense()
         key = ("ln_fold_lora",) + PackCache.ident(lora.a_cat, node.weight, node.bias)
 
         def make() -> tuple[Any, Tensor, Tensor]:
@@ -556,8 +592,10 @@ class Lowering:
     def linear_T(self, x: Tensor, spec: LinSpec, out_t: Tensor) -> Tensor:
         """out_t[N, M] = W x^T (+ LoRA): the V^T layout mi355x_attention consumes (operands swapped, no bias)."""
         _expect(spec.b is None, "transposed projection with bias is not supported")
-        if spec.lora is not None and spec.lora.a32 is not None and self.lora_inlaunch and out_t.stride(1) == 1:
-            native.gemm([(x, self.kblocked(spec.w))], None, out_t=out_t, nt_begin=0, lora=([(0, spec.lora.a32)], spec.lora.bs32))
+        if spec.lora is not None and spec.lora.a_kb is not None and self.lora_inlaunch and out_t.stride(1) == 1:
+            sy = self.lora_sync(1, x.shape[0], spec.lora.R)
+            native.gemm([(x, self.kblocked(spec.w))], None, out_t=out_t, nt_begin=0, lora=([(0, spec.lora.a_kb)], spec.lora.bs_r), lora_sync=sy)
+            self.pool.put(sy[0])
             return out_t
         segs = [(self.kblocked(spec.w), x)]
         t = None
@@ -578,7 +616,10 @@ class Lowering:
         out = self.pool.get(a.B * OH * OW, spec.cout)
         segs = [(a.image(), self.kblocked(spec.w), spec.ksize, spec.stride, ups, int(spec.asym))]
         t = None
-        if spec.lora is not None:
+        lo = sy = None
+        if spec.lora is not None and spec.lora.a_kb is not None and self.lora_inlaunch:
+            lo = ([(0, spec.lora.a_kb)], spec.lora.bs_r)  # Conv2dLora inside this launch
+        elif spec.lora is not None:
             kd, ku, st = spec.lora.conv  # type: ignore[misc]
             t = self.pool.get(a.B * OH * OW, spec.lora.a_cat.shape[0])
             native.conv_gemm([(a.image(), spec.lora.a_cat, kd, st, ups, int(spec.asym))], t, a.B, OH, OW)
@@ -599,7 +640,11 @@ class Lowering:
         if tiles128 <= 192 and total_kb >= 96:
             tile, ksplit = 1, 3
             ws = self.splitk_workspace(ksplit * M_out * spec.cout)
-        native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res, tile=tile, ksplit=ksplit, ws=ws)
+        if lo is not None:
+            sy = self.lora_sync(1, M_out, spec.lora.R)
+        native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res, tile=tile, ksplit=ksplit, ws=ws, lora=lo, lora_sync=sy)
+        if sy is not None:
+            self.pool.put(sy[0])
         self.pool.put(t)
         return Act(out, a.B, OH, OW)
 
@@ -774,7 +819,7 @@ class Lowering:
         lnarg = (stats, ln) if fold else None
         h = x if fold else self.layernorm(x, ln)
         no_lora = qs.lora is None and ks.lora is None and vs.lora is None
-        all_inlaunch = self.lora_inlaunch and all(sp.lora is not None and sp.lora.a32 is not None for sp in (qs, ks, vs))
+        all_inlaunch = self.lora_inlaunch and all(sp.lora is not None and sp.lora.a_kb is not None for sp in (qs, ks, vs)) and len({sp.lora.R for sp in (qs, ks, vs)}) == 1
         qk = q = k = vt = vt_full = None
         if (no_lora or all_inlaunch) and native_path and self.qkv_merge and L % 64 == 0 and C % 128 == 0 and self.device.type != "meta":
             # ONE launch for the three projections: [Wq; Wk; Wv] stacked, Q | K row-major, V stored transposed
@@ -784,18 +829,23 @@ class Lowering:
             vt = vt_full[:, :M] if self.vt_pad else vt_full
             if fold:
                 wl, ls, lc = self.ln_fold(wqkv, ln)
-                lo = None
+                lo = sy = None
                 if not no_lora:
                     packs = [self.ln_fold_lora(sp.lora, ln) for sp in (qs, ks, vs)]
-                    bs = self.cache.get(("qkv_bs",) + PackCache.ident(qs.lora.bs32, ks.lora.bs32, vs.lora.bs32), lambda: torch.cat([qs.lora.bs32, ks.lora.bs32, vs.lora.bs32], 0).contiguous())
+                    bs = self.cache.get(("qkv_bs",) + PackCache.ident(qs.lora.bs_r, ks.lora.bs_r, vs.lora.bs_r), lambda: torch.cat([qs.lora.bs_r, ks.lora.bs_r, vs.lora.bs_r], 0).contiguous())
+                    sy = self.lora_sync(3, M, qs.lora.R)
                     lsc = self.cache.get(("qkv_lsc",) + PackCache.ident(*[t for pk in packs for t in pk[1:]]), lambda: (torch.cat([pk[1] for pk in packs]).contiguous(), torch.cat([pk[2] for pk in packs]).contiguous()))
                     lo = ([(0, packs[0][0]), (C, packs[1][0]), (2 * C, packs[2][0])], bs, lsc[0], lsc[1])
-                native.gemm([(h, self.kblocked(wl))], qk, out_t=vt, nt_begin=2 * C, ln=(stats, ls, lc, float(ln.eps)), lora=lo)
+                native.gemm([(h, self.kblocked(wl))], qk, out_t=vt, nt_begin=2 * C, ln=(stats, ls, lc, float(ln.eps)), lora=lo, lora_sync=sy)
+                if sy is not None:
+                    self.pool.put(sy[0])
             elif no_lora:
                 native.gemm([(h, self.kblocked(wqkv.w))], qk, out_t=vt, nt_begin=2 * C)
             else:  # three LoRA sets in one launch: a stacked-down block per column group, the up rows stacked like the weights
-                bs = self.cache.get(("qkv_bs",) + PackCache.ident(qs.lora.bs32, ks.lora.bs32, vs.lora.bs32), lambda: torch.cat([qs.lora.bs32, ks.lora.bs32, vs.lora.bs32], 0).contiguous())
-                native.gemm([(h, self.kblocked(wqkv.w))], qk, out_t=vt, nt_begin=2 * C, lora=([(0, qs.lora.a32), (C, ks.lora.a32), (2 * C, vs.lora.a32)], bs))
+                bs = self.cache.get(("qkv_bs",) + PackCache.ident(qs.lora.bs_r, ks.lora.bs_r, vs.lora.bs_r), lambda: torch.cat([qs.lora.bs_r, ks.lora.bs_r, vs.lora.bs_r], 0).contiguous())
+                sy = self.lora_sync(3, M, qs.lora.R)
+                native.gemm([(h, self.kblocked(wqkv.w))], qk, out_t=vt, nt_begin=2 * C, lora=([(0, qs.lora.a_kb), (C, ks.lora.a_kb), (2 * C, vs.lora.a_kb)], bs), lora_sync=sy)
+                self.pool.put(sy[0])
             q, k = qk[:, :C], qk[:, C:]
         else:
             # The V^T projection and the packed Q|K projection read the same h and do not depend on each other; neither fills the
@@ -933,7 +983,8 @@ class Lowering:
         s1, s2 = self.linear_spec(w1, geglu=True), self.linear_spec(w2)
         # the intermediate [M, 4C] has 10 KB rows at C = 1280: the second GEMM would stream it at half rate, so the GEGLU epilogue
         # stores it K-blocked (same bytes, [column block][M][128 B]) whenever the kernel's vector store path applies
-        blocked = self.kblock_policy > 0 and s1.lora is None and s2.lora is None and s1.N % 256 == 0 and self.device.type != "meta"
+        inl = lambda sp: sp.lora is None or (sp.lora.a_kb is not None and self.lora_inlaunch)  # noqa: E731  (the two-launch LoRA path reads x row-major)
+        blocked = self.kblock_policy > 0 and inl(s1) and inl(s2) and s1.N % 256 == 0 and self.device.type != "meta"
         if self.ln_fusable(stats, s1):
             ff = self.linear(x, s1, out_kblocked=blocked, ln=(stats, ln))
         else:

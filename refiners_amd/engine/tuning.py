@@ -32,6 +32,10 @@ def lookup(signature: str, stages: int = 0) -> tuple[int, int]:
     """(tile, stages) for a launch whose caller did not choose: the table's entry, else (0, stages) = library heuristic."""
     if enabled:
         got = table().get(signature)
+        if got is None and signature.endswith("lora"):  # the LoRA producers leave the tiles' K loop untouched: same choice as the un-adapted launch
+            got = table().get(signature[: -len("lora")])
+            if got is not None and (got[0] > 4 or got[1] != 2):  # the LoRA kernels exist for the 4-wave tiles with two LDS stages
+                got = (got[0] if got[0] <= 4 else 1, 2)
         if got is not None:
             return int(got[0]), int(got[1])
     return 0, stages

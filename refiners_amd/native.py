@@ -90,7 +90,8 @@ class KBlocked:
 
 
 MAX_PREFETCH = 2  # == MI355X_MAX_PREFETCH
-LORA_R = 32  # stacked LoRA rank mi355x_gemm handles inside the parent launch (gemm_kernel.cuh)
+LORA_R = 32  # granularity of the stacked LoRA rank mi355x_gemm handles inside the parent launch (gemm_kernel.cuh: LORA_RC)
+LORA_RMAX = 128  # largest stacked rank (LORA_RMAX there)
 
 
 class GemmArgs(C.Structure):
@@ -136,9 +137,13 @@ class GemmArgs(C.Structure):
         ("lora_a", C.c_void_p * 3),
         ("lora_nb", C.c_int32 * 3),
         ("lora_groups", C.c_int32),
+        ("lora_r", C.c_int32),
         ("lora_b", C.c_void_p),
         ("lora_ls", C.c_void_p),
         ("lora_lc", C.c_void_p),
+        ("lora_t", C.c_void_p),
+        ("lora_flags", C.c_void_p),
+        ("lora_epoch", C.c_void_p),
         ("xattn_kv", C.c_void_p),
         ("xattn_nstream", C.c_int32),
         ("xattn_lq", C.c_int32),
@@ -244,6 +249,7 @@ EXPORTS = [
     "mi355x_abi_version",
     "mi355x_device_info",
     "mi355x_gemm",
+    "mi355x_epoch_bump",
     "mi355x_attention",
     "mi355x_attention_general",
     "mi355x_layernorm",
@@ -288,6 +294,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_abi_version.restype = C.c_int
     lib.mi355x_device_info.argtypes = [C.c_char_p, C.c_int32]
     lib.mi355x_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+    lib.mi355x_epoch_bump.argtypes = [C.c_void_p, C.c_void_p]
     lib.mi355x_attention.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
     lib.mi355x_attention_general.argtypes = [C.POINTER(AttnGeneralArgs), C.c_void_p]
     lib.mi355x_layernorm.argtypes = [C.POINTER(LayerNormArgs), C.c_void_p]
@@ -315,7 +322,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_groupnorm_set_fused.argtypes = [C.c_int, C.c_int64]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
-    if lib.mi355x_abi_version() != 4:
+    if lib.mi355x_abi_version() != 5:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
     import os
@@ -521,6 +528,64 @@ def pack_conv_weight(w: Tensor) -> Tensor:
     return w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous()
 
 
+# ------------------------------------------------------------------------------------------------ in-launch LoRA hand-off state
+class LoraSync:
+    """Device-side state of mi355x_gemm's in-launch LoRA (include/mi355x_refiners.h: lora_t / lora_flags / lora_epoch): the epoch word that
+    a recorded program bumps once per replay (`bump_op()` goes to the head of the program), per-site flag arrays (zeroed, never shared
+    between launches of one replay) and scratch for t = x A^T, which consecutive launches may share (stream order)."""
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
+        self.keep: list = []
+
+    def flags(self, groups: int, M: int) -> Tensor:
+        f = torch.zeros(groups * ((M + 63) // 64), dtype=torch.int32, device=self.device)
+        self.keep.append(f)
+        return f
+
+    def scratch(self, groups: int, M: int, r: int, dtype: torch.dtype) -> Tensor:
+        return torch.empty(groups * M * r, dtype=dtype, device=self.device)
+
+    def bump_op(self) -> tuple:
+        return (getattr(load(), "mi355x_epoch_bump"), (self.epoch.data_ptr(),), "mi355x_epoch_bump", (self,))
+
+    def bump(self) -> None:
+        check(load().mi355x_epoch_bump(self.epoch.data_ptr(), stream_ptr()), "mi355x_epoch_bump")
+
+
+_eager_sync: dict[int, "LoraSync"] = {}
+
+
+def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: int, keep: list, sync: Optional[tuple]) -> None:
+    """lora = ([(first column of the group, K-blocked stacked down rows [R, K])], pre-scaled up rows [N, R] (, sA, cA float32 [groups, R])).
+    sync = (t scratch, flags, LoraSync) from the engine; None (eager calls: tests, probes) = fresh buffers and an epoch bump per call."""
+    groups, lb = lora[0], lora[1]
+    R = lb.shape[1]
+    assert 1 <= len(groups) <= 3 and lb.dim() == 2 and lb.shape[0] == a.N and R % LORA_R == 0 and LORA_R <= R <= LORA_RMAX and lb.is_contiguous() and lb.dtype == dtype
+    for g, (nb, la) in enumerate(groups):
+        assert isinstance(la, KBlocked) and la.shape == (R, K) and la.dtype == dtype, (la.shape, R, K)
+        a.lora_a[g], a.lora_nb[g] = la.data_ptr(), nb
+    a.lora_groups, a.lora_r, a.lora_b = len(groups), R, lb.data_ptr()
+    if len(lora) > 2:  # LayerNorm folded into this launch as well
+        ls_, lc_ = lora[2], lora[3]
+        assert ln_given and ls_.dtype == torch.float32 and lc_.dtype == torch.float32 and ls_.is_contiguous() and lc_.is_contiguous()
+        assert ls_.numel() == len(groups) * R and lc_.numel() == len(groups) * R
+        a.lora_ls, a.lora_lc = ls_.data_ptr(), lc_.data_ptr()
+    if sync is None:
+        assert _recorder is None, "a recorded program passes its own LoRA hand-off buffers (Lowering.lora_sync)"
+        dev = lb.device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        ls = _eager_sync.setdefault(idx, LoraSync(dev))
+        ls.keep.clear()
+        ls.bump()
+        sync = (ls.scratch(len(groups), a.M, R, dtype), ls.flags(len(groups), a.M), ls)
+    t, flags, ls = sync
+    assert t.numel() >= len(groups) * a.M * R and t.dtype == dtype and flags.numel() >= len(groups) * ((a.M + 63) // 64) and flags.dtype == torch.int32
+    a.lora_t, a.lora_flags, a.lora_epoch = t.data_ptr(), flags.data_ptr(), ls.epoch.data_ptr()
+    keep.append((lora, t, flags, ls))
+
+
 # ------------------------------------------------------------------------------------------------ call wrappers
 def _seg_plain(x: Any, w: Any) -> tuple:
     """(x, ldx, w, ldw, k, kblocked flags) of one plain K segment; either operand may be a KBlocked weight."""
@@ -558,6 +623,7 @@ def gemm(
     stats_out: Optional[Tensor] = None,
     out_f32: bool = False,
     lora: Optional[tuple[Sequence[tuple[int, "KBlocked"]], Tensor]] = None,
+    lora_sync: Optional[tuple] = None,
     xattn: Optional[tuple[Sequence[tuple[Tensor, Tensor, int, float]], int, Optional[float]]] = None,
 ) -> Optional[Tensor]:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
@@ -599,19 +665,8 @@ def gemm(
     if out_f32:
         assert out is not None and out.dtype == torch.float32
         a.out_f32 = 1
-    if lora is not None:  # ([(first column of the group, K-blocked stacked down rows [32, K])], pre-scaled up rows [N, 32]): LoRA inside this launch
-        groups, lb = lora[0], lora[1]
-        assert 1 <= len(groups) <= 3 and lb.dim() == 2 and lb.shape == (a.N, LORA_R) and lb.is_contiguous() and lb.dtype == x0.dtype
-        for g, (nb, la) in enumerate(groups):
-            assert isinstance(la, KBlocked) and la.shape == (LORA_R, tuple(x0.shape)[1]) and la.dtype == x0.dtype
-            a.lora_a[g], a.lora_nb[g] = la.data_ptr(), nb
-        a.lora_groups, a.lora_b = len(groups), lb.data_ptr()
-        if len(lora) > 2:  # (.., sA [groups, 32], cA [groups, 32]) float32: LayerNorm folded into this launch as well
-            ls_, lc_ = lora[2], lora[3]
-            assert ln is not None and ls_.dtype == torch.float32 and lc_.dtype == torch.float32 and ls_.is_contiguous() and lc_.is_contiguous()
-            assert ls_.numel() == len(groups) * LORA_R and lc_.numel() == len(groups) * LORA_R
-            a.lora_ls, a.lora_lc = ls_.data_ptr(), lc_.data_ptr()
-        keep.append(lora)
+    if lora is not None:  # LoRA inside this launch (see _lora_fill)
+        _lora_fill(a, lora, ln is not None, x0.dtype, tuple(x0.shape)[1], keep, lora_sync)
     if ln is not None:
         stats, ls, lc, eps = ln
         assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 3 and stats.shape[1] == a.M and stats.shape[2] == 2
@@ -654,11 +709,14 @@ def conv_gemm(
     ksplit: int = 1,
     ws: Optional[Tensor] = None,
     stages: int = 0,
+    lora: Optional[tuple] = None,
+    lora_sync: Optional[tuple] = None,
 ) -> Tensor:
     """Implicit-GEMM convolution over NHWC images.
 
     segs: (image [B,H,W,C] NHWC-contiguous or channel-sliced view, packed weight [N, ksize*ksize*C], ksize, stride, ups).
     out: [B*OH*OW, N] rows (i.e. NHWC output).
+    lora = ([(0, K-blocked packed down-conv weights [R, ksize*ksize*C])], pre-scaled 1x1 up weights [N, R]): Conv2dLora on segment 0 inside this launch.
     """
     a = GemmArgs()
     img0, w0 = segs[0][0], segs[0][1]
@@ -681,8 +739,11 @@ def conv_gemm(
         sg.kblocked = 1 if isinstance(w, KBlocked) else 0
     a.zeros = zero_page(img0.device).data_ptr()
     _fill_epilogue(a, out, bias, rowbias, rows_per_group, res, False)
+    keep: list = []
+    if lora is not None:
+        _lora_fill(a, lora, False, img0.dtype, tuple(w0.shape)[1], keep, lora_sync)
     _fill_split(a, tile, ksplit, ws, stages)
-    _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm(conv)")
+    _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm(conv)", keep=tuple(keep))
     return out
 
 

@@ -686,28 +686,30 @@ def softmax_rows_case(M, L, Lp, dtype, seed=255):
 
 
 def _lora_pack(K, N, dtype, ranks, seed, perm=None):
-    """(A32 K-blocked, sB [N, 32], dense reference delta [N, K] float32) of stacked LoRAs with scales 1.0, 0.8, ..."""
+    """(A K-blocked [R, K], sB [N, R], dense reference delta [N, K] float32) of stacked LoRAs with scales 1.0, 0.8, ...; R = the stacked
+    rank rounded up to 32."""
     rt = sum(ranks)
-    a = torch.zeros(native.LORA_R, K, dtype=dtype, device=DEV)
-    bs = torch.zeros(N, native.LORA_R, dtype=dtype, device=DEV)
+    R = (rt + native.LORA_R - 1) // native.LORA_R * native.LORA_R
+    a = torch.zeros(R, K, dtype=dtype, device=DEV)
+    bs = torch.zeros(N, R, dtype=dtype, device=DEV)
     delta = torch.zeros(N, K, dtype=torch.float32, device=DEV)
     o = 0
     for i, r in enumerate(ranks):
         d = _rand(r, K, dtype=dtype, seed=seed + 10 * i, scale=K ** -0.5)
         u = _rand(N, r, dtype=dtype, seed=seed + 10 * i + 1, scale=0.5)
-        sc = 1.0 - 0.2 * i
+        sc = 1.0 - 0.2 * (i % 4)
         a[o : o + r] = d
         bs[:, o : o + r] = (u.float() * sc).to(dtype)
         delta += bs[:, o : o + r].float() @ d.float()
         o += r
-    assert rt <= native.LORA_R
+    assert R <= native.LORA_RMAX
     if perm is not None:
         bs = bs[perm].contiguous()
     return native.KBlocked(a), bs, delta
 
 
 def gemm_lora_inlaunch_case(M, K, N, dtype, *, ranks=(16, 16), tile=0, geglu=False, transposed=False, seed=260):
-    """LoraAdapter as ONE launch: x A_cat^T in the parent's K loop, the pre-scaled up-projections as its last K step."""
+    """LoraAdapter as ONE launch: producer workgroups compute x A_cat^T once per row block, the pre-scaled up-projections are the tiles' last K steps."""
     x = _rand(M, K, dtype=dtype, seed=seed)
     w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
     b = _rand(N, dtype=dtype, seed=seed + 2)
@@ -774,6 +776,60 @@ def gemm_ln_lora_case(M, Cc, N2, dtype, *, tile=0, transposed=False, seed=280):
         native.gemm([(x, native.KBlocked(wl))], out, ln=(stats, ls, lc, eps), lora=lo, tile=tile)
         e = _cmp(out, full, dtype)
     return e[0], e[1], e[2] * (2.0 if dtype == torch.bfloat16 else 1.0)
+
+
+def conv_lora_inlaunch_case(B, Cin, Cout, H, W, dtype, *, ranks=(16, 16), stride=1, shortcut=0, ksplit=1, tile=0, seed=290):
+    """Conv2dLora inside the parent conv's launch: 3x3 down convs (the parent's stride / padding), 1x1 up convs; optionally a fused 1x1
+    shortcut segment (not adapted) and split-K (the first split carries the LoRA term)."""
+    x = _rand(B, H, W, Cin, dtype=dtype, seed=seed)
+    w = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=(9 * Cin) ** -0.5)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2)
+    rt = sum(ranks)
+    R = (rt + native.LORA_R - 1) // native.LORA_R * native.LORA_R
+    a = torch.zeros(R, 9 * Cin, dtype=dtype, device=DEV)
+    bs = torch.zeros(Cout, R, dtype=dtype, device=DEV)
+    xn = x.float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xn, w.float(), b.float(), stride=stride, padding=1)
+    o = 0
+    for i, r in enumerate(ranks):
+        d = _rand(r, Cin, 3, 3, dtype=dtype, seed=seed + 10 * i + 3, scale=(9 * Cin) ** -0.5)
+        u = _rand(Cout, r, dtype=dtype, seed=seed + 10 * i + 4, scale=0.5)
+        sc = 1.0 - 0.2 * i
+        a[o : o + r] = native.pack_conv_weight(d)
+        bs[:, o : o + r] = (u.float() * sc).to(dtype)
+        t = torch.nn.functional.conv2d(xn, d.float(), None, stride=stride, padding=1)
+        ref = ref + torch.nn.functional.conv2d(t, bs[:, o : o + r].float()[:, :, None, None])
+        o += r
+    OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+    segs = [(x, native.KBlocked(native.pack_conv_weight(w)), 3, stride, 1)]
+    if shortcut:
+        xs = _rand(B, OH, OW, shortcut, dtype=dtype, seed=seed + 7)
+        ws = _rand(Cout, shortcut, dtype=dtype, seed=seed + 8, scale=shortcut ** -0.5)
+        segs.append((xs, ws, 1, 1, 1))
+        ref = ref + torch.nn.functional.conv2d(xs.float().permute(0, 3, 1, 2), ws.float()[:, :, None, None])
+    out = torch.full((B * OH * OW, Cout), float("nan"), dtype=dtype, device=DEV)
+    wsb = torch.empty(ksplit * out.numel(), dtype=torch.float32, device=DEV) if ksplit > 1 else None
+    native.conv_gemm(segs, out, B, OH, OW, bias=b, lora=([(0, native.KBlocked(a))], bs), ksplit=ksplit, ws=wsb, tile=tile)
+    return _cmp(out, ref.permute(0, 2, 3, 1).reshape(B * OH * OW, Cout), dtype)
+
+
+def gemm_lora_repeat_case(M, K, N, dtype, seed=295):
+    """The hand-off under reuse: the SAME scratch / flags / epoch word driven through several launches with different inputs (what a
+    replayed program does), every word of every result checked -- a stale t (flag seen early, L1-resident line) would show here."""
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    a_kb, bs, delta = _lora_pack(K, N, dtype, (16, 16), seed + 3)
+    sync = native.LoraSync(torch.device(DEV))
+    t, flags = sync.scratch(1, M, 32, dtype), sync.flags(1, M)
+    wk = native.KBlocked(w)
+    worst = (0.0, 0.0, 1.0)
+    for rnd in range(6):
+        x = _rand(M, K, dtype=dtype, seed=seed + 50 + rnd)
+        out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+        sync.bump()
+        native.gemm([(x, wk)], out, lora=([(0, a_kb)], bs), lora_sync=(t, flags, sync), tile=(1, 4, 2, 3)[rnd % 4])
+        e = _cmp(out, x.float() @ (w.float() + delta).t(), dtype)
+        worst = (max(worst[0], e[0]), max(worst[1], e[1]), e[2])
+    return worst
 
 
 def all_cases():
@@ -947,6 +1003,17 @@ def all_cases():
             (f"gemm_{tag}_ln_lora_1024x1280", lambda dt=dt: gemm_ln_lora_case(1024, 1280, 1280, dt)),
             (f"gemm_{tag}_ln_lora_tile4", lambda dt=dt: gemm_ln_lora_case(300, 640, 384, dt, tile=4)),
             (f"gemm_{tag}_ln_lora_transposed_tile3", lambda dt=dt: gemm_ln_lora_case(512, 640, 256, dt, tile=3, transposed=True)),
+            (f"gemm_{tag}_lora1_rank64", lambda dt=dt: gemm_lora_inlaunch_case(520, 640, 384, dt, ranks=(32, 16, 8))),
+            (f"gemm_{tag}_lora1_rank128", lambda dt=dt: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, ranks=(128,))),
+            (f"gemm_{tag}_lora1_rank128_tile4_to_3", lambda dt=dt: gemm_lora_inlaunch_case(300, 640, 200, dt, ranks=(64, 64), tile=4)),
+            (f"gemm_{tag}_lora1_rank64_tile2", lambda dt=dt: gemm_lora_inlaunch_case(520, 320, 384, dt, ranks=(64,), tile=2)),
+            (f"gemm_{tag}_lora1_rank96_transposed", lambda dt=dt: gemm_lora_inlaunch_case(154, 2048, 640, dt, ranks=(64, 32), transposed=True)),
+            (f"gemm_{tag}_lora1_ff2_2048x1280x5120", lambda dt=dt: gemm_lora_inlaunch_case(2048, 5120, 1280, dt)),
+            (f"gemm_{tag}_lora1_repeat_shared_scratch", lambda dt=dt: gemm_lora_repeat_case(1024, 640, 1280, dt)),
+            (f"conv_{tag}_lora1_2x64x128_32x32", lambda dt=dt: conv_lora_inlaunch_case(2, 64, 128, 32, 32, dt)),
+            (f"conv_{tag}_lora1_rank128_stride2", lambda dt=dt: conv_lora_inlaunch_case(2, 128, 256, 32, 32, dt, ranks=(128,), stride=2)),
+            (f"conv_{tag}_lora1_shortcut_tile1", lambda dt=dt: conv_lora_inlaunch_case(1, 64, 128, 24, 40, dt, ranks=(8,), shortcut=64, tile=1)),
+            (f"conv_{tag}_lora1_splitk3", lambda dt=dt: conv_lora_inlaunch_case(2, 320, 128, 16, 16, dt, ksplit=3, tile=1)),
             (f"wide_head_{tag}_384x512", lambda dt=dt: wide_head_attention_case(384, 512, dt)),
             (f"wide_head_{tag}_1024x512", lambda dt=dt: wide_head_attention_case(1024, 512, dt)),
             (f"softmax_rows_{tag}_vec", lambda dt=dt: softmax_rows_case(33, 1000, 1024, dt)),
