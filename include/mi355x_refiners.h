@@ -157,16 +157,16 @@ typedef struct {
     int32_t out_f32;        /* 1 = `out` is float32 whatever `dtype` says (ldo in float elements; 16-byte aligned rows): raw scores for
                                mi355x_softmax_rows.  Not combinable with geglu / stats_out / out_t / ksplit. */
     /* LoRA inside the parent launch -- LoraAdapter = Sum(target, *loras), src/refiners/fluxion/adapters/lora.py:383-397, with
-       Lora = Chain(down, up, Multiply(scale)) (:14-60; LinearLora :269-322, Conv2dLora :325-380) -- for a stacked rank lora_r that is a
-       multiple of 32 and at most 128 (zero-padded):
+       Lora = Chain(down, up, Multiply(scale)) (:14-60; LinearLora :269-322, Conv2dLora :325-380) -- for a stacked rank lora_r of 32, 64
+       or 128 (zero-padded):
          out += T( x . A_g^T ) . lora_b[n]^T      g = column group of n (lora_nb[g] <= n, groups start on multiples of 128)
        lora_a[g]: the lora_r stacked down-projection rows of group g, K-BLOCKED: [K*sizeof/128][lora_r][128 bytes] (conv == 1: the down
        convolutions' weights packed like w, same kernel size / stride / padding as segment 0; the up convolutions must be 1x1);
        lora_b: [N][lora_r] row-major, the up-projections already multiplied by their scales (rows follow the same N-packing as w).
-       The LoRAs adapt segment 0.  x A^T is computed ONCE per row block, by extra workgroups at the head of the launch's grid (no column
+       The LoRAs adapt segment 0.  x A^T is computed ONCE per 32 rows, by extra workgroups at the head of the launch's grid (no column
        tile recomputes it), rounded to `dtype` (the reference's intermediate tensor), handed to the output tiles through
          lora_t     scratch, >= groups * M * lora_r elements of `dtype`, 16-byte aligned,
-         lora_flags int32[groups * ceil(M / 64)], zeroed once by the caller and private to this call site (they keep the last epoch),
+         lora_flags int32[groups * ceil(M / 32)], zeroed once by the caller and private to this call site (they keep the last epoch),
          lora_epoch device pointer to an int32 whose value differs from every value left in lora_flags: increment it (mi355x_epoch_bump)
                     before each launch, or once per replay of a recorded program whose LoRA launches each own their flags,
        and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with xattn_kv, out_f32 or the 8-wave tiles;

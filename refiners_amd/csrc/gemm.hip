@@ -147,7 +147,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     if (a->lora_b) {
         if (a->ksplit > 1 && a->geglu) return MI355X_ESHAPE;
         if ((a->ln_stats && (!a->lora_ls || !a->lora_lc)) || a->out_f32 || a->xattn_kv || a->lora_groups < 1 || a->lora_groups > 3 || a->lora_nb[0] != 0 ||
-            !aligned16(a->lora_b) || a->lora_r < 32 || a->lora_r > mi355x::LORA_RMAX || a->lora_r % 32 || !a->lora_t || !aligned16(a->lora_t) || !a->lora_flags ||
+            !aligned16(a->lora_b) || (a->lora_r != 32 && a->lora_r != 64 && a->lora_r != 128) || !a->lora_t || !aligned16(a->lora_t) || !a->lora_flags ||
             !a->lora_epoch || (a->conv && a->lora_groups != 1))
             return MI355X_ESHAPE;
         for (int g = 0; g < a->lora_groups; ++g) {

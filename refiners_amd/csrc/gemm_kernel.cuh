@@ -31,17 +31,18 @@
 //     per-row (mean, M2) partials over 32-column chunks that the launch PRODUCING r wrote from its epilogue (Chan-merged
 //     in a fixed order: deterministic, no atomics);
 //   * LoRA inside the parent launch (LORA = true): y = x W^T + b + sum_i s_i (x A_i^T) B_i^T from ONE kernel
-//     (fluxion/adapters/lora.py:383-397) without any column tile recomputing the down-projection.  tiles_m x groups extra workgroups at
-//     the head of the grid (the "producers", one per row block and column group) compute t = x A_cat^T for their BM rows with this
-//     kernel's own loader (plain rows or conv taps) against the stacked down rows A_cat [R][K] (R <= 128), round t to the storage type
-//     like the reference's intermediate tensor, store it write-through (sc1) to a scratch [groups][M][R] and publish a per-row-block
-//     flag (= the launch's epoch, read from device memory).  Every output tile runs its K loop exactly like an un-adapted launch, then
-//     waits for its row block's flag (set long before: the producers' K loop carries R / BN of a tile's MFMAs), pulls its t rows
-//     (sc1 loads) and multiplies them, 32 ranks per step, against the pre-scaled up rows (s B_cat) [N][R]; the first 32 ranks of those
-//     were staged into LDS by the prologue.  Producers have the lowest workgroup ids of the launch, so they are dispatched before any
-//     tile that waits for them (the spin is bounded by the wall clock and traps rather than hangs).  Per-column-group A so that a
-//     merged Q|K|V launch keeps its three LoRA sets; Conv2dLora = the same with the conv loader (down conv of the parent's kernel
-//     size / stride, 1x1 up conv);
+//     (fluxion/adapters/lora.py:383-397) without any column tile recomputing the down-projection.  ceil(M / 32) x groups extra
+//     workgroups at the head of the grid (the "producers", one per 32 rows and column group) compute t = x A_cat^T with this kernel's
+//     own loader (plain rows or conv taps) against the stacked down rows A_cat [R][K] (R = 32 / 64 / 128) through an up-to-8-deep LDS
+//     ring, round t to the storage type like the reference's intermediate tensor, store it write-through (sc1) to a scratch
+//     [groups][M][R] and publish a flag per 32 rows (= the launch's epoch, read from device memory).  Every output tile runs its K loop
+//     exactly like an un-adapted launch; three trips before its end the first lanes of wave 0 load the tile's flags, one trip later
+//     every thread requests its 16-byte pieces of the t rows (sc1 loads: they land while the last K block is multiplied), and after
+//     the loop t goes through LDS, 32 ranks per step, against the pre-scaled up rows (s B_cat) [N][R], whose first 32 ranks the prologue
+//     staged into LDS.  Producers have the lowest workgroup ids of the launch, so they are dispatched before any tile that waits for
+//     them (a tile that does not find its flags set spins after the loop, bounded by the wall clock, and traps rather than hangs).
+//     Per-column-group A so that a merged Q|K|V launch keeps its three LoRA sets; Conv2dLora = the same with the conv loader (down
+//     conv of the parent's kernel size / stride, 1x1 up conv);
 //   * bf16 -> v_mfma_f32_16x16x32_bf16, f32 (parity mode) -> v_mfma_f32_16x16x4_f32; identical LDS image.
 #pragma once
 #include <type_traits>
@@ -106,9 +107,9 @@ struct GemmP {
     const float* lora_ls;  // LayerNorm folded into this launch AND LoRA: [groups][lora_r] sum_k A'[r][k] and
     const float* lora_lc;  //                                            [groups][lora_r] sum_k beta[k] A[r][k]
     char* lora_t;          // [groups][M][lora_r] of T: the producers' t = x A^T (already divided by rstd when LayerNorm is folded in)
-    int* lora_flags;       // [groups][tiles_m]: == *lora_epoch once that row block's t is complete
+    int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
     const int* lora_epoch;
-    int lp_blocks;         // producer workgroups at the head of the grid (tiles_m * groups rounded up to a multiple of 8)
+    int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
     const char* pf_ptr[MI355X_MAX_PREFETCH];
@@ -406,6 +407,7 @@ MI_DEV void xatt_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], char* smem, cons
 }
 
 constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
+constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)
 constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch (control-lora-*-rank128)
 
 // 8-byte relaxed agent-scope accesses: sc1 (write-through / L1-bypassing) on gfx950, the form the microarchitecture guide lists as valid
@@ -470,10 +472,11 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     int bid = (int)blockIdx.x - p.pf_blocks;
     if constexpr (LORA) {
         if (bid < p.lp_blocks) {
-            if (bid >= p.tiles_m * p.lora_groups) return;  // padding up to a multiple of 8 (keeps compute block b on XCD b % 8)
+            const int npb = (p.M + LORA_PM - 1) / LORA_PM;  // producer row blocks of LORA_PM rows
+            if (bid >= npb * p.lora_groups) return;  // padding up to a multiple of 8 (keeps compute block b on XCD b % 8)
             prod = true;
-            pgi = bid / p.tiles_m;
-            tm = bid - pgi * p.tiles_m;
+            pgi = bid / npb;
+            tm = bid - pgi * npb;
         }
         bid -= p.lp_blocks;
     }
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     }
     if (tm >= p.tiles_m || tn >= p.tiles_n) return;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = prod ? tm * LORA_PM : tm * BM, n0 = tn * BN;
     const bool tr = !CONV && !prod && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
     const int Nw = prod ? p.lora_r : p.N;                // rows of the weight operand this workgroup streams
     const int nseg = prod ? 1 : p.nseg;                  // the LoRAs adapt segment 0 (the conv / Linear itself, not a fused shortcut)
@@ -700,9 +703,11 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 issue_half(s0, 1);
             }
     } else {
+        if (!prod) {  // (a producer fills its own, deeper ring: see producer_loop)
 #pragma unroll
-        for (int s0 = 0; s0 < D; ++s0)
-            if (s0 < my_kb) issue(s0);
+            for (int s0 = 0; s0 < D; ++s0)
+                if (s0 < my_kb) issue(s0);
+        }
     }
 
     if (p.ln_stats) {
@@ -762,6 +767,38 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     //   phase B(t): MFMA on F1(t)                            || ds_read F0(t+1)
     // One barrier per K block, between the phases.  The interleave inside a phase is pinned with sched_group_barrier (the
     // machine scheduler otherwise sinks every ds_read to just before its first use and waits lgkmcnt(0) eight times per block).
+    // LORA, output tiles: the hand-off is started INSIDE the K loop so that its two dependent round trips (flags, then the t rows) overlap
+    // the last K blocks: at trip hook_t the first lanes of wave 0 load the row block's flags (right behind the loop's last stage issue);
+    // one trip later -- the loop's vmcnt(0) has retired them -- wave 0 publishes "all set" through LDS ahead of that trip's barrier and
+    // every thread issues its L1-bypassing loads of the t rows, which land while the last block is multiplied.
+    constexpr int L_RB = LORA_RC * (int)sizeof(T), L_CPRB = L_RB / 16, L_TI = LORA ? BM * L_CPRB / NTHR : 1;
+    uint64_t tv[L_TI][2];
+    int lora_fl = lora_tag, lora_ok = 0;
+    int* const lds_ok = reinterpret_cast<int*>(lora_b0 + BN * L_RB);
+    const int nfl_blocks = (p.M + LORA_PM - 1) / LORA_PM;
+    const int hook_t = (lora_tail && max_kb >= 4) ? max_kb - 3 : -2;
+    auto lora_poll = [&]() __attribute__((always_inline)) {  // lanes 0 .. BM / 32 - 1 of wave 0: one flag each (row blocks past M count as set)
+        if (wid == 0 && lane < BM / LORA_PM) {
+            const int fb = m0 / LORA_PM + lane;
+            if (fb < nfl_blocks) lora_fl = __hip_atomic_load(p.lora_flags + lgi * nfl_blocks + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto lora_load_t = [&](int c) __attribute__((always_inline)) {  // this thread's 16-byte pieces of the tile's t rows, rank chunk c
+        const char* tg = p.lora_t + (int64_t)lgi * p.M * p.lora_r * (int)sizeof(T);
+#pragma unroll
+        for (int it = 0; it < L_TI; ++it) {
+            const int q = it * NTHR + tid, row = q / L_CPRB, ch = q % L_CPRB;
+            int mr = row;
+            if (tr) {
+                const int rl = row % WME;
+                mr = (row - rl) + 4 * MT * ((rl >> 2) & 3) + 4 * (rl >> 4) + (rl & 3);
+            }
+            const int m = min(m0 + mr, p.M - 1);
+            const char* src = tg + ((int64_t)m * p.lora_r + c * LORA_RC) * (int)sizeof(T) + ch * 16;
+            tv[it][0] = ld_agent8(src);
+            tv[it][1] = ld_agent8(src + 8);
+        }
+    };
     auto mainloop = [&](auto trc) {
         constexpr bool TR = decltype(trc)::value;
         constexpr int RR = MT + NT;                                // ds_read_b128 per phase
@@ -812,9 +849,23 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             if (t + 1 < max_kb) {
                 if (t + 1 + D <= my_kb) wait_vm<(D - 1) * LPS>();
                 else wait_vm0();
+                if constexpr (LORA) {
+                    if (t == hook_t + 1 && wid == 0) {  // the flags loaded one trip ago have arrived (vmcnt(0) above: the last D trips drain everything)
+                        const bool all = __builtin_amdgcn_ballot_w64(lora_fl == lora_tag) == ~0ull;
+                        if (lane == 0) *lds_ok = all ? 1 : 0;
+                    }
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (t + 1 + D < my_kb) issue((t + 1 + D) % NSTAGE);
+                if constexpr (LORA) {
+                    if (t == hook_t) lora_poll();
+                    if (t == hook_t + 1) {
+                        // (an explicit ds_read: a volatile generic load here compiles to flat_load + vmcnt(0))
+                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(lora_ok) : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)lds_ok) : "memory");
+                        if (lora_ok) lora_load_t(0);
+                    }
+                }
             }
             if (active) {  // phase B
                 read_half(xf0, wf0, t + 1, 0);  // (past the last block: a harmless read of a stale stage; keeps the phase one basic block)
@@ -953,81 +1004,88 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     };
     if constexpr (LORA) {
         if (prod) {
-            // ---- LoRA producer: t[m0 .. m0 + BM)[0 .. R) = x A_g^T.  Wave (wm, wn) takes its MT row blocks x rpw = R / (16 WN) rank blocks
-            // (weight rows unpermuted: LDS row r = rank r); same LDS ring and counted waits as the main loop, no register pipelining
-            // (the loop is latency-bound: R / BN of a tile's MFMAs).
-            const int rpw = p.lora_r / (16 * WN);
-            f32x4 ta[MT][LORA_RMAX / (16 * WN)];
+            // ---- LoRA producer: t[m0 .. m0 + 32)[0 .. R) = x A_g^T, R = 32 RI.  The loop is latency-bound (R / BN of a tile's MFMAs on a quarter
+            // of its rows), so the workgroup's LDS is re-cut into a ring of up to 8 stages of (32 x rows + R weight rows) x 128 B: 7 K blocks in
+            // flight.  Wave w takes row block w & 1 and the RI rank blocks (w >> 1) RI .. (weight rows unpermuted: LDS row r = rank r).
+            auto producer_loop = [&](auto ric) {
+                constexpr int RI = decltype(ric)::value;
+                constexpr int PXB = LORA_PM * 128, PSTAGE = PXB + 32 * RI * 128;
+                constexpr int RING = KG * NSTAGE * STAGE;
+                constexpr int PST = RING / PSTAGE < 8 ? RING / PSTAGE : 8;
+                static_assert(PST >= 2, "LoRA producer: the tile's LDS ring holds fewer than two producer stages");
+                static_assert(RI <= WI, "LoRA producer: more weight-row loads than the tile's loader has");
+                constexpr int PD = PST - 1, PL = 1 + RI;
+                auto issue_p = [&](int buf) __attribute__((always_inline)) {
+                    char* st = smem + buf * PSTAGE;
+                    const char* src;
+                    if constexpr (CONV) src = xbase[0] ? xbase[0] + (int64_t)cb * 128 : p.zeros + xcoff[0];
+                    else src = xbase[0] + xoff;
+                    glds16(src, st + wid * 64 * 16);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                    for (int j = 0; j < RI; ++j) glds16(wbase[j] + woff, st + PXB + (j * NTHR + wid * 64) * 16);
+                    advance();
+                };
+                const int rb = wid & 1, rg = wid >> 1;
+                f32x4 ta[RI];
 #pragma unroll
-                for (int j = 0; j < LORA_RMAX / (16 * WN); ++j) ta[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (D <= my_kb) wait_vm<(D - 1) * LPS>();
-            else wait_vm0();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (D < my_kb) issue(D % NSTAGE);
-            for (int t = 0; t < my_kb; ++t) {
-                const char* xs = smem_g + (t % NSTAGE) * STAGE;
-                const char* ws = xs + XBYTES;
+                for (int j = 0; j < RI; ++j) ta[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    frag_t xf[MT];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) xf[i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
-#pragma unroll
-                    for (int j = 0; j < LORA_RMAX / (16 * WN); ++j)
-                        if (j < rpw) {  // wave-uniform
-                            const frag_t af = lds_read_frag(ws, tile_off<128>((wn * rpw + j) * 16 + c16, 4 * kk + g));
-#pragma unroll
-                            for (int i = 0; i < MT; ++i) mma_step<T>(ta[i][j], af, xf[i]);  // D[rank 16 j' + 4 g + r][row 16 i + c16]
-                        }
-                }
-                if (t + 1 < my_kb) {
-                    if (t + 1 + D <= my_kb) wait_vm<(D - 1) * LPS>();
+                for (int s0 = 0; s0 < PD; ++s0)
+                    if (s0 < my_kb) issue_p(s0);
+                for (int t = 0; t < my_kb; ++t) {
+                    if (t + PD <= my_kb) wait_vm<(PD - 1) * PL>();  // block t has landed, the PD - 1 younger ones stay in flight
                     else wait_vm0();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    if (t + 1 + D < my_kb) issue((t + 1 + D) % NSTAGE);
-                }
-            }
-            // epilogue: LayerNorm folded in -> what is published is t / rstd = (x A'^T - mean sA) + cA / rstd, the tile epilogue's
-            // rstd * (acc - mean s) + c then scales the up-projected product back (one rounding of t, as in the reference); rounded to T;
-            // written through to L2 (8-byte agent-scope stores), then the row block's flag
-            char* tg = p.lora_t + (int64_t)pgi * p.M * p.lora_r * (int)sizeof(T);
+                    if (t + PD < my_kb) issue_p((t + PD) % PST);  // into the buffer block t - 1 was read from (every wave retired those reads above)
+                    const char* st = smem + (t % PST) * PSTAGE;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int mrow = wm * WME + 16 * i + c16, m = m0 + mrow;
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const frag_t xf = lds_read_frag(st, tile_off<128>(16 * rb + c16, 4 * kk + g));
+#pragma unroll
+                        for (int j = 0; j < RI; ++j) {
+                            const frag_t af = lds_read_frag(st + PXB, tile_off<128>((rg * RI + j) * 16 + c16, 4 * kk + g));
+                            mma_step<T>(ta[j], af, xf);  // D[rank 16 (rg RI + j) + 4 g + r][row 16 rb + c16]
+                        }
+                    }
+                }
+                // epilogue: LayerNorm folded in -> what is published is t / rstd = (x A'^T - mean sA) + cA / rstd, the tile epilogue's
+                // rstd * (acc - mean s) + c then scales the up-projected product back (one rounding of t, as in the reference); rounded to T;
+                // written through to L2 (8-byte agent-scope stores), then the row block's flag
+                char* tg = p.lora_t + (int64_t)pgi * p.M * p.lora_r * (int)sizeof(T);
+                const int mrow = 16 * rb + c16, m = m0 + mrow;
                 float mean = 0.f, inv = 1.f;
                 if (p.ln_stats) {
                     mean = rowstat[2 * mrow];
                     inv = 1.0f / rowstat[2 * mrow + 1];
                 }
 #pragma unroll
-                for (int j = 0; j < LORA_RMAX / (16 * WN); ++j)
-                    if (j < rpw) {
-                        const int r0 = (wn * rpw + j) * 16 + 4 * g;
-                        f32x4 v = ta[i][j];
-                        if (p.ln_stats) {
-                            const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + pgi * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + pgi * p.lora_r + r0);
+                for (int j = 0; j < RI; ++j) {
+                    const int r0 = (rg * RI + j) * 16 + 4 * g;
+                    f32x4 v = ta[j];
+                    if (p.ln_stats) {
+                        const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + pgi * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + pgi * p.lora_r + r0);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean * sa[e]) + ca[e] * inv;
-                        }
-                        if (m < p.M) {
-                            char* dst = tg + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
-                            if constexpr (sizeof(T) == 4) {
-                                st_agent8(dst, __builtin_bit_cast(uint64_t, f32x2{v[0], v[1]}));
-                                st_agent8(dst + 8, __builtin_bit_cast(uint64_t, f32x2{v[2], v[3]}));
-                            } else {
-                                const bf16x4 b4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                                st_agent8(dst, __builtin_bit_cast(uint64_t, b4));
-                            }
+                        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean * sa[e]) + ca[e] * inv;
+                    }
+                    if (m < p.M) {
+                        char* dst = tg + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
+                        if constexpr (sizeof(T) == 4) {
+                            st_agent8(dst, __builtin_bit_cast(uint64_t, f32x2{v[0], v[1]}));
+                            st_agent8(dst + 8, __builtin_bit_cast(uint64_t, f32x2{v[2], v[3]}));
+                        } else {
+                            const bf16x4 b4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                            st_agent8(dst, __builtin_bit_cast(uint64_t, b4));
                         }
                     }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(p.lora_flags + pgi * p.tiles_m + tm, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.lora_flags + pgi * ((p.M + LORA_PM - 1) / LORA_PM) + tm, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            if (p.lora_r == 32) producer_loop(std::integral_constant<int, 1>{});
+            else if (p.lora_r == 64) producer_loop(std::integral_constant<int, 2>{});
+            else if constexpr (WI >= 4) producer_loop(std::integral_constant<int, 4>{});  // ranks 96 / 128 (zero-padded to 128 rows by the host)
             return;
         }
     }
@@ -1055,40 +1113,31 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     if constexpr (LORA) {
         // ---- up-projection: acc += T(t) . (s B_cat)^T, 32 ranks per step through LDS; t comes from this row block's producer -------------
         if (lora_tail) {
-            constexpr int RB = LORA_RC * (int)sizeof(T);  // bytes per row of both LDS images (64 / 128)
-            constexpr int CPRB = RB / 16;                 // 16-byte chunks per row
+            constexpr int RB = L_RB;                      // bytes per row of both LDS images (64 / 128)
+            constexpr int CPRB = L_CPRB;                  // 16-byte chunks per row
             constexpr int KS = LORA_RC / DT<T>::KSTEP;    // MMA steps per chunk (bf16: 1, f32: 2)
-            constexpr int TI = BM * CPRB / NTHR, BI = BN * CPRB / NTHR;
+            constexpr int TI = L_TI, BI = BN * CPRB / NTHR;
             static_assert(BM * CPRB % NTHR == 0, "t tile / thread mismatch");
             char* tl = smem;             // [BM rows in LDS order][32 ranks] of T
             char* bl = smem + BM * RB;   // [BN rows in LDS order][32 ranks] of T: chunks after the first (the first sits in lora_b0)
             const int nch = p.lora_r / LORA_RC;
-            const char* tg = p.lora_t + (int64_t)lgi * p.M * p.lora_r * (int)sizeof(T);
-            if (tid == 0) {  // the producer finished long ago unless the whole launch is one wave of tiles; bounded by the wall clock
-                const int* fp = p.lora_flags + lgi * p.tiles_m + tm;
-                const uint64_t t0 = wall_clock64();
-                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lora_tag) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (wall_clock64() - t0 > 200000000ull) __builtin_trap();  // 2 s of the 100 MHz clock: a lost producer must not hang the GPU
+            if (!lora_ok) {  // not seen from inside the loop (a short K loop, or a producer still running): wait here, bounded by the wall clock
+                lora_poll();
+                if (wid == 0 && lane < BM / LORA_PM) {
+                    const int fb = min(m0 / LORA_PM + lane, nfl_blocks - 1);
+                    const int* fp = p.lora_flags + lgi * nfl_blocks + fb;
+                    const uint64_t t0 = wall_clock64();
+                    while (lora_fl != lora_tag) {
+                        __builtin_amdgcn_s_sleep(2);
+                        lora_fl = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (wall_clock64() - t0 > 200000000ull) __builtin_trap();  // 2 s of the 100 MHz clock: a lost producer must not hang the GPU
+                    }
                 }
             }
-            __syncthreads();  // every wave is done with the stage buffers; the flag has been seen
+            __syncthreads();  // every wave is done with the stage buffers; the flags have been seen
             for (int c = 0; c < nch; ++c) {
                 if (c) __syncthreads();  // the previous chunk's fragments have been read
-                uint64_t tv[TI][2];
-#pragma unroll
-                for (int it = 0; it < TI; ++it) {  // L1-bypassing loads: this CU may hold stale lines of the scratch from an earlier launch
-                    const int q = it * NTHR + tid, row = q / CPRB, ch = q % CPRB;
-                    int mr = row;
-                    if (tr) {
-                        const int rl = row % WME;
-                        mr = (row - rl) + 4 * MT * ((rl >> 2) & 3) + 4 * (rl >> 4) + (rl & 3);
-                    }
-                    const int m = min(m0 + mr, p.M - 1);
-                    const char* src = tg + ((int64_t)m * p.lora_r + c * LORA_RC) * (int)sizeof(T) + ch * 16;
-                    tv[it][0] = ld_agent8(src);
-                    tv[it][1] = ld_agent8(src + 8);
-                }
+                if (c || !lora_ok) lora_load_t(c);  // (chunk 0 was requested from inside the loop)
                 frag_t bv[BI];
                 if (c) {
 #pragma unroll
@@ -1428,7 +1477,7 @@ extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS 
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
-    constexpr int LDS0 = KG * NSTAGE * (BM + BN) * 128 + BM * 8 + (LORA ? BN * LORA_RC * (int)sizeof(T) : 0);
+    constexpr int LDS0 = KG * NSTAGE * (BM + BN) * 128 + BM * 8 + (LORA ? BN * LORA_RC * (int)sizeof(T) + 16 : 0);
     constexpr int LDS = XATT && 2 * xa_head_bytes<T>() > LDS0 ? 2 * xa_head_bytes<T>() : LDS0;  // the epilogue's K / V^T of two heads reuse the ring
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(KG == 1 || (BM / WM / 16) * (BN / WN / 16) * WM * WN * 1024 <= KG * NSTAGE * (BM + BN) * 128, "partial-tile exchange must fit the stage buffers");
@@ -1480,7 +1529,7 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     q.pf_blocks = (q.pf_blocks + 7) / 8 * 8;  // a multiple of 8: compute block b still lands on XCD b % 8
     if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
     q.pf_mode = g_pf_mode;
-    q.lp_blocks = LORA ? (q.tiles_m * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
+    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
     const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), (q.ln_stats || XATT || LORA) ? LDS : LDS - BM * 8, stream, q);

@@ -340,8 +340,8 @@ class Lowering:
             if row_perm is not None:
                 bs = bs[row_perm].contiguous()
             pack = LoraPack(a, bs)
-            R = (rt + native.LORA_R - 1) // native.LORA_R * native.LORA_R
-            if R <= native.LORA_RMAX and self.device.type != "meta":  # fits mi355x_gemm's in-launch LoRA: ONE kernel per adapted Linear
+            R = native.lora_rank(rt)
+            if R and self.device.type != "meta":  # fits mi355x_gemm's in-launch LoRA: ONE kernel per adapted Linear
                 ar = torch.zeros(R, k_in, device=self.device, dtype=self.dtype)
                 ar[: min(R, rpad)] = a[: min(R, rpad)]
                 br = torch.zeros(n_out, R, device=self.device, dtype=self.dtype)
@@ -457,8 +457,8 @@ class Lowering:
                     bs4[:, off : off + r] = u.weight.detach().to(device=self.device, dtype=torch.float32) * s
                     off += r
                 pack = LoraPack(a, native.pack_conv_weight(bs4.to(self.dtype)), conv=(kd, ku, leaf.stride[0]))
-                R = (rt + native.LORA_R - 1) // native.LORA_R * native.LORA_R
-                if ku == 1 and kd == kh and R <= native.LORA_RMAX and self.device.type != "meta" and all(_pad2(d) == _pad2(leaf) for d in downs):
+                R = native.lora_rank(rt)
+                if ku == 1 and kd == kh and R and self.device.type != "meta" and all(_pad2(d) == _pad2(leaf) for d in downs):
                     # Conv2dLora inside the parent conv's launch: down conv = the parent's kernel size / stride / padding, 1x1 up conv
                     ar = torch.zeros(R, kd * kd * i, device=self.device, dtype=self.dtype)
                     ar[: min(R, rpad)] = a[: min(R, rpad)]

@@ -94,6 +94,11 @@ LORA_R = 32  # granularity of the stacked LoRA rank mi355x_gemm handles inside t
 LORA_RMAX = 128  # largest stacked rank (LORA_RMAX there)
 
 
+def lora_rank(rt: int) -> int:
+    """Stacked rank -> the padded rank the kernel handles (32, 64 or 128); 0 = too large for the in-launch path."""
+    return next((r for r in (32, 64, 128) if rt <= r), 0)
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32),
@@ -540,7 +545,7 @@ class LoraSync:
         self.keep: list = []
 
     def flags(self, groups: int, M: int) -> Tensor:
-        f = torch.zeros(groups * ((M + 63) // 64), dtype=torch.int32, device=self.device)
+        f = torch.zeros(groups * ((M + 31) // 32), dtype=torch.int32, device=self.device)
         self.keep.append(f)
         return f
 
@@ -562,7 +567,7 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
     sync = (t scratch, flags, LoraSync) from the engine; None (eager calls: tests, probes) = fresh buffers and an epoch bump per call."""
     groups, lb = lora[0], lora[1]
     R = lb.shape[1]
-    assert 1 <= len(groups) <= 3 and lb.dim() == 2 and lb.shape[0] == a.N and R % LORA_R == 0 and LORA_R <= R <= LORA_RMAX and lb.is_contiguous() and lb.dtype == dtype
+    assert 1 <= len(groups) <= 3 and lb.dim() == 2 and lb.shape[0] == a.N and R in (32, 64, 128) and lb.is_contiguous() and lb.dtype == dtype
     for g, (nb, la) in enumerate(groups):
         assert isinstance(la, KBlocked) and la.shape == (R, K) and la.dtype == dtype, (la.shape, R, K)
         a.lora_a[g], a.lora_nb[g] = la.data_ptr(), nb
@@ -581,7 +586,7 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
         ls.bump()
         sync = (ls.scratch(len(groups), a.M, R, dtype), ls.flags(len(groups), a.M), ls)
     t, flags, ls = sync
-    assert t.numel() >= len(groups) * a.M * R and t.dtype == dtype and flags.numel() >= len(groups) * ((a.M + 63) // 64) and flags.dtype == torch.int32
+    assert t.numel() >= len(groups) * a.M * R and t.dtype == dtype and flags.numel() >= len(groups) * ((a.M + 31) // 32) and flags.dtype == torch.int32
     a.lora_t, a.lora_flags, a.lora_epoch = t.data_ptr(), flags.data_ptr(), ls.epoch.data_ptr()
     keep.append((lora, t, flags, ls))
 

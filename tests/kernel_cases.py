@@ -689,7 +689,7 @@ def _lora_pack(K, N, dtype, ranks, seed, perm=None):
     """(A K-blocked [R, K], sB [N, R], dense reference delta [N, K] float32) of stacked LoRAs with scales 1.0, 0.8, ...; R = the stacked
     rank rounded up to 32."""
     rt = sum(ranks)
-    R = (rt + native.LORA_R - 1) // native.LORA_R * native.LORA_R
+    R = native.lora_rank(rt)
     a = torch.zeros(R, K, dtype=dtype, device=DEV)
     bs = torch.zeros(N, R, dtype=dtype, device=DEV)
     delta = torch.zeros(N, K, dtype=torch.float32, device=DEV)
@@ -702,7 +702,7 @@ def _lora_pack(K, N, dtype, ranks, seed, perm=None):
         bs[:, o : o + r] = (u.float() * sc).to(dtype)
         delta += bs[:, o : o + r].float() @ d.float()
         o += r
-    assert R <= native.LORA_RMAX
+    assert R
     if perm is not None:
         bs = bs[perm].contiguous()
     return native.KBlocked(a), bs, delta
@@ -785,7 +785,7 @@ def conv_lora_inlaunch_case(B, Cin, Cout, H, W, dtype, *, ranks=(16, 16), stride
     w = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=(9 * Cin) ** -0.5)
     b = _rand(Cout, dtype=dtype, seed=seed + 2)
     rt = sum(ranks)
-    R = (rt + native.LORA_R - 1) // native.LORA_R * native.LORA_R
+    R = native.lora_rank(rt)
     a = torch.zeros(R, 9 * Cin, dtype=dtype, device=DEV)
     bs = torch.zeros(Cout, R, dtype=dtype, device=DEV)
     xn = x.float().permute(0, 3, 1, 2)
