@@ -10,6 +10,7 @@ int g_pf_blocks = 64;
 int g_pf_mode = 1;
 int g_tile = 0;
 int g_stages = 0;
+int g_lora_dbg = 0;
 
 namespace {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -30,6 +31,10 @@ extern "C" int mi355x_set_option(const char* name, int value) {
     if (name[0] == 'p') {  // "pfblocks" / "pfmode"
         if (name[2] == 'b') g_pf_blocks = value < 0 ? 0 : (value + 7) / 8 * 8;
         else g_pf_mode = value;
+        return MI355X_OK;
+    }
+    if (name[0] == 'l') {  // "lora_dbg"
+        g_lora_dbg = value;
         return MI355X_OK;
     }
     if (name[0] == 't') {  // "tile"
@@ -154,6 +159,10 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
             if (!a->lora_a[g] || !aligned16(a->lora_a[g]) || a->lora_nb[g] % 128 || (g && a->lora_nb[g] <= a->lora_nb[g - 1])) return MI355X_ESHAPE;
             p.lora_a[g] = static_cast<const char*>(a->lora_a[g]);
             p.lora_nb[g] = a->lora_nb[g];
+        }
+        if (a->lora_a_all) {
+            if (a->lora_groups < 2 || a->lora_groups * a->lora_r > mi355x::LORA_RMAX || !aligned16(a->lora_a_all)) return MI355X_ESHAPE;
+            p.lora_a_all = static_cast<const char*>(a->lora_a_all);
         }
         p.lora_groups = a->lora_groups;
         p.lora_r = a->lora_r;

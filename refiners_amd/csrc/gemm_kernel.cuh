@@ -100,9 +100,11 @@ struct GemmP {
     // LoRA inside the launch: per column group g (columns >= lora_nb[g]) the K-blocked stacked down rows, [K blocks][lora_r][128 B];
     // lora_b: [N][lora_r] pre-scaled up-projections (row n = output column n), row-major
     const char* lora_a[3];
+    const char* lora_a_all;  // optional: the down rows of ALL groups stacked, K-blocked [K blocks][groups * lora_r][128 B] (groups * lora_r <= 128):
+                             // one producer per 32 rows then serves every group (a merged Q|K|V launch reads x once instead of three times)
     int lora_nb[3];
     int lora_groups;
-    int lora_r;            // stacked rank, a multiple of 32, <= 128
+    int lora_r;            // stacked rank: 32, 64 or 128
     const char* lora_b;
     const float* lora_ls;  // LayerNorm folded into this launch AND LoRA: [groups][lora_r] sum_k A'[r][k] and
     const float* lora_lc;  //                                            [groups][lora_r] sum_k beta[k] A[r][k]
@@ -110,6 +112,7 @@ struct GemmP {
     int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
     const int* lora_epoch;
     int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
+    int lora_dbg;          // probing only (mi355x_set_option "lora_dbg"): bit 0 = producers exit at once (valid only while the flags still hold the epoch)
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
     const char* pf_ptr[MI355X_MAX_PREFETCH];
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     constexpr int XI = BM * 8 / NTHR, WI = BN * 8 / NTHR;
     constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
-    static_assert(!LORA || (KG == 1 && NTHR == 256 && WN == 2 && !STAG && !XATT), "in-launch LoRA: 4 waves as 2 x 2");
+    static_assert(!LORA || (KG == 1 && NTHR == 256 && WN == 2 && !STAG && !XATT && NSTAGE == 2), "in-launch LoRA: 4 waves as 2 x 2, two LDS stages");
     static_assert(!STAG || (BM == 256 && BN == 128 && WM == 4 && WN == 2 && NSTAGE == 3 && KG == 1 && !LORA), "staggered schedule: 256 x 128, 8 waves, 3 stages");
     static_assert(KG == 1 || KG == 2, "one or two K groups");
     static_assert(!XATT || (BM == 128 && BN == 128 && WM == 2 && WN == 2 && !CONV && KG == 1 && !LORA && !STAG), "cross-attention epilogue: the 128 x 128 tile, 2 x 2 waves");
@@ -473,7 +476,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     if constexpr (LORA) {
         if (bid < p.lp_blocks) {
             const int npb = (p.M + LORA_PM - 1) / LORA_PM;  // producer row blocks of LORA_PM rows
-            if (bid >= npb * p.lora_groups) return;  // padding up to a multiple of 8 (keeps compute block b on XCD b % 8)
+            if (bid >= npb * (p.lora_a_all ? 1 : p.lora_groups)) return;  // padding up to a multiple of 8 (keeps compute block b on XCD b % 8)
+            if (p.lora_dbg & 1) return;
             prod = true;
             pgi = bid / npb;
             tm = bid - pgi * npb;
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     }
     const int m0 = prod ? tm * LORA_PM : tm * BM, n0 = tn * BN;
     const bool tr = !CONV && !prod && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
-    const int Nw = prod ? p.lora_r : p.N;                // rows of the weight operand this workgroup streams
+    const int Nw = prod ? (p.lora_a_all ? p.lora_groups * p.lora_r : p.lora_r) : p.N;  // rows of the weight operand this workgroup streams
     const int nseg = prod ? 1 : p.nseg;                  // the LoRAs adapt segment 0 (the conv / Linear itself, not a fused shortcut)
     const int lora_tag = LORA ? *p.lora_epoch : 0;
 
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         const SegP& sp = p.seg[s];
         cur_nkb = sp.nkb;
         cur_cpb = sp.cpb;
-        const char* wsrc = prod ? p.lora_a[pgi] : sp.w;  // producer: the stacked down rows, always K-blocked
+        const char* wsrc = prod ? (p.lora_a_all ? p.lora_a_all : p.lora_a[pgi]) : sp.w;  // producer: the stacked down rows, always K-blocked
         const bool wkb = prod || sp.wkb;
         wstep = wkb ? (int64_t)Nw * 128 : 128;
         woff = (int64_t)kb0 * wstep;
@@ -767,16 +771,18 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     //   phase B(t): MFMA on F1(t)                            || ds_read F0(t+1)
     // One barrier per K block, between the phases.  The interleave inside a phase is pinned with sched_group_barrier (the
     // machine scheduler otherwise sinks every ds_read to just before its first use and waits lgkmcnt(0) eight times per block).
-    // LORA, output tiles: the hand-off is started INSIDE the K loop so that its two dependent round trips (flags, then the t rows) overlap
-    // the last K blocks: at trip hook_t the first lanes of wave 0 load the row block's flags (right behind the loop's last stage issue);
-    // one trip later -- the loop's vmcnt(0) has retired them -- wave 0 publishes "all set" through LDS ahead of that trip's barrier and
-    // every thread issues its L1-bypassing loads of the t rows, which land while the last block is multiplied.
+    // LORA, output tiles: the hand-off is started INSIDE the K loop so that its two dependent round trips (flags, then the t rows) ride
+    // in the loop's own load stream -- a dependent load issued from a streaming CU waits 1-3 us in that CU's memory queue
+    // (microarchitecture guide, handoff-1to1), far more than the epilogue could hide.  At trip hook_t = max_kb - 4 the first lanes of
+    // wave 0 load the row block's flags right behind that trip's stage issue; one trip later -- the loop's vmcnt(0) has retired them
+    // -- wave 0 publishes "all set" through LDS ahead of the barrier, and every thread issues its L1-bypassing loads of the t rows
+    // TOGETHER with the loop's last stage: the vmcnt(0) that waits for the last K block waits for them too, nothing else does.
     constexpr int L_RB = LORA_RC * (int)sizeof(T), L_CPRB = L_RB / 16, L_TI = LORA ? BM * L_CPRB / NTHR : 1;
     uint64_t tv[L_TI][2];
     int lora_fl = lora_tag, lora_ok = 0;
     int* const lds_ok = reinterpret_cast<int*>(lora_b0 + BN * L_RB);
     const int nfl_blocks = (p.M + LORA_PM - 1) / LORA_PM;
-    const int hook_t = (lora_tail && max_kb >= 4) ? max_kb - 3 : -2;
+    const int hook_t = (lora_tail && max_kb >= 4) ? max_kb - 4 : -2;
     auto lora_poll = [&]() __attribute__((always_inline)) {  // lanes 0 .. BM / 32 - 1 of wave 0: one flag each (row blocks past M count as set)
         if (wid == 0 && lane < BM / LORA_PM) {
             const int fb = m0 / LORA_PM + lane;
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 if (t + 1 + D <= my_kb) wait_vm<(D - 1) * LPS>();
                 else wait_vm0();
                 if constexpr (LORA) {
-                    if (t == hook_t + 1 && wid == 0) {  // the flags loaded one trip ago have arrived (vmcnt(0) above: the last D trips drain everything)
+                    if (t == hook_t + 1 && wid == 0) {  // the flags loaded one trip ago have arrived (D = 1: every trip's vmcnt(0) drains the queue)
                         const bool all = __builtin_amdgcn_ballot_w64(lora_fl == lora_tag) == ~0ull;
                         if (lane == 0) *lds_ok = all ? 1 : 0;
                     }
@@ -1012,9 +1018,14 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 constexpr int PXB = LORA_PM * 128, PSTAGE = PXB + 32 * RI * 128;
                 constexpr int RING = KG * NSTAGE * STAGE;
                 constexpr int PST = RING / PSTAGE < 8 ? RING / PSTAGE : 8;
-                static_assert(PST >= 2, "LoRA producer: the tile's LDS ring holds fewer than two producer stages");
-                static_assert(RI <= WI, "LoRA producer: more weight-row loads than the tile's loader has");
+                static_assert(PST >= 2 || RI > 3, "LoRA producer: the tile's LDS ring holds fewer than two producer stages");
                 constexpr int PD = PST - 1, PL = 1 + RI;
+                const char* pw[RI];  // this thread's 16 bytes of weight rows j * 32 + (tid >> 3) of a K block (rank r = LDS row r)
+#pragma unroll
+                for (int j = 0; j < RI; ++j) {
+                    const int q = j * NTHR + tid, row = q >> 3, pch = q & 7;
+                    pw[j] = (p.lora_a_all ? p.lora_a_all : p.lora_a[pgi]) + (int64_t)row * 128 + ((pch ^ swz<128>(row)) << 4);
+                }
                 auto issue_p = [&](int buf) __attribute__((always_inline)) {
                     char* st = smem + buf * PSTAGE;
                     const char* src;
@@ -1022,7 +1033,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                     else src = xbase[0] + xoff;
                     glds16(src, st + wid * 64 * 16);
 #pragma unroll
-                    for (int j = 0; j < RI; ++j) glds16(wbase[j] + woff, st + PXB + (j * NTHR + wid * 64) * 16);
+                    for (int j = 0; j < RI; ++j) glds16(pw[j] + woff, st + PXB + (j * NTHR + wid * 64) * 16);
                     advance();
                 };
                 const int rb = wid & 1, rg = wid >> 1;
@@ -1052,7 +1063,6 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 // epilogue: LayerNorm folded in -> what is published is t / rstd = (x A'^T - mean sA) + cA / rstd, the tile epilogue's
                 // rstd * (acc - mean s) + c then scales the up-projected product back (one rounding of t, as in the reference); rounded to T;
                 // written through to L2 (8-byte agent-scope stores), then the row block's flag
-                char* tg = p.lora_t + (int64_t)pgi * p.M * p.lora_r * (int)sizeof(T);
                 const int mrow = 16 * rb + c16, m = m0 + mrow;
                 float mean = 0.f, inv = 1.f;
                 if (p.ln_stats) {
@@ -1061,10 +1071,12 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 }
 #pragma unroll
                 for (int j = 0; j < RI; ++j) {
-                    const int r0 = (rg * RI + j) * 16 + 4 * g;
+                    const int rglob = (rg * RI + j) * 16 + 4 * g;  // rank row of the streamed weight operand
+                    const int gq = p.lora_a_all ? rglob / p.lora_r : pgi, r0 = p.lora_a_all ? rglob % p.lora_r : rglob;  // -> (column group, rank)
+                    char* tg = p.lora_t + (int64_t)gq * p.M * p.lora_r * (int)sizeof(T);
                     f32x4 v = ta[j];
                     if (p.ln_stats) {
-                        const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + pgi * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + pgi * p.lora_r + r0);
+                        const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + gq * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + gq * p.lora_r + r0);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean * sa[e]) + ca[e] * inv;
                     }
@@ -1081,11 +1093,21 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
                 __syncthreads();
-                if (tid == 0) __hip_atomic_store(p.lora_flags + pgi * ((p.M + LORA_PM - 1) / LORA_PM) + tm, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int npb = (p.M + LORA_PM - 1) / LORA_PM;
+                if (p.lora_a_all) {
+                    if (tid < p.lora_groups) __hip_atomic_store(p.lora_flags + tid * npb + tm, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (tid == 0) {
+                    __hip_atomic_store(p.lora_flags + pgi * npb + tm, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             };
-            if (p.lora_r == 32) producer_loop(std::integral_constant<int, 1>{});
-            else if (p.lora_r == 64) producer_loop(std::integral_constant<int, 2>{});
-            else if constexpr (WI >= 4) producer_loop(std::integral_constant<int, 4>{});  // ranks 96 / 128 (zero-padded to 128 rows by the host)
+            switch (Nw / 32) {  // 32-rank blocks of the streamed weight operand
+                case 1: producer_loop(std::integral_constant<int, 1>{}); break;
+                case 2: producer_loop(std::integral_constant<int, 2>{}); break;
+                case 3: producer_loop(std::integral_constant<int, 3>{}); break;
+                default:
+                    if constexpr (BN >= 128) producer_loop(std::integral_constant<int, 4>{});  // (the host routes such launches to the 128-column tiles)
+                    break;
+            }
             return;
         }
     }
@@ -1474,6 +1496,7 @@ extern int g_pf_blocks;  // default number of prefetch workgroups when the calle
 extern int g_pf_mode;    // 1 = plain loads, 2 = non-temporal
 extern int g_tile;       // 0 = heuristic / caller's hint, 1..6 = force a tile configuration (probing / A-B runs)
 extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS pipeline depth
+extern int g_lora_dbg;   // probing: see GemmP::lora_dbg
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
@@ -1529,7 +1552,8 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     q.pf_blocks = (q.pf_blocks + 7) / 8 * 8;  // a multiple of 8: compute block b still lands on XCD b % 8
     if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
     q.pf_mode = g_pf_mode;
-    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
+    q.lora_dbg = g_lora_dbg;
+    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * (q.lora_a_all ? 1 : q.lora_groups) + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
     const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), (q.ln_stats || XATT || LORA) ? LDS : LDS - BM * 8, stream, q);
@@ -1582,7 +1606,7 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
         if (p.xa.nstream) return launch_cfg<T, 128, 128, 2, 2, false, 2, 1, false, 0, true>(p, stream);  // cross-attention epilogue: the tile that holds 128 queries x 2 heads
     }
     if (p.lora_b) {  // in-launch LoRA: the 4-wave tiles, two LDS stages; a stacked rank above 64 needs the 128-column tiles (the producers stage R weight rows)
-        if (p.lora_r > 64 && (tile == 2 || tile == 4)) tile = tile == 2 ? 1 : 3;
+        if ((p.lora_r > 64 || (p.lora_a_all && p.lora_groups * p.lora_r > 96)) && (tile == 2 || tile == 4)) tile = tile == 2 ? 1 : 3;
         if constexpr (CONV) {
             return tile == 1 ? launch_cfg<T, 128, 128, 2, 2, true, 2, 1, true>(p, stream) : launch_cfg<T, 64, 128, 2, 2, true, 2, 1, true>(p, stream);
         } else {

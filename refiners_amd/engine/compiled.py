@@ -292,6 +292,7 @@ class CompiledSDXL:
     def condition_scale(self, value: float) -> None:  # baked into the device coefficient table: rebuild it on the next set_inputs / step
         self._condition_scale = value
         self.coef_table = None
+        self.graph = None  # self-attention guidance bakes sag.scale / condition_scale into the captured launches as a host scalar
 
     @property
     def solver(self) -> Any:
@@ -372,7 +373,9 @@ class CompiledSDXL:
             tail()
             native.cfg_ddim_step(self.x, io.out, self.coef)
             return self.x
-        gkey = (eng.key, None if self.engine2 is None or sag is None else self.engine2.key)
+        # everything a captured graph holds by value or by address: both programs, and for self-attention guidance the host-side ratio
+        # sag.scale / condition_scale and the blur weights' tensor (kernel_size, sigma)
+        gkey = (eng.key, None if self.engine2 is None or sag is None else (self.engine2.key, float(sag.scale) / float(self.condition_scale), int(sag.kernel_size), float(sag.sigma)))
         if self.graph is None or self.graph_key != gkey:
             keep = self.x.clone()
             self._fill()
@@ -411,9 +414,14 @@ class CompiledSDXL:
             self.engine2 = CompiledUNet(self.unet, use_graph=False, lora_mode=self.engine.lora_mode)
             self.engine2.sag_capture = False  # the reference recomputes (and discards) the attention map in this pass
         e2 = self.engine2
-        half = lambda t: None if t is None else t[: t.shape[0] // 2]  # noqa: E731 -- [negative ; conditional] stacks -> negative half
-        got2 = {"timestep": got["timestep"], "pooled": half(got["pooled"]), "time_ids": half(got["time_ids"]), "tokens": {k: half(v) for k, v in got["tokens"].items()},
-                "conditions": {}, "t2i": {}}
+        # [negative ; conditional] stacks -> negative half.  The views are made once per set_inputs: a fresh view per step would look like a
+        # new prompt to engine2 (_ident keys on id()) and re-run its whole prologue (text / image K, V projections) every step.
+        halves = getattr(self, "_sag_halves", None)
+        if halves is None or halves[0] is not self.inputs:
+            half = lambda t: None if t is None else t[: t.shape[0] // 2]  # noqa: E731
+            halves = (self.inputs, {"pooled": half(got["pooled"]), "time_ids": half(got["time_ids"]), "tokens": {k: half(v) for k, v in got["tokens"].items()}})
+            self._sag_halves = halves
+        got2 = {"timestep": got["timestep"], **halves[1], "conditions": {}, "t2i": {}}
         x = self.x
         if e2.prepare_explicit((n,) + tuple(x.shape[1:]), x.device, got2):
             e2.run_prologue()
@@ -443,7 +451,11 @@ class CompiledSDXL:
         if getattr(self.solver, "needs_noise", None) is not None and self.solver.needs_noise(step):
             # LCMSolver re-noises the consistency estimate (solvers/lcm.py:143-150): same draw as the reference (shape, device,
             # dtype, generator), placed in the kernel's history slot whose coefficient is the next timestep's noise std
-            noise = torch.randn(tuple(self.x.shape), generator=getattr(self, "generator", None), device=self.x.device, dtype=self.x.dtype)
+            # drawn where and as what the reference draws it (solvers/lcm.py:143-150: the SOLVER's device and dtype), so that the same
+            # generator and seed give the same stream; then cast / moved into the history slot
+            sdev = getattr(self.solver, "device", self.x.device)
+            sdt = getattr(self.solver, "dtype", self.x.dtype)
+            noise = torch.randn(tuple(self.x.shape), generator=getattr(self, "generator", None), device=sdev, dtype=sdt)
             self.hist.copy_(noise)
         if not self.primed or self.primed_key != eng.key:  # first step of a trajectory, or the engine re-lowered into new buffers
             self._fill()  # cat(x, x) ...

@@ -375,7 +375,7 @@ class Lowering:
                 acc = w.detach().to(device=self.device, dtype=torch.float32).clone()
                 for d, u, sc in zip(downs, ups, scales):
                     _expect(tuple(d.shape)[1] == k_in and tuple(u.shape)[0] == n_out, "LoRA shape does not match its target")
-                    acc.addmm_(u.detach().to(self.device, torch.float32), d.detach().to(self.device, torch.float32), alpha=sc)
+                    acc = self._mm(u.detach().to(self.device, torch.float32) * sc, d.detach().to(self.device, torch.float32).t(), res=acc)  # acc + s B A
                 acc = acc.to(self.dtype)
                 return acc[perm].contiguous() if perm is not None else acc.contiguous()
 
@@ -429,7 +429,8 @@ class Lowering:
             def merge_conv() -> Tensor:
                 acc = w.detach().to(device=self.device, dtype=torch.float32).clone()
                 for d, u, sc in zip(dws, uws, scs):  # (B A)[o, i, ky, kx] = sum_r B[o, r] A[r, i, ky, kx]
-                    acc += sc * torch.einsum("or,rikl->oikl", u.detach().to(self.device, torch.float32)[:, :, 0, 0], d.detach().to(self.device, torch.float32))
+                    d32 = d.detach().to(self.device, torch.float32)
+                    acc = self._mm(u.detach().to(self.device, torch.float32)[:, :, 0, 0] * sc, d32.reshape(d32.shape[0], -1).t(), res=acc.reshape(o, -1)).reshape(acc.shape)
                 return native.pack_conv_weight(acc.to(self.dtype))
 
             wp = self.cache.get(("merged_conv",) + PackCache.ident(w, *dws, *uws) + scs, merge_conv)
@@ -473,6 +474,14 @@ class Lowering:
         return ConvSpec(wp, self._w(leaf.bias), i, o, kh, leaf.stride[0], lora, time, asym)
 
     # -- emitters: GEMM family -------------------------------------------------------------------------------
+    def _mm(self, x: Tensor, w: Tensor, res: Optional[Tensor] = None) -> Tensor:
+        """x [M, K] @ w [N, K]^T (+ res), float32: weight preparation at lowering time, on the library's own f32 MFMA kernel where there is
+        a GPU (native.matmul_f32), plain torch on the meta / CPU devices of the dry-lowering tests."""
+        if self.device.type == "cuda":
+            return native.matmul_f32(x.contiguous(), w.contiguous(), None if res is None else res.contiguous())
+        y = x @ w.t()
+        return y if res is None else y + res
+
     def lora_sync(self, groups: int, M: int, R: int) -> tuple:
         """(t scratch, flags, LoraSync) of one in-launch LoRA site (native._lora_fill); the first site of a program puts the epoch bump at
         the program's head.  The scratch comes from the pool (give it back with pool.put once the launch is recorded); flags are the site's own."""
@@ -552,7 +561,7 @@ class Lowering:
             ls = wl.to(torch.float32).sum(dim=1).contiguous()
             lc = torch.zeros(w32.shape[0], device=self.device, dtype=torch.float32)
             if node.bias is not None:
-                lc = w32 @ node.bias.detach().to(self.device, torch.float32)
+                lc = self._mm(w32, node.bias.detach().to(self.device, torch.float32).unsqueeze(0)).reshape(-1)
             if spec.b is not None:
                 lc = lc + spec.b.detach().to(self.device, torch.float32)
             return wl, ls, lc.contiguous()
@@ -574,7 +583,7 @@ class Lowering:
             g32 = node.weight.detach().to(self.device, torch.float32)
             al = (a32 * g32.unsqueeze(0)).to(self.dtype).contiguous()
             ls = al.to(torch.float32).sum(dim=1).contiguous()
-            lc = (a32 @ node.bias.detach().to(self.device, torch.float32)).contiguous() if node.bias is not None else torch.zeros_like(ls)
+            lc = self._mm(a32, node.bias.detach().to(self.device, torch.float32).unsqueeze(0)).reshape(-1).contiguous() if node.bias is not None else torch.zeros_like(ls)
             return native.KBlocked(al), ls, lc
 
         return self.cache.get(key, make)

@@ -173,11 +173,16 @@ class SAMLowering(Lowering):
             E2 = node.horizontal_embedding.detach().to(**f).flip(0)  # second grid axis
             wqp, bqp = torch.zeros(H, Lp, C, **f), torch.zeros(H, Lp, **f)
             wqp[:, :d], bqp[:, :d] = Wq * d ** -0.5, bq * d ** -0.5
-            wqp[:, d:o1], bqp[:, d:o1] = torch.einsum("rd,hdc->hrc", E1, Wq), torch.einsum("rd,hd->hr", E1, bq)
-            wqp[:, o1:o2], bqp[:, o1:o2] = torch.einsum("rd,hdc->hrc", E2, Wq), torch.einsum("rd,hd->hr", E2, bq)
+            # P_e[h][r][c] = sum_d E_e[r][d] Wq[h][d][c] (and the same with the bias as one more column): per head a small matrix product, on
+            # the library's own float32 kernel (Lowering._mm) like every other piece of weight preparation
+            Wqb = torch.cat([Wq, bq.unsqueeze(-1)], dim=-1)  # [H, d, C + 1]
+            for E, lo, hi in ((E1, d, o1), (E2, o1, o2)):
+                for h in range(H):
+                    pe = self._mm(E, Wqb[h].t())  # [r, C + 1]
+                    wqp[h, lo:hi], bqp[h, lo:hi] = pe[:, :C], pe[:, C]
             wkp, bkp = torch.zeros(H, Dq, C, **f), torch.zeros(H, Dq, **f)
             wkp[:, :d], bkp[:, :d] = Wk, bk
-            bo = out.w.detach().to(**f) @ bv + (out.b.detach().to(**f) if out.b is not None else 0)
+            bo = self._mm(out.w.detach().to(**f), bv.unsqueeze(0)).reshape(-1) + (out.b.detach().to(**f) if out.b is not None else 0)
             c = lambda t: t.to(self.dtype).contiguous()  # noqa: E731
             return dict(wqp=c(wqp.view(H * Lp, C)), bqp=c(bqp.view(-1)), wkp=c(wkp.view(H * Dq, C)), bkp=c(bkp.view(-1)), wv=c(Wv), bo=c(bo))
 

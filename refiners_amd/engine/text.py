@@ -86,7 +86,7 @@ class TextLowering(Lowering):
             def fold() -> Tensor:
                 if self.device.type == "meta":
                     return torch.empty(C, device=self.device, dtype=self.dtype)
-                acc = os_.w.float() @ vs.b.float()
+                acc = self._mm(os_.w.float(), vs.b.float().unsqueeze(0)).reshape(-1)
                 return (acc + os_.b.float() if os_.b is not None else acc).to(self.dtype).contiguous()
 
             bo = self.cache.get(("clip_bo",) + PackCache.ident(os_.w, os_.b, vs.b), fold)

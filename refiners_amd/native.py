@@ -140,6 +140,7 @@ class GemmArgs(C.Structure):
         ("stats_out", C.c_void_p),
         ("out_f32", C.c_int32),
         ("lora_a", C.c_void_p * 3),
+        ("lora_a_all", C.c_void_p),
         ("lora_nb", C.c_int32 * 3),
         ("lora_groups", C.c_int32),
         ("lora_r", C.c_int32),
@@ -407,6 +408,41 @@ class recording:
         _recorder = self._saved
 
 
+class not_recording:
+    """Context manager: native calls made inside are LAUNCHED even while a program is being recorded (weight preparation at lowering time)."""
+
+    def __enter__(self) -> None:
+        global _recorder
+        self._saved = _recorder
+        _recorder = None
+
+    def __exit__(self, *exc: object) -> None:
+        global _recorder
+        _recorder = self._saved
+
+
+def matmul_f32(x: Tensor, w: Tensor, res: Optional[Tensor] = None) -> Tensor:
+    """x [M, K] @ w [N, K]^T (+ res) in float32 on the library's own f32 MFMA path (v_mfma_f32_16x16x4_f32), launched at once.  For the
+    set-up arithmetic of the engine (LoRA merges, LayerNorm folding): no vendor BLAS inside the product package.  K is zero-padded to the
+    kernel's 32-float granularity."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.dtype == torch.float32 and w.dtype == torch.float32
+    Kp = (K + 31) // 32 * 32
+
+    def prep(t: Tensor) -> Tensor:
+        if Kp == K and t.is_contiguous() and t.data_ptr() % 16 == 0:
+            return t
+        p = torch.zeros(t.shape[0], Kp, dtype=torch.float32, device=t.device)
+        p[:, :K] = t
+        return p
+
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    with not_recording():
+        gemm([(prep(x), prep(w))], out, res=res)
+    return out
+
+
 _side_depth = 0
 _side_streams: dict[int, "torch.cuda.Stream"] = {}
 SIDE = "@side"  # suffix of the name of a recorded launch that runs on the side stream
@@ -572,6 +608,15 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
         assert isinstance(la, KBlocked) and la.shape == (R, K) and la.dtype == dtype, (la.shape, R, K)
         a.lora_a[g], a.lora_nb[g] = la.data_ptr(), nb
     a.lora_groups, a.lora_r, a.lora_b = len(groups), R, lb.data_ptr()
+    if len(groups) > 1 and len(groups) * R <= LORA_RMAX:
+        # one producer set for all groups: their down rows stacked into one K-blocked operand (cached on the first group's pack)
+        la0 = groups[0][1]
+        key = tuple(id(la) for _, la in groups)
+        merged = getattr(la0, "_stacked", None)
+        if merged is None or merged[0] != key:
+            merged = (key, KBlocked(torch.cat([la.dense() for _, la in groups], 0).contiguous()))
+            la0._stacked = merged
+        a.lora_a_all = merged[1].data_ptr()
     if len(lora) > 2:  # LayerNorm folded into this launch as well
         ls_, lc_ = lora[2], lora[3]
         assert ln_given and ls_.dtype == torch.float32 and lc_.dtype == torch.float32 and ls_.is_contiguous() and lc_.is_contiguous()

@@ -46,6 +46,10 @@ def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     rank = dist.get_rank()
+    tensors = list(tensors)
+    # every rank must walk the SAME list (count, shapes, dtypes, device kinds): arena offsets and the number of collectives follow
+    # from it, so a mismatch would hang or silently shift weights.  Compared against the source's manifest before anything moves.
+    check_same_on_all_ranks([(tuple(t.shape), str(t.dtype), t.device.type) for t in tensors], "broadcast_tensors: tensor list", src)
     groups: dict[tuple[torch.dtype, torch.device], list[Tensor]] = {}
     for t in tensors:
         groups.setdefault((t.dtype, t.device), []).append(t)
@@ -68,6 +72,32 @@ def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int
             dist.broadcast(arena[lo : min(lo + per, total)], src=src)
             launches += 1
     return launches
+
+
+def check_same_on_all_ranks(value: Any, what: str, src: int = 0) -> None:
+    """Raise on EVERY rank when any rank's `value` (a small picklable description) differs from the source's."""
+    import hashlib
+    import pickle
+
+    mine = hashlib.sha256(pickle.dumps(value)).hexdigest()
+    box = [mine]
+    dist.broadcast_object_list(box, src=src)
+    ok = [None] * dist.get_world_size()
+    dist.all_gather_object(ok, box[0] == mine)
+    if not all(ok):
+        bad = [r for r, o in enumerate(ok) if not o]
+        raise RuntimeError(f"{what} differs from rank {src}'s on ranks {bad}")
+
+
+def propagate_failure(exc: BaseException | None, what: str) -> None:
+    """Collective: when any rank passes an exception, every rank raises (the failing one re-raises its own)."""
+    msgs: list[Any] = [None] * dist.get_world_size()
+    dist.all_gather_object(msgs, None if exc is None else f"{type(exc).__name__}: {exc}")
+    if exc is not None:
+        raise exc
+    bad = [(r, m) for r, m in enumerate(msgs) if m is not None]
+    if bad:
+        raise RuntimeError(f"{what} failed on rank {bad[0][0]}: {bad[0][1]}")
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 512 << 20) -> int:
@@ -93,15 +123,38 @@ def load_and_broadcast(module: torch.nn.Module, tensors_path: Any, device: torch
     Returns the number of collective launches (0 in a single-process run)."""
     from safetensors.torch import load_file
 
+    multi = dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if rank == src:
-        state = load_file(str(tensors_path), device=str(device))
-        want = module.state_dict()
-        cast = {k: (v if k not in want or v.dtype == want[k].dtype else v.to(want[k].dtype)) for k, v in state.items()}
-        module.load_state_dict(cast, strict=strict, assign=True)
-    else:
-        module.to_empty(device=device)
+    err: BaseException | None = None
+    try:
+        if rank == src:
+            state = load_file(str(tensors_path), device=str(device))
+            want = module.state_dict()
+            cast = {k: (v if k not in want or v.dtype == want[k].dtype else v.to(want[k].dtype)) for k, v in state.items()}
+            module.load_state_dict(cast, strict=strict, assign=True)
+            # strict=False / a tree that was not built on meta: whatever the file did not cover must end up on `device` too, or the
+            # source's tensor list (and with it the arena layout) would differ from the receivers'
+            _materialise(module, torch.device(device))
+        else:
+            module.to_empty(device=device)
+    except BaseException as e:  # noqa: BLE001 -- a source-only failure (missing file, strict mismatch) must not leave the others in the collective
+        if not multi:
+            raise
+        err = e
+    if multi:
+        propagate_failure(err, "load_and_broadcast")
     return broadcast_module(module, src=src)
+
+
+def _materialise(module: torch.nn.Module, device: torch.device) -> None:
+    """Every parameter / buffer still on meta gets (uninitialised) storage on `device`; anything on another device moves there."""
+    for mod in module.modules():
+        for store in (mod._parameters, mod._buffers):
+            for name, t in list(store.items()):
+                if t is None or t.device == device:
+                    continue
+                new = torch.empty_like(t, device=device) if t.device.type == "meta" else t.detach().to(device)
+                store[name] = torch.nn.Parameter(new, requires_grad=t.requires_grad) if isinstance(t, torch.nn.Parameter) else new
 
 
 def shard_range(n_items: int, rank: int, world: int) -> range:

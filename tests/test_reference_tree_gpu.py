@@ -61,6 +61,7 @@ def _build(case):
 
 @pytest.mark.parametrize("case", ["sdxl_bare", "sdxl_lora_ip", "sdxl_control", "sdxl_conv_lora"])
 def test_compiled_unet_on_the_real_refiners_tree(gpu_device, case):
+    _api()
     from refiners.foundationals.latent_diffusion.solvers import DDIM
 
     from refiners_amd.engine.compiled import CompiledUNet
@@ -134,6 +135,7 @@ def test_the_proposed_binding_on_refiners_own_stable_diffusion_xl(gpu_device, ca
     """INTEGRATION.md section 1 executed: refiners' LatentDiffusionModel.forward (model.py:128-159: set_unet_context, cat(x, x),
     scale_model_input, unet(latents).chunk(2), CFG combine, solver step) runs unchanged with its `self.unet(latents)` bound to
     CompiledUNet; the result is the reference's own x_next."""
+    api = _api()
     from refiners.foundationals.latent_diffusion.solvers import DDIM
     from refiners.foundationals.latent_diffusion.stable_diffusion_xl.model import StableDiffusion_XL
 
@@ -141,7 +143,6 @@ def test_the_proposed_binding_on_refiners_own_stable_diffusion_xl(gpu_device, ca
     from tests import support as S
 
     cfg, unet, specs, inp = _build(case)
-    api = _api()
     sdxl = StableDiffusion_XL(unet=unet, lda=api.fl.Identity(), clip_text_encoder=api.fl.Identity(), solver=DDIM(num_inference_steps=cfg["num_steps"]),
                               device="cuda", dtype=torch.float32)
     fast = CompiledUNet(sdxl.unet)

@@ -1,0 +1,117 @@
+"""Where the in-launch LoRA's time goes, per shape class of the SDXL step (hot weights, HIP graph of N launches, bf16):
+  plain      the un-adapted launch (what lora_mode="merged" runs)
+  full       producers + tiles, epoch bumped before every launch (what lora_mode="fused" runs)
+  nowait     the same launches WITHOUT the bump: the flags still hold the epoch, no tile ever waits (producers still run)
+  tail       nowait + producers exit at once (mi355x_set_option lora_dbg 1): only the tiles' hand-off + up-projection remain
+  bump+plain the un-adapted launch behind a bump kernel (the extra launch boundary `full` pays in this probe, not in the engine)."""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+from refiners_amd import native  # noqa: E402
+
+dev, dt = "cuda", torch.bfloat16
+N_LAUNCH = 24
+
+
+def graph_time(fn, iters=20):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / iters / N_LAUNCH * 1e3)
+    return best  # us per launch
+
+
+def case(M, K, N, *, geglu=False, ln=False, qkv=False, tile=0, ranks=(16, 16)):
+    x = torch.randn(M, K, device=dev).to(dt)
+    w = native.KBlocked((torch.randn(N, K, device=dev) * K ** -0.5).to(dt))
+    R = native.lora_rank(sum(ranks))
+    groups = 3 if qkv else 1
+    a = [native.KBlocked((torch.randn(R, K, device=dev) * K ** -0.5).to(dt)) for _ in range(groups)]
+    bs = (torch.randn(N, R, device=dev) * 0.1).to(dt)
+    out = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=dt)
+    kw = {}
+    lo_extra = ()
+    if ln:
+        stats = torch.zeros(K // 32, M, 2, device=dev)
+        stats[..., 1] = 32.0
+        kw["ln"] = (stats, torch.randn(N, device=dev), torch.randn(N, device=dev), 1e-5)
+        lo_extra = (torch.randn(groups * R, device=dev), torch.randn(groups * R, device=dev))
+    vt = None
+    if qkv:
+        C = N // 3
+        out = torch.empty(M, 2 * C, device=dev, dtype=dt)
+        vt = torch.empty(C, M, device=dev, dtype=dt)
+        kw.update(out_t=vt, nt_begin=2 * C)
+        lgroups = [(0, a[0]), (C, a[1]), (2 * C, a[2])]
+    else:
+        lgroups = [(0, a[0])]
+    sync = native.LoraSync(torch.device(dev))
+    t, flags = sync.scratch(groups, M, R, dt), sync.flags(groups, M)
+    lora = (lgroups, bs) + lo_extra
+    bias = None if ln else torch.randn(N, device=dev).to(dt)
+
+    def plain():
+        for _ in range(N_LAUNCH):
+            native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, **kw)
+
+    def bump_plain():
+        for _ in range(N_LAUNCH):
+            sync.bump()
+            native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, **kw)
+
+    def full():
+        for _ in range(N_LAUNCH):
+            sync.bump()
+            native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, lora=lora, lora_sync=(t, flags, sync), **kw)
+
+    def nowait():
+        for _ in range(N_LAUNCH):
+            native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, lora=lora, lora_sync=(t, flags, sync), **kw)
+
+    lib = native.load()
+    res = {}
+    res["plain"] = graph_time(plain)
+    res["bump+plain"] = graph_time(bump_plain)
+    res["full"] = graph_time(full)
+    sync.bump()
+    native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, lora=lora, lora_sync=(t, flags, sync), **kw)  # flags now hold the epoch
+    torch.cuda.synchronize()
+    res["nowait"] = graph_time(nowait)
+    lib.mi355x_set_option(b"lora_dbg", 1)
+    res["tail"] = graph_time(nowait)
+    lib.mi355x_set_option(b"lora_dbg", 0)
+    fl = 2.0 * M * K * N
+    print(f"M={M} K={K} N={N} geglu={int(geglu)} ln={int(ln)} qkv={int(qkv)} tile={tile} R={R}: " + "  ".join(f"{k} {v:6.2f} us" for k, v in res.items())
+          + f"   | plain {fl / res['plain'] / 1e6:.0f} TF, full-(bump+plain) = {res['full'] - res['bump+plain']:+.2f} us", flush=True)
+
+
+def main():
+    native.load()
+    for tile in (0, 1):
+        case(2048, 1280, 1280, tile=tile)
+    case(2048, 1280, 1280, ln=True)
+    case(2048, 1280, 3840, ln=True, qkv=True)
+    case(2048, 1280, 10240, geglu=True, ln=True)
+    case(2048, 5120, 1280)
+    case(8192, 640, 640)
+    case(2048, 1280, 1280, ranks=(128,))
+
+
+if __name__ == "__main__":
+    main()
