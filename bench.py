@@ -31,6 +31,7 @@ import torch  # noqa: E402
 
 STEP_TFLOP = {"bare": 13.522, "lora_ip": 13.895, "control": 19.563}  # algorithmic FLOPs of one CFG-pair UNet forward
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0     # HBM3E peak of the same guide (6.3 TB/s is what a float4 copy reaches)
 LATENT = (128, 128)
 
 
@@ -92,7 +93,7 @@ def pmc_mfma_util(family: str):
         fam = doc["families"][family]
         return {"mfma_util": round(fam["mfma_util"], 4), "SQ_VALU_MFMA_BUSY_CYCLES": fam["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": fam["GRBM_GUI_ACTIVE"],
                 "definition": "fraction of GPU-active time with the matrix pipes busy: counter ratio anchored on a calibration launch of known MFMA count (see the file)",
-                "source": f"profiles/{f.name}"}
+                "scope": doc.get("scope", "whole process"), "source": f"profiles/{f.name}"}
     except Exception:  # noqa: BLE001 -- no committed pass
         return None
 
@@ -120,9 +121,10 @@ def pmc_traffic(family: str):
     separate profiler runs, they cannot be taken inside this process): FETCH_SIZE doubled per MI355X_MICROARCH.md, KiB -> B."""
     try:
         f = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]  # the latest committed pass
-        fam = json.loads(f.read_text())["families"][family]
+        doc = json.loads(f.read_text())
+        fam = doc["families"][family]
         return {"fetch_bytes_per_launch": round(fam["FETCH_SIZE"]["bytes_per_launch"]), "write_bytes_per_launch": round(fam["WRITE_SIZE"]["bytes_per_launch"]),
-                "source": f"profiles/{f.name}"}
+                "scope": doc.get("scope", "whole process"), "source": f"profiles/{f.name}"}
     except Exception:  # noqa: BLE001 -- no committed PMC pass for this family
         return None
 
@@ -189,16 +191,17 @@ def timed_steps(pipe, steps: int, warmup: int, world: int, dev: torch.device) ->
     """W untimed steps, then exactly K steps between barrier + synchronize pairs; seconds, max over ranks."""
     from refiners_amd import parallel
 
+    sync = torch.cuda.synchronize if torch.device(dev).type == "cuda" else (lambda: None)  # (CPU: the gloo dry run of tests/test_parallel_cpu.py)
     for i in range(warmup):
         pipe.step(i % 50)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    sync()
     t1 = time.perf_counter()
     for i in range(steps):
         pipe.step(i % 50)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         torch.distributed.barrier()
     return parallel.max_over_ranks(time.perf_counter() - t1, device=dev)
@@ -217,6 +220,34 @@ def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict
         fl = sum(op_flops(e) for e in ops)
         fam[name] = {"launches": len(ops), "ms": round(sec * 1e3, 4), "avg_us": round(sec / len(ops) * 1e6, 2), "tflop": round(fl / 1e12, 4),
                      "tflops": round(fl / sec / 1e12, 1) if fl else None}
+    # GroupNorm (three HBM-bound kernels per call: partial sums, finalize, apply + SiLU): algorithmic bytes = two reads + one write of the tensor
+    gn_ops = groups.get("mi355x_groupnorm", [])
+    if gn_ops:
+        gbytes = sum(3.0 * a.B * a.HW * a.C * (4 if a.dtype == 0 else 2) for a in (e[1][0]._obj for e in gn_ops))
+        gsec = fam["mi355x_groupnorm"]["ms"] * 1e-3
+        fam["mi355x_groupnorm"].update(algorithmic_gb=round(gbytes / 1e9, 4), hbm_gbps=round(gbytes / gsec / 1e9, 1), frac_of_hbm_peak=round(gbytes / gsec / 1e9 / PEAK_HBM_GBPS, 4))
+    # the five shape classes that take the most time, each replayed on its own (entry point + shape = the key of profiles/*_inplace_by_shape.md)
+    classes: dict[str, list] = {}
+    for e in low.step:
+        if e[0] is not None and op_flops(e):
+            classes.setdefault(program_entry(e)["key"], []).append(e)
+    cls = []
+    for key, ops in classes.items():
+        fl = sum(op_flops(e) for e in ops)
+        cls.append((key, ops, fl))
+    timed = []
+    for key, ops, fl in sorted(cls, key=lambda c: -c[2])[:8]:  # by FLOPs first (cheap), then timed
+        sec = time_ops(ops, iters=3)
+        timed.append({"class": key, "launches": len(ops), "ms": round(sec * 1e3, 4), "avg_us": round(sec / len(ops) * 1e6, 2), "tflops": round(fl / sec / 1e12, 1),
+                      "frac": round(fl / sec / 1e12 / PEAK_BF16_TFLOPS, 4)})
+    top_classes = sorted(timed, key=lambda c: -c["ms"])[:5]
+    try:  # the matrix-pipe utilisation of the same classes from the latest committed counter pass (step program only)
+        pm = json.loads(sorted((ROOT / "profiles").glob("r*_pmc_mfma.json"))[-1].read_text()).get("classes", {})
+        for c in top_classes:
+            if c["class"] in pm:
+                c["mfma_util_pmc"] = round(pm[c["class"]]["mfma_util"], 4)
+    except Exception:  # noqa: BLE001 -- no committed pass
+        pass
     dom = max((n for n in fam if fam[n]["tflop"]), key=lambda n: fam[n]["ms"])
     executed_tflop = sum(f["tflop"] for f in fam.values())
     algo = STEP_TFLOP[workload] * n_img
@@ -226,7 +257,7 @@ def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict
         "traffic": pmc_traffic(dom), "mfma_util": pmc_mfma_util(dom),
         "step": {"algorithmic_tflop": algo, "executed_tflop": round(executed_tflop, 3), "achieved": round(algo / (ms_per_step * 1e-3), 1),
                  "frac": round(algo / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)},
-        "families": fam,
+        "families": fam, "top_classes": top_classes,
     }
 
 
@@ -260,6 +291,29 @@ def cpu_baseline_step(bare_sd: dict, specs: dict, workload: str, threads: int) -
             "sample": "1 of the 50 DDIM steps of one 1024x1024 image (CFG pair) of this workload; images/s extrapolated x50"}
 
 
+def sam_point(dev: torch.device, dtype: torch.dtype) -> dict:
+    """configs[4]: SAM ViT-H image encoder with the HQ-SAM early-embedding hook on one 1024x1024 image (random-init weights in HBM)."""
+    from refiners_amd.engine.sam import CompiledSAMViT
+    from refiners_amd.segment_anything import SAMViTAdapter, SAMViTH
+
+    vit = SAMViTH(device="meta")
+    gpu_weights(vit, seed=11, dtype=dtype, device=dev)
+    ad = SAMViTAdapter(vit).inject()
+    ad.set_context("hq_sam", {"early_vit_embedding": None})
+    x = torch.rand(1, 3, 1024, 1024, device=dev).to(dtype)
+    fast = CompiledSAMViT(vit)
+    with torch.no_grad():
+        y = fast(x)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(5):
+            fast(x)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / 5 * 1e3
+    return {"workload": "SAM ViT-H image encoder + HQ-SAM hook, 1x3x1024x1024", "ms_per_image": round(ms, 3), "algorithmic_tflop": 5.96, "tflops": round(5.96 / (ms * 1e-3), 1),
+            "launches": fast.stats["step_ops"], "fallback_nodes": fast.stats["fallback_nodes"], "output_finite": bool(torch.isfinite(y.float()).all())}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,8 +328,9 @@ def main() -> None:
     ap.add_argument("--no-extra", action="store_true", help="skip the informational extras (configs[1] line, fused-LoRA line, VAE decode, 4-images-per-GPU point)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-family replay (profiler passes: the kernel table then holds the timed steps only)")
     ap.add_argument("--dump-program", default=None, help="write the recorded step program (one entry per launch: entry point + shape class) as JSON: tools/profile_round.py")
-    ap.add_argument("--lora-mode", choices=["fused", "merged"], default="merged",
-                    help="merged: W' = W + sum s B A formed at lowering time (one launch per adapted layer); fused: run-time LoRA inside the parent launch")
+    ap.add_argument("--lora-mode", choices=["fused", "merged"], default="fused",
+                    help="fused (default, the engine's default and the north star's kernel): run-time LoRA inside the parent launch, adapters stay live; "
+                         "merged: W' = W + sum s B A formed at lowering time (reported under extra.lora_mode_merged)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -394,6 +449,25 @@ def main() -> None:
                 del pipe4
             except Exception as exc:  # noqa: BLE001
                 extra["throughput_operating_point"] = f"failed: {type(exc).__name__}: {exc}"
+
+    if world == 1 and n_img == 1 and not args.no_extra:
+        # ---- BASELINE configs[3]'s per-GPU shape: ControlLora (canny), 4 prompts per GPU (UNet batch 8) ------------------------------
+        try:
+            unet_c, _, _, pipe_c, _ = build_pipeline("control", 4, rank, dev, dtype, args.lora_mode, use_graph, broadcast=False)
+            sc = timed_steps(pipe_c, 6, 2, 1, dev)
+            msc = sc / 6 * 1e3
+            extra["configs3_per_gpu_shape"] = {"workload": "SDXL-base + ControlLora (canny), 4 images per GPU (32 prompts over 8 GPUs)", "ms_per_step": round(msc, 3),
+                                               "images_per_s": round(4 / (msc * 1e-3 * 50), 4), "launches_per_step": pipe_c.engine.stats["step_ops"],
+                                               "step_tflops": round(4 * STEP_TFLOP["control"] / (msc * 1e-3), 1), "fallback_nodes": pipe_c.engine.stats["fallback_nodes"]}
+            del pipe_c, unet_c
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001
+            extra["configs3_per_gpu_shape"] = f"failed: {type(exc).__name__}: {exc}"
+        # ---- BASELINE configs[4]: SegmentAnything ViT-H image encoder + HQ-SAM hook, 1024x1024, bf16 ---------------------------------
+        try:
+            extra["configs4_sam_vit_h"] = sam_point(dev, dtype)
+        except Exception as exc:  # noqa: BLE001
+            extra["configs4_sam_vit_h"] = f"failed: {type(exc).__name__}: {exc}"
 
     line = {
         "metric": "sdxl_base_1024px_images_per_sec_50_ddim_steps", "value": round(images_per_s, 4), "unit": "images/s",

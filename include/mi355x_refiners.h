@@ -174,9 +174,6 @@ typedef struct {
        With ln_stats (x un-normalised): lora_a carries gamma like w does (A' = A . diag(gamma)) and the caller adds
          lora_ls[g][r] = sum_k A'_g[r][k],   lora_lc[g][r] = sum_k beta[k] A_g[r][k]        (float32, [groups][lora_r]). */
     const void* lora_a[3];
-    const void* lora_a_all; /* optional, lora_groups >= 2 and lora_groups * lora_r <= 128: the down rows of ALL groups stacked group after group,
-                               K-blocked [K*sizeof/128][lora_groups * lora_r][128 bytes]; one set of producer workgroups then serves every group
-                               (x is read once instead of once per group).  lora_a[g] must still be given (the same rows, per group). */
     int32_t lora_nb[3];
     int32_t lora_groups;
     int32_t lora_r;

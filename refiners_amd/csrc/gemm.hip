@@ -160,10 +160,6 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
             p.lora_a[g] = static_cast<const char*>(a->lora_a[g]);
             p.lora_nb[g] = a->lora_nb[g];
         }
-        if (a->lora_a_all) {
-            if (a->lora_groups < 2 || a->lora_groups * a->lora_r > mi355x::LORA_RMAX || !aligned16(a->lora_a_all)) return MI355X_ESHAPE;
-            p.lora_a_all = static_cast<const char*>(a->lora_a_all);
-        }
         p.lora_groups = a->lora_groups;
         p.lora_r = a->lora_r;
         p.lora_b = static_cast<const char*>(a->lora_b);

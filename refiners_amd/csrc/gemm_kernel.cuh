@@ -100,8 +100,6 @@ struct GemmP {
     // LoRA inside the launch: per column group g (columns >= lora_nb[g]) the K-blocked stacked down rows, [K blocks][lora_r][128 B];
     // lora_b: [N][lora_r] pre-scaled up-projections (row n = output column n), row-major
     const char* lora_a[3];
-    const char* lora_a_all;  // optional: the down rows of ALL groups stacked, K-blocked [K blocks][groups * lora_r][128 B] (groups * lora_r <= 128):
-                             // one producer per 32 rows then serves every group (a merged Q|K|V launch reads x once instead of three times)
     int lora_nb[3];
     int lora_groups;
     int lora_r;            // stacked rank: 32, 64 or 128
@@ -112,7 +110,8 @@ struct GemmP {
     int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
     const int* lora_epoch;
     int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
-    int lora_dbg;          // probing only (mi355x_set_option "lora_dbg"): bit 0 = producers exit at once (valid only while the flags still hold the epoch)
+    int lora_dbg;          // probing only (mi355x_set_option "lora_dbg", tools/probe_lora.py; timing, not results): 1 = producers exit at once (valid only
+                           // while the flags still hold the epoch), 4 = tiles skip the LoRA term entirely, 8 = in-loop hand-off but no product, 16 = product but no hand-off
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
     const char* pf_ptr[MI355X_MAX_PREFETCH];
@@ -413,10 +412,162 @@ constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of th
 constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)
 constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch (control-lora-*-rank128)
 
-// 8-byte relaxed agent-scope accesses: sc1 (write-through / L1-bypassing) on gfx950, the form the microarchitecture guide lists as valid
-// for an inter-workgroup hand-off without fences ("8-B agent atomics both sides")
+// 8-byte relaxed agent-scope store: sc1 (write-through) on gfx950, the producer half of the hand-off forms the microarchitecture guide lists
+// as valid without fences (write-through payload, vmcnt(0), then the flag)
 MI_DEV void st_agent8(void* p, uint64_t v) { __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-MI_DEV uint64_t ld_agent8(const void* p) { return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- LoRA producer ---------------------------------------------------------------------------------------------------------------
+// t[m0 .. m0 + 32)[0 .. R) = x A_g^T for one (column group, 32-row block), R = 32 RI.  A SEPARATE, non-inlined function called at the very
+// top of gemm_kernel by the workgroups at the head of a LoRA launch's grid: compiled on its own, it does not touch the register allocation
+// or the instruction stream of the tiles' path (inlined, its mere presence cost every tile ~0.8 us: profiles/r03_g_bisect.log).
+// The loop is latency-bound (R / BN of a tile's MFMAs on a quarter of its rows), so the workgroup's LDS ring is re-cut into PST <= 8 stages of
+// (32 x rows + R weight rows) x 128 B, PST - 1 K blocks in flight.  Own loader: one 16-byte piece of x per thread and K block (plain rows,
+// K-blocked rows, or the taps of a convolution gathered from the NHWC image) + RI pieces of the stacked down rows (always K-blocked:
+// [K blocks][R][128 B]; LDS row r = rank r).  Wave w multiplies row block w & 1 against the RI rank blocks (w >> 1) RI ...
+// LayerNorm folded in -> what is published is t / rstd = (x A'^T - mean sA) + cA / rstd (the tile epilogue's rstd * (acc - mean s) + c then
+// scales the up-projected product back: one rounding of t, as in the reference); (mean, M2) of a row = the producer launch's 32-column
+// partials Chan-merged in index order.  t is rounded to T, written through to L2 (8-byte agent-scope stores), then the block's flag.
+template <typename T, bool CONV, int RI, int PST>
+__device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTHR = 256, PXB = LORA_PM * 128, PSTAGE = PXB + 32 * RI * 128, PD = PST - 1, PL = 1 + RI;
+    static_assert(PST >= 2 && PST <= 8, "LoRA producer: 2..8 stages");
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id(), g = lane >> 4, c16 = lane & 15;
+    const int npb = (p.M + LORA_PM - 1) / LORA_PM;
+    const int pgi = q / npb, tm = q - pgi * npb, m0 = tm * LORA_PM;
+    const int tag = *p.lora_epoch;
+    const SegP& sp = p.seg[0];  // the LoRAs adapt segment 0 (the conv / Linear itself, not a fused shortcut)
+    const int nkb = sp.nkb;
+    // ---- this thread's piece of the x tile: row tid >> 3, logical chunk tid & 7 (swizzled source chunk, lane-linear LDS image) ----
+    const int row = tid >> 3, pch = tid & 7;
+    const int xcoff = (pch ^ swz<128>(row)) << 4;
+    const bool xvalid = m0 + row < p.M;
+    const int xm = xvalid ? m0 + row : p.M - 1;
+    int xb = 0, xoy = 0, xox = 0;
+    if constexpr (CONV) {
+        const int ohw = p.OH * p.OW;
+        xb = xm / ohw;
+        const int rem = xm - xb * ohw;
+        xoy = rem / p.OW;
+        xox = rem - xoy * p.OW;
+    }
+    const char* xbase = nullptr;
+    int64_t xoff = 0, woff = 0;
+    const int64_t xstep = CONV ? 128 : (sp.xkb ? (int64_t)p.M * 128 : 128), wstep = (int64_t)p.lora_r * 128;
+    int tap = 0, cb = 0;
+    auto set_tap = [&]() __attribute__((always_inline)) {
+        int dy = tap / sp.ksize, dx = tap - dy * sp.ksize;
+        dy -= sp.pad;
+        dx -= sp.pad;
+        const int iy = xoy * sp.stride + dy, ix = xox * sp.stride + dx;
+        const int HH = sp.H << sp.ups_shift, WW = sp.W << sp.ups_shift;
+        const bool ok = xvalid && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
+        const int sy = iy >> sp.ups_shift, sx = ix >> sp.ups_shift;
+        const int64_t pix = ((int64_t)xb * sp.H + sy) * sp.W + sx;
+        xbase = ok ? sp.x + pix * sp.ldxb + xcoff : nullptr;
+    };
+    if constexpr (CONV) set_tap();
+    else xbase = sp.x + (sp.xkb ? (int64_t)xm * 128 : (int64_t)xm * sp.ldxb) + xcoff;
+    const char* pw[RI];
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        const int qq = j * NTHR + tid, r = qq >> 3, c = qq & 7;
+        pw[j] = p.lora_a[pgi] + (int64_t)r * 128 + ((c ^ swz<128>(r)) << 4);
+    }
+    int kb = 0;
+    auto issue_p = [&](int buf) __attribute__((always_inline)) {
+        char* st = smem + buf * PSTAGE;
+        const char* src;
+        if constexpr (CONV) src = xbase ? xbase + (int64_t)cb * 128 : p.zeros + xcoff;
+        else src = xbase + xoff;
+        glds16(src, st + wid * 64 * 16);
+#pragma unroll
+        for (int j = 0; j < RI; ++j) glds16(pw[j] + woff, st + PXB + (j * NTHR + wid * 64) * 16);
+        ++kb;
+        woff += wstep;
+        if constexpr (CONV) {
+            if (++cb == sp.cpb) {
+                cb = 0;
+                ++tap;
+                if (kb < nkb) set_tap();
+            }
+        } else {
+            xoff += xstep;
+        }
+    };
+    // ---- LayerNorm folded in: (mean, 1 / rstd) of this lane's row 16 rb + c16.  The producer launch's 32-column partials are requested
+    // BEFORE the first stages and merged after their issue: one round trip, overlapped with the stages' (a serial load-merge chain
+    // would be ln_parts dependent L2 round trips at the head of every producer).
+    const int rb = wid & 1, rg = wid >> 1;
+    const int mrow = 16 * rb + c16, m = m0 + mrow;
+    float mean = 0.f, inv = 1.f;
+    constexpr int MAXP = 48;  // partials held in registers at once (K <= 1536 in one batch)
+    f32x2 lst[MAXP];
+    const float* sp2 = p.ln_stats ? p.ln_stats + (int64_t)min(m, p.M - 1) * 2 : nullptr;
+    const int64_t pstride = (int64_t)p.M * 2;
+    if (sp2) {
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) lst[i] = i < p.ln_parts ? *reinterpret_cast<const f32x2*>(sp2 + i * pstride) : f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < PD; ++s0)
+        if (s0 < nkb) issue_p(s0);
+    if (sp2) {
+        float m2 = 0.f, cn = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i)
+            if (i < p.ln_parts) stat_merge(cn, mean, m2, 32.f, lst[i][0], lst[i][1]);
+        for (int part = MAXP; part < p.ln_parts; ++part) {  // wider rows: the slow way
+            const f32x2 s2 = *reinterpret_cast<const f32x2*>(sp2 + part * pstride);
+            stat_merge(cn, mean, m2, 32.f, s2[0], s2[1]);
+        }
+        inv = sqrtf(m2 / cn + p.ln_eps);  // 1 / rstd
+    }
+    f32x4 ta[RI];
+#pragma unroll
+    for (int j = 0; j < RI; ++j) ta[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nkb; ++t) {
+        if (t + PD <= nkb) wait_vm<(PD - 1) * PL>();  // block t has landed, the PD - 1 younger ones stay in flight
+        else wait_vm0();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + PD < nkb) issue_p((t + PD) % PST);  // into the buffer block t - 1 was read from (every wave retired those reads above)
+        const char* st = smem + (t % PST) * PSTAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const frag_t xf = lds_read_frag(st, tile_off<128>(16 * rb + c16, 4 * kk + g));
+#pragma unroll
+            for (int j = 0; j < RI; ++j) {
+                const frag_t af = lds_read_frag(st + PXB, tile_off<128>((rg * RI + j) * 16 + c16, 4 * kk + g));
+                mma_step<T>(ta[j], af, xf);  // D[rank 16 (rg RI + j) + 4 g + r][row 16 rb + c16]
+            }
+        }
+    }
+    char* tg = p.lora_t + (int64_t)pgi * p.M * p.lora_r * (int)sizeof(T);
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        const int r0 = (rg * RI + j) * 16 + 4 * g;
+        f32x4 v = ta[j];
+        if (p.ln_stats) {
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + pgi * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + pgi * p.lora_r + r0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean * sa[e]) + ca[e] * inv;
+        }
+        if (m < p.M) {
+            char* dst = tg + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
+            if constexpr (sizeof(T) == 4) {
+                st_agent8(dst, __builtin_bit_cast(uint64_t, f32x2{v[0], v[1]}));
+                st_agent8(dst + 8, __builtin_bit_cast(uint64_t, f32x2{v[2], v[3]}));
+            } else {
+                const bf16x4 b4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                st_agent8(dst, __builtin_bit_cast(uint64_t, b4));
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(p.lora_flags + pgi * npb + tm, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
 __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_eu(XATT ? 2 : 1))) void gemm_kernel(const GemmP p) {
@@ -436,7 +587,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     static_assert(BM * 8 % NTHR == 0 && BN * 8 % NTHR == 0, "tile/thread mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* rowstat = reinterpret_cast<float*>(smem + KG * NSTAGE * STAGE);  // [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer)
-    char* const lora_b0 = smem + KG * NSTAGE * STAGE + BM * 8;               // LORA: [BN][32 ranks] of T, the first up-projection chunk (staged by the prologue)
+    char* const lora_b0 = smem + KG * NSTAGE * STAGE + (p.ln_stats ? BM * 8 : 0);  // LORA: [BN][32 ranks] of T, the first up-projection chunk (staged by the prologue)
 
     const int tid_all = threadIdx.x, wid_all = wave_id();
     const int kg = KG > 1 ? wid_all / NW : 0;
@@ -469,24 +620,23 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         if (acc == 0x5a5a1234 && p.pf_bytes[0] < 0) *reinterpret_cast<int*>(p.out) = acc;  // never taken: keeps the loads alive
         return;
     }
-    // LoRA producer role (see the header): workgroup q = (column group, row block) computes t = x A^T for its BM rows
-    bool prod = false;
-    int pgi = 0, split = 0, tm = 0, tn = 0;
     int bid = (int)blockIdx.x - p.pf_blocks;
     if constexpr (LORA) {
-        if (bid < p.lp_blocks) {
-            const int npb = (p.M + LORA_PM - 1) / LORA_PM;  // producer row blocks of LORA_PM rows
-            if (bid >= npb * (p.lora_a_all ? 1 : p.lora_groups)) return;  // padding up to a multiple of 8 (keeps compute block b on XCD b % 8)
-            if (p.lora_dbg & 1) return;
-            prod = true;
-            pgi = bid / npb;
-            tm = bid - pgi * npb;
+        if (bid < p.lp_blocks) {  // LoRA producer role: see lora_producer (a separate function; nothing of it lives in the tiles' path)
+            if ((p.lora_dbg & 1) || bid >= (p.M + LORA_PM - 1) / LORA_PM * p.lora_groups) return;  // (probing) / padding up to a multiple of 8
+            constexpr int RING = KG * NSTAGE * (BM + BN) * 128;
+            constexpr int PB1 = (LORA_PM + 32) * 128, PB2 = (LORA_PM + 64) * 128, PB4 = (LORA_PM + 128) * 128;  // bytes per producer stage
+            constexpr int P1 = RING / PB1 < 8 ? RING / PB1 : 8, P2 = RING / PB2 < 8 ? RING / PB2 : 8, P4 = RING / PB4;
+            if (p.lora_r == 32) lora_producer<T, CONV, 1, P1>(p, bid);
+            else if (p.lora_r == 64) lora_producer<T, CONV, 2, P2>(p, bid);
+            else if constexpr (P4 >= 2) lora_producer<T, CONV, 4, (P4 < 8 ? P4 : 8)>(p, bid);  // (the host routes rank-128 launches to the 128-column tiles)
+            return;
         }
         bid -= p.lp_blocks;
     }
-    if (!prod) {
-    split = p.ksplit > 1 ? bid / p.grid0 : 0;
+    const int split = p.ksplit > 1 ? bid / p.grid0 : 0;
     const int bx = bid - split * p.grid0;
+    int tm, tn;
     if (p.pn > 0) {  // rectangular regions (exact split of the tile grid, grid0 = 8 * hm * hn)
         const int xcd = bx & 7, idx = bx >> 3;
         const int rm = xcd / p.pn, rn = xcd - rm * p.pn;
@@ -504,12 +654,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         }
     }
     if (tm >= p.tiles_m || tn >= p.tiles_n) return;
-    }
-    const int m0 = prod ? tm * LORA_PM : tm * BM, n0 = tn * BN;
-    const bool tr = !CONV && !prod && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
-    const int Nw = prod ? (p.lora_a_all ? p.lora_groups * p.lora_r : p.lora_r) : p.N;  // rows of the weight operand this workgroup streams
-    const int nseg = prod ? 1 : p.nseg;                  // the LoRAs adapt segment 0 (the conv / Linear itself, not a fused shortcut)
-    const int lora_tag = LORA ? *p.lora_epoch : 0;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bool tr = !CONV && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
 
     // ---- per-thread loader coordinates (fixed for the whole K loop) ----
     // Exactly one operand's rows are permuted inside each wave's 16*T-row span (see the header): the weights' normally, the
@@ -544,8 +690,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         const int q = it * NTHR + tid, row = q >> 3, pch = q & 7;
         wcoff[it] = (pch ^ swz<128>(row)) << 4;
         const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
-        const int n = n0 + (tr || prod ? row : (row - rl) + 4 * NT * a + 4 * j + b);  // producer: rank r = LDS row r
-        wnrow[it] = n < Nw ? n : Nw - 1;
+        const int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
+        wnrow[it] = n < p.N ? n : p.N - 1;
     }
 
     f32x4 acc[MT][NT];
@@ -555,17 +701,17 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // in-launch LoRA: column group of this tile, and whether this workgroup adds the LoRA term (split-K: the first split only)
     const int lgi = LORA ? (p.lora_groups > 1 && n0 >= p.lora_nb[1] ? 1 : 0) + (p.lora_groups > 2 && n0 >= p.lora_nb[2] ? 1 : 0) : 0;
-    const bool lora_tail = LORA && !prod && split == 0;
+    const bool lora_tail = LORA && split == 0 && !(p.lora_dbg & 4);
 
     // ---- K-block iteration state ----
     int seg = 0, kb = 0;  // kb = block index inside the current segment
     int total_kb = 0;
-    for (int s = 0; s < nseg; ++s) total_kb += p.seg[s].nkb;
-    if (p.ksplit > 1 && !prod) {  // this workgroup's share of the K blocks: [first, first + total_kb)
+    for (int s = 0; s < p.nseg; ++s) total_kb += p.seg[s].nkb;
+    if (p.ksplit > 1) {  // this workgroup's share of the K blocks: [first, first + total_kb)
         const int first = split * p.kb_per_split;
         total_kb = min(p.kb_per_split, total_kb - first);
         kb = first;
-        while (seg < nseg - 1 && kb >= p.seg[seg].nkb) {
+        while (seg < p.nseg - 1 && kb >= p.seg[seg].nkb) {
             kb -= p.seg[seg].nkb;
             ++seg;
         }
@@ -601,12 +747,10 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         const SegP& sp = p.seg[s];
         cur_nkb = sp.nkb;
         cur_cpb = sp.cpb;
-        const char* wsrc = prod ? (p.lora_a_all ? p.lora_a_all : p.lora_a[pgi]) : sp.w;  // producer: the stacked down rows, always K-blocked
-        const bool wkb = prod || sp.wkb;
-        wstep = wkb ? (int64_t)Nw * 128 : 128;
+        wstep = sp.wkb ? (int64_t)p.N * 128 : 128;
         woff = (int64_t)kb0 * wstep;
 #pragma unroll
-        for (int it = 0; it < WI; ++it) wbase[it] = wsrc + (wkb ? (int64_t)wnrow[it] * 128 : (int64_t)wnrow[it] * sp.ldwb) + wcoff[it];
+        for (int it = 0; it < WI; ++it) wbase[it] = sp.w + (sp.wkb ? (int64_t)wnrow[it] * 128 : (int64_t)wnrow[it] * sp.ldwb) + wcoff[it];
         if constexpr (CONV) {
             tap = kb0 / sp.cpb;
             cb = kb0 - tap * sp.cpb;
@@ -619,7 +763,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         }
     };
     auto advance = [&]() __attribute__((always_inline)) {  // one K block forward; cross into the next tap / segment when this one is exhausted
-        if (seg >= nseg) return;
+        if (seg >= p.nseg) return;
         ++kb;
         woff += wstep;
         if constexpr (CONV) {
@@ -634,7 +778,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         if (kb == cur_nkb) {
             kb = 0;
             ++seg;
-            if (seg < nseg) enter(seg, 0);
+            if (seg < p.nseg) enter(seg, 0);
         }
     };
     enter(seg, kb);
@@ -707,11 +851,9 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 issue_half(s0, 1);
             }
     } else {
-        if (!prod) {  // (a producer fills its own, deeper ring: see producer_loop)
 #pragma unroll
-            for (int s0 = 0; s0 < D; ++s0)
-                if (s0 < my_kb) issue(s0);
-        }
+        for (int s0 = 0; s0 < D; ++s0)
+            if (s0 < my_kb) issue(s0);
     }
 
     if (p.ln_stats) {
@@ -772,37 +914,57 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     // One barrier per K block, between the phases.  The interleave inside a phase is pinned with sched_group_barrier (the
     // machine scheduler otherwise sinks every ds_read to just before its first use and waits lgkmcnt(0) eight times per block).
     // LORA, output tiles: the hand-off is started INSIDE the K loop so that its two dependent round trips (flags, then the t rows) ride
-    // in the loop's own load stream -- a dependent load issued from a streaming CU waits 1-3 us in that CU's memory queue
-    // (microarchitecture guide, handoff-1to1), far more than the epilogue could hide.  At trip hook_t = max_kb - 4 the first lanes of
-    // wave 0 load the row block's flags right behind that trip's stage issue; one trip later -- the loop's vmcnt(0) has retired them
-    // -- wave 0 publishes "all set" through LDS ahead of the barrier, and every thread issues its L1-bypassing loads of the t rows
-    // TOGETHER with the loop's last stage: the vmcnt(0) that waits for the last K block waits for them too, nothing else does.
-    constexpr int L_RB = LORA_RC * (int)sizeof(T), L_CPRB = L_RB / 16, L_TI = LORA ? BM * L_CPRB / NTHR : 1;
-    uint64_t tv[L_TI][2];
-    int lora_fl = lora_tag, lora_ok = 0;
-    int* const lds_ok = reinterpret_cast<int*>(lora_b0 + BN * L_RB);
-    const int nfl_blocks = (p.M + LORA_PM - 1) / LORA_PM;
-    const int hook_t = (lora_tail && max_kb >= 4) ? max_kb - 4 : -2;
-    auto lora_poll = [&]() __attribute__((always_inline)) {  // lanes 0 .. BM / 32 - 1 of wave 0: one flag each (row blocks past M count as set)
-        if (wid == 0 && lane < BM / LORA_PM) {
-            const int fb = m0 / LORA_PM + lane;
-            if (fb < nfl_blocks) lora_fl = __hip_atomic_load(p.lora_flags + lgi * nfl_blocks + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // in the loop's own load stream (a dependent load issued from a streaming CU waits 1-3 us in that CU's memory queue: microarchitecture
+    // guide, handoff-1to1).  At trip hook_t = max_kb - 4 the first lanes of every wave load the row block's flags (and the launch's epoch)
+    // right behind that trip's stage issue; one trip later -- the loop's vmcnt(0) has retired them -- the wave compares them (a ballot:
+    // no cross-wave hand-off, no LDS word) and every lane loads its t values STRAIGHT INTO MFMA FRAGMENT LAYOUT together with the loop's last stage
+    // (a wave's 16 rows x 64 B of one row block are 1 KB contiguous: the layout a ds_read of an LDS copy would return is the layout in
+    // memory, so t needs no LDS staging and the product after the loop no barrier).  Everything the hooks need is computed inside them
+    // (behind an opaque zero, so that nothing is hoisted and kept live through the loop).
+    //
+    // Why the fast path may use PLAIN (L1 / L2 cacheable) loads although the writers are other CUs, possibly on other XCDs: every t
+    // line and flag word is written once per launch, BEFORE its flag is published (write-through stores, acknowledged, then the flag),
+    // and this CU's L1 / this XCD's L2 hold no copy from an earlier launch (a kernel boundary makes earlier kernels' writes visible to
+    // plain loads of later ones -- what every two-kernel HIP program relies on -- so no stale copy survives it).  Within the launch a
+    // cached copy of a t line can only have been fetched by a tile that had already seen its flag set, i.e. it holds the final data;
+    // a cached flag word can only be stale in the harmless direction ("not set yet"), which sends the tile to the slow path after
+    // the loop: L1-bypassing agent-scope atomics (2-3 us per dependent access from a streaming CU, which is why they are not the default).
+    constexpr int L_RB = LORA_RC * (int)sizeof(T), L_KS = LORA_RC / DT<T>::KSTEP;  // bytes per 32-rank row / MMA steps per 32 ranks (bf16: 1, f32: 2)
+    frag_t tfr[LORA ? MT : 1][L_KS];
+    int lora_fl = 0, lora_tg = 1, lora_ok = 0;
+    bool lora_mine = false;
+    const int hook_t = (lora_tail && max_kb >= 4 && !(p.lora_dbg & 16)) ? max_kb - 4 : -2;
+    auto opaque0 = [&]() __attribute__((always_inline)) {
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        return z;
+    };
+    auto lora_poll = [&]() __attribute__((always_inline)) {  // lanes 0 .. BM / 32 - 1 of EVERY wave: one flag each (no cross-wave hand-off needed)
+        {
+            const int z = opaque0();
+            const int nfl = (p.M + LORA_PM - 1) / LORA_PM, fb = m0 / LORA_PM + lane + z;
+            // both are VECTOR loads (address through z): nothing here waits -- a scalar load of the epoch would park wave 0 on lgkmcnt(0)
+            // for a memory round trip, and with it the workgroup's next barrier
+            lora_tg = p.lora_epoch[z];
+            const bool mine = lane < BM / LORA_PM && fb < nfl;
+            lora_fl = p.lora_flags[mine ? lgi * nfl + fb : 0];  // plain load (see above); lanes without a row block compare equal below
+            lora_mine = mine;
         }
     };
-    auto lora_load_t = [&](int c) __attribute__((always_inline)) {  // this thread's 16-byte pieces of the tile's t rows, rank chunk c
-        const char* tg = p.lora_t + (int64_t)lgi * p.M * p.lora_r * (int)sizeof(T);
+    auto lora_load_t = [&](int c) __attribute__((always_inline)) {  // this lane's t fragments of rank chunk c: rows 16 i + c16 of the wave's row span
+        const int z = opaque0();
+        const char* tg = p.lora_t + ((int64_t)lgi * p.M * p.lora_r + c * LORA_RC + z) * (int)sizeof(T);
 #pragma unroll
-        for (int it = 0; it < L_TI; ++it) {
-            const int q = it * NTHR + tid, row = q / L_CPRB, ch = q % L_CPRB;
+        for (int i = 0; i < MT; ++i) {
+            const int row = wm * WME + 16 * i + c16;
             int mr = row;
             if (tr) {
                 const int rl = row % WME;
                 mr = (row - rl) + 4 * MT * ((rl >> 2) & 3) + 4 * (rl >> 4) + (rl & 3);
             }
             const int m = min(m0 + mr, p.M - 1);
-            const char* src = tg + ((int64_t)m * p.lora_r + c * LORA_RC) * (int)sizeof(T) + ch * 16;
-            tv[it][0] = ld_agent8(src);
-            tv[it][1] = ld_agent8(src + 8);
+#pragma unroll
+            for (int ks = 0; ks < L_KS; ++ks) tfr[i][ks] = *reinterpret_cast<const frag_t*>(tg + (int64_t)m * p.lora_r * (int)sizeof(T) + (4 * ks + g) * 16);
         }
     };
     auto mainloop = [&](auto trc) {
@@ -845,7 +1007,13 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         __builtin_amdgcn_s_barrier();
         if (D < my_kb) issue(D % NSTAGE);
         if (my_kb > 0) read_half(xf0, wf0, 0, 0);
-        for (int t = 0; t < max_kb; ++t) {
+        // LORA: the loop is PEELED -- trips [0, hook_t) run a copy without any hand-off code (instruction for instruction the un-adapted
+        // kernel's loop: even a few wave-uniform compares and branches between a trip's barrier and its stage issue cost every trip
+        // ~70 cycles of the barrier -> issue -> landed critical path, 0.7 us per tile: profiles/r03_g_bisect.log), the last four trips the
+        // two trips that carry the hand-off run the copy with the hooks, the last two the plain copy again.
+        auto trips = [&](auto hookc, int t_begin, int t_end) __attribute__((always_inline)) {
+        constexpr bool HOOKS = decltype(hookc)::value;
+        for (int t = t_begin; t < t_end; ++t) {
             const bool active = KG == 1 || t < my_kb;  // the odd group of an odd block count idles through the last trip
             if (active) {  // phase A
                 read_half(xf1, wf1, t, 1);
@@ -855,20 +1023,14 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             if (t + 1 < max_kb) {
                 if (t + 1 + D <= my_kb) wait_vm<(D - 1) * LPS>();
                 else wait_vm0();
-                if constexpr (LORA) {
-                    if (t == hook_t + 1 && wid == 0) {  // the flags loaded one trip ago have arrived (D = 1: every trip's vmcnt(0) drains the queue)
-                        const bool all = __builtin_amdgcn_ballot_w64(lora_fl == lora_tag) == ~0ull;
-                        if (lane == 0) *lds_ok = all ? 1 : 0;
-                    }
-                }
+
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (t + 1 + D < my_kb) issue((t + 1 + D) % NSTAGE);
-                if constexpr (LORA) {
+                if constexpr (HOOKS) {
                     if (t == hook_t) lora_poll();
-                    if (t == hook_t + 1) {
-                        // (an explicit ds_read: a volatile generic load here compiles to flat_load + vmcnt(0))
-                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(lora_ok) : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)lds_ok) : "memory");
+                    if (t == hook_t + 1) {  // the flags loaded one trip ago have arrived (D = 1: this trip's vmcnt(0) drained the queue)
+                        lora_ok = __builtin_amdgcn_ballot_w64(!lora_mine || lora_fl == lora_tg) == ~0ull ? 1 : 0;  // wave-uniform
                         if (lora_ok) lora_load_t(0);
                     }
                 }
@@ -878,6 +1040,15 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 mma_half(xf1, wf1);
                 pin();
             }
+        }
+        };
+        if constexpr (LORA) {
+            const int ts = hook_t >= 0 ? hook_t : max_kb, te = hook_t >= 0 ? hook_t + 2 : max_kb;
+            trips(std::false_type{}, 0, ts);
+            trips(std::true_type{}, ts, te);   // the two trips that carry the hand-off
+            trips(std::false_type{}, te, max_kb);
+        } else {
+            trips(std::false_type{}, 0, max_kb);
         }
     };
     // ---- the staggered schedule (STAG): 4 barrier slots per K block; group 0 = waves 0-3 (wm 0, 1), group 1 = waves 4-7 one slot behind ---
@@ -1008,109 +1179,6 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    if constexpr (LORA) {
-        if (prod) {
-            // ---- LoRA producer: t[m0 .. m0 + 32)[0 .. R) = x A_g^T, R = 32 RI.  The loop is latency-bound (R / BN of a tile's MFMAs on a quarter
-            // of its rows), so the workgroup's LDS is re-cut into a ring of up to 8 stages of (32 x rows + R weight rows) x 128 B: 7 K blocks in
-            // flight.  Wave w takes row block w & 1 and the RI rank blocks (w >> 1) RI .. (weight rows unpermuted: LDS row r = rank r).
-            auto producer_loop = [&](auto ric) {
-                constexpr int RI = decltype(ric)::value;
-                constexpr int PXB = LORA_PM * 128, PSTAGE = PXB + 32 * RI * 128;
-                constexpr int RING = KG * NSTAGE * STAGE;
-                constexpr int PST = RING / PSTAGE < 8 ? RING / PSTAGE : 8;
-                static_assert(PST >= 2 || RI > 3, "LoRA producer: the tile's LDS ring holds fewer than two producer stages");
-                constexpr int PD = PST - 1, PL = 1 + RI;
-                const char* pw[RI];  // this thread's 16 bytes of weight rows j * 32 + (tid >> 3) of a K block (rank r = LDS row r)
-#pragma unroll
-                for (int j = 0; j < RI; ++j) {
-                    const int q = j * NTHR + tid, row = q >> 3, pch = q & 7;
-                    pw[j] = (p.lora_a_all ? p.lora_a_all : p.lora_a[pgi]) + (int64_t)row * 128 + ((pch ^ swz<128>(row)) << 4);
-                }
-                auto issue_p = [&](int buf) __attribute__((always_inline)) {
-                    char* st = smem + buf * PSTAGE;
-                    const char* src;
-                    if constexpr (CONV) src = xbase[0] ? xbase[0] + (int64_t)cb * 128 : p.zeros + xcoff[0];
-                    else src = xbase[0] + xoff;
-                    glds16(src, st + wid * 64 * 16);
-#pragma unroll
-                    for (int j = 0; j < RI; ++j) glds16(pw[j] + woff, st + PXB + (j * NTHR + wid * 64) * 16);
-                    advance();
-                };
-                const int rb = wid & 1, rg = wid >> 1;
-                f32x4 ta[RI];
-#pragma unroll
-                for (int j = 0; j < RI; ++j) ta[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s0 = 0; s0 < PD; ++s0)
-                    if (s0 < my_kb) issue_p(s0);
-                for (int t = 0; t < my_kb; ++t) {
-                    if (t + PD <= my_kb) wait_vm<(PD - 1) * PL>();  // block t has landed, the PD - 1 younger ones stay in flight
-                    else wait_vm0();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (t + PD < my_kb) issue_p((t + PD) % PST);  // into the buffer block t - 1 was read from (every wave retired those reads above)
-                    const char* st = smem + (t % PST) * PSTAGE;
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const frag_t xf = lds_read_frag(st, tile_off<128>(16 * rb + c16, 4 * kk + g));
-#pragma unroll
-                        for (int j = 0; j < RI; ++j) {
-                            const frag_t af = lds_read_frag(st + PXB, tile_off<128>((rg * RI + j) * 16 + c16, 4 * kk + g));
-                            mma_step<T>(ta[j], af, xf);  // D[rank 16 (rg RI + j) + 4 g + r][row 16 rb + c16]
-                        }
-                    }
-                }
-                // epilogue: LayerNorm folded in -> what is published is t / rstd = (x A'^T - mean sA) + cA / rstd, the tile epilogue's
-                // rstd * (acc - mean s) + c then scales the up-projected product back (one rounding of t, as in the reference); rounded to T;
-                // written through to L2 (8-byte agent-scope stores), then the row block's flag
-                const int mrow = 16 * rb + c16, m = m0 + mrow;
-                float mean = 0.f, inv = 1.f;
-                if (p.ln_stats) {
-                    mean = rowstat[2 * mrow];
-                    inv = 1.0f / rowstat[2 * mrow + 1];
-                }
-#pragma unroll
-                for (int j = 0; j < RI; ++j) {
-                    const int rglob = (rg * RI + j) * 16 + 4 * g;  // rank row of the streamed weight operand
-                    const int gq = p.lora_a_all ? rglob / p.lora_r : pgi, r0 = p.lora_a_all ? rglob % p.lora_r : rglob;  // -> (column group, rank)
-                    char* tg = p.lora_t + (int64_t)gq * p.M * p.lora_r * (int)sizeof(T);
-                    f32x4 v = ta[j];
-                    if (p.ln_stats) {
-                        const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + gq * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + gq * p.lora_r + r0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean * sa[e]) + ca[e] * inv;
-                    }
-                    if (m < p.M) {
-                        char* dst = tg + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
-                        if constexpr (sizeof(T) == 4) {
-                            st_agent8(dst, __builtin_bit_cast(uint64_t, f32x2{v[0], v[1]}));
-                            st_agent8(dst + 8, __builtin_bit_cast(uint64_t, f32x2{v[2], v[3]}));
-                        } else {
-                            const bf16x4 b4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                            st_agent8(dst, __builtin_bit_cast(uint64_t, b4));
-                        }
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
-                __syncthreads();
-                const int npb = (p.M + LORA_PM - 1) / LORA_PM;
-                if (p.lora_a_all) {
-                    if (tid < p.lora_groups) __hip_atomic_store(p.lora_flags + tid * npb + tm, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (tid == 0) {
-                    __hip_atomic_store(p.lora_flags + pgi * npb + tm, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            };
-            switch (Nw / 32) {  // 32-rank blocks of the streamed weight operand
-                case 1: producer_loop(std::integral_constant<int, 1>{}); break;
-                case 2: producer_loop(std::integral_constant<int, 2>{}); break;
-                case 3: producer_loop(std::integral_constant<int, 3>{}); break;
-                default:
-                    if constexpr (BN >= 128) producer_loop(std::integral_constant<int, 4>{});  // (the host routes such launches to the 128-column tiles)
-                    break;
-            }
-            return;
-        }
-    }
     if constexpr (STAG == 2) {
         if constexpr (CONV) {
             stagloop2(std::false_type{});
@@ -1133,69 +1201,54 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     }
 
     if constexpr (LORA) {
-        // ---- up-projection: acc += T(t) . (s B_cat)^T, 32 ranks per step through LDS; t comes from this row block's producer -------------
-        if (lora_tail) {
-            constexpr int RB = L_RB;                      // bytes per row of both LDS images (64 / 128)
-            constexpr int CPRB = L_CPRB;                  // 16-byte chunks per row
-            constexpr int KS = LORA_RC / DT<T>::KSTEP;    // MMA steps per chunk (bf16: 1, f32: 2)
-            constexpr int TI = L_TI, BI = BN * CPRB / NTHR;
-            static_assert(BM * CPRB % NTHR == 0, "t tile / thread mismatch");
-            char* tl = smem;             // [BM rows in LDS order][32 ranks] of T
-            char* bl = smem + BM * RB;   // [BN rows in LDS order][32 ranks] of T: chunks after the first (the first sits in lora_b0)
+        // ---- up-projection: acc += T(t) . (s B_cat)^T, 32 ranks per MMA chunk; t comes from this row block's producers ----------------------
+        if (lora_tail && !(p.lora_dbg & 8)) {
+            constexpr int RB = L_RB, CPRB = RB / 16, BI = BN * CPRB / NTHR;
             const int nch = p.lora_r / LORA_RC;
-            if (!lora_ok) {  // not seen from inside the loop (a short K loop, or a producer still running): wait here, bounded by the wall clock
-                lora_poll();
-                if (wid == 0 && lane < BM / LORA_PM) {
-                    const int fb = min(m0 / LORA_PM + lane, nfl_blocks - 1);
-                    const int* fp = p.lora_flags + lgi * nfl_blocks + fb;
-                    const uint64_t t0 = wall_clock64();
-                    while (lora_fl != lora_tag) {
-                        __builtin_amdgcn_s_sleep(2);
-                        lora_fl = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (wall_clock64() - t0 > 200000000ull) __builtin_trap();  // 2 s of the 100 MHz clock: a lost producer must not hang the GPU
+            if (p.lora_dbg & 16) lora_ok = 1;  // (probing: no hand-off at all, the product runs on whatever the registers hold)
+            if (!lora_ok) {  // this wave did not see its flags set from inside the loop (a short K loop, or a producer still running): wait here, bounded by the wall clock
+                {
+                    const int nfl = (p.M + LORA_PM - 1) / LORA_PM, fb = m0 / LORA_PM + lane;
+                    const int tag = *p.lora_epoch;
+                    if (lane < BM / LORA_PM && fb < nfl) {
+                        const int* fp = p.lora_flags + lgi * nfl + fb;
+                        const uint64_t t0 = wall_clock64();
+                        while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {  // L1-bypassing: correct whatever this CU has cached
+                            __builtin_amdgcn_s_sleep(2);
+                            if (wall_clock64() - t0 > 200000000ull) __builtin_trap();  // 2 s of the 100 MHz clock: a lost producer must not hang the GPU
+                        }
                     }
                 }
+                lora_load_t(0);
             }
-            __syncthreads();  // every wave is done with the stage buffers; the flags have been seen
             for (int c = 0; c < nch; ++c) {
-                if (c) __syncthreads();  // the previous chunk's fragments have been read
-                if (c || !lora_ok) lora_load_t(c);  // (chunk 0 was requested from inside the loop)
-                frag_t bv[BI];
-                if (c) {
+                const char* bs = lora_b0;  // chunk 0: staged by the prologue, made visible by the K loop's barriers
+                if (c) {  // ranks beyond 32: t straight from memory again, the up rows through the (drained) stage buffers
+                    __syncthreads();  // every wave is done with the stage buffers / with the previous chunk's rows
+                    lora_load_t(c);
+                    char* bl = smem;
 #pragma unroll
                     for (int it = 0; it < BI; ++it) {
                         const int q = it * NTHR + tid, row = q / CPRB, ch = q % CPRB;
                         const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
                         int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
                         n = n < p.N ? n : p.N - 1;
-                        bv[it] = *reinterpret_cast<const frag_t*>(p.lora_b + ((int64_t)n * p.lora_r + c * LORA_RC) * (int)sizeof(T) + ch * 16);
+                        *reinterpret_cast<frag_t*>(bl + q * 16) = *reinterpret_cast<const frag_t*>(p.lora_b + ((int64_t)n * p.lora_r + c * LORA_RC) * (int)sizeof(T) + ch * 16);
                     }
+                    __syncthreads();
+                    bs = bl;
                 }
 #pragma unroll
-                for (int it = 0; it < TI; ++it) {
-                    const int q = it * NTHR + tid;
-                    *reinterpret_cast<uint64_t*>(tl + q * 16) = tv[it][0];
-                    *reinterpret_cast<uint64_t*>(tl + q * 16 + 8) = tv[it][1];
-                }
-                if (c) {
-#pragma unroll
-                    for (int it = 0; it < BI; ++it) *reinterpret_cast<frag_t*>(bl + (it * NTHR + tid) * 16) = bv[it];
-                }
-                __syncthreads();
-                const char* bs = c ? bl : lora_b0;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    frag_t tf[MT], bf[NT];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) tf[i] = lds_read_frag(tl, (wm * WME + 16 * i + c16) * RB + (4 * ks + g) * 16);
+                for (int ks = 0; ks < L_KS; ++ks) {
+                    frag_t bf[NT];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) bf[j] = lds_read_frag(bs, (wn * WNE + 16 * j + c16) * RB + (4 * ks + g) * 16);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
-                            if (tr) mma_step<T>(acc[i][j], tf[i], bf[j]);
-                            else mma_step<T>(acc[i][j], bf[j], tf[i]);
+                            if (tr) mma_step<T>(acc[i][j], tfr[i][ks], bf[j]);
+                            else mma_step<T>(acc[i][j], bf[j], tfr[i][ks]);
                         }
                 }
             }
@@ -1500,7 +1553,7 @@ extern int g_lora_dbg;   // probing: see GemmP::lora_dbg
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
-    constexpr int LDS0 = KG * NSTAGE * (BM + BN) * 128 + BM * 8 + (LORA ? BN * LORA_RC * (int)sizeof(T) + 16 : 0);
+    constexpr int LDS0 = KG * NSTAGE * (BM + BN) * 128 + BM * 8 + (LORA ? BN * LORA_RC * (int)sizeof(T) : 0);
     constexpr int LDS = XATT && 2 * xa_head_bytes<T>() > LDS0 ? 2 * xa_head_bytes<T>() : LDS0;  // the epilogue's K / V^T of two heads reuse the ring
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(KG == 1 || (BM / WM / 16) * (BN / WN / 16) * WM * WN * 1024 <= KG * NSTAGE * (BM + BN) * 128, "partial-tile exchange must fit the stage buffers");
@@ -1553,10 +1606,10 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
     q.pf_mode = g_pf_mode;
     q.lora_dbg = g_lora_dbg;
-    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * (q.lora_a_all ? 1 : q.lora_groups) + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
+    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
     const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), (q.ln_stats || XATT || LORA) ? LDS : LDS - BM * 8, stream, q);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), (q.ln_stats || XATT) ? LDS : LDS - BM * 8, stream, q);
     if (q.ksplit > 1) {
         const int64_t work = (int64_t)q.M * ((q.N + 3) / 4);
         int64_t rb = (work + 255) / 256;
@@ -1606,7 +1659,7 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
         if (p.xa.nstream) return launch_cfg<T, 128, 128, 2, 2, false, 2, 1, false, 0, true>(p, stream);  // cross-attention epilogue: the tile that holds 128 queries x 2 heads
     }
     if (p.lora_b) {  // in-launch LoRA: the 4-wave tiles, two LDS stages; a stacked rank above 64 needs the 128-column tiles (the producers stage R weight rows)
-        if ((p.lora_r > 64 || (p.lora_a_all && p.lora_groups * p.lora_r > 96)) && (tile == 2 || tile == 4)) tile = tile == 2 ? 1 : 3;
+        if (p.lora_r > 64 && (tile == 2 || tile == 4)) tile = tile == 2 ? 1 : 3;
         if constexpr (CONV) {
             return tile == 1 ? launch_cfg<T, 128, 128, 2, 2, true, 2, 1, true>(p, stream) : launch_cfg<T, 64, 128, 2, 2, true, 2, 1, true>(p, stream);
         } else {

@@ -140,7 +140,6 @@ class GemmArgs(C.Structure):
         ("stats_out", C.c_void_p),
         ("out_f32", C.c_int32),
         ("lora_a", C.c_void_p * 3),
-        ("lora_a_all", C.c_void_p),
         ("lora_nb", C.c_int32 * 3),
         ("lora_groups", C.c_int32),
         ("lora_r", C.c_int32),
@@ -608,15 +607,6 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
         assert isinstance(la, KBlocked) and la.shape == (R, K) and la.dtype == dtype, (la.shape, R, K)
         a.lora_a[g], a.lora_nb[g] = la.data_ptr(), nb
     a.lora_groups, a.lora_r, a.lora_b = len(groups), R, lb.data_ptr()
-    if len(groups) > 1 and len(groups) * R <= LORA_RMAX:
-        # one producer set for all groups: their down rows stacked into one K-blocked operand (cached on the first group's pack)
-        la0 = groups[0][1]
-        key = tuple(id(la) for _, la in groups)
-        merged = getattr(la0, "_stacked", None)
-        if merged is None or merged[0] != key:
-            merged = (key, KBlocked(torch.cat([la.dense() for _, la in groups], 0).contiguous()))
-            la0._stacked = merged
-        a.lora_a_all = merged[1].data_ptr()
     if len(lora) > 2:  # LayerNorm folded into this launch as well
         ls_, lc_ = lora[2], lora[3]
         assert ln_given and ls_.dtype == torch.float32 and lc_.dtype == torch.float32 and ls_.is_contiguous() and lc_.is_contiguous()

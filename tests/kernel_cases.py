@@ -813,7 +813,7 @@ def conv_lora_inlaunch_case(B, Cin, Cout, H, W, dtype, *, ranks=(16, 16), stride
     return _cmp(out, ref.permute(0, 2, 3, 1).reshape(B * OH * OW, Cout), dtype)
 
 
-def gemm_lora_repeat_case(M, K, N, dtype, seed=295):
+def gemm_lora_repeat_case(M, K, N, dtype, seed=295, rounds=12):
     """The hand-off under reuse: the SAME scratch / flags / epoch word driven through several launches with different inputs (what a
     replayed program does), every word of every result checked -- a stale t (flag seen early, L1-resident line) would show here."""
     w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
@@ -822,7 +822,7 @@ def gemm_lora_repeat_case(M, K, N, dtype, seed=295):
     t, flags = sync.scratch(1, M, 32, dtype), sync.flags(1, M)
     wk = native.KBlocked(w)
     worst = (0.0, 0.0, 1.0)
-    for rnd in range(6):
+    for rnd in range(rounds):
         x = _rand(M, K, dtype=dtype, seed=seed + 50 + rnd)
         out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
         sync.bump()
@@ -1010,6 +1010,7 @@ def all_cases():
             (f"gemm_{tag}_lora1_rank96_transposed", lambda dt=dt: gemm_lora_inlaunch_case(154, 2048, 640, dt, ranks=(64, 32), transposed=True)),
             (f"gemm_{tag}_lora1_ff2_2048x1280x5120", lambda dt=dt: gemm_lora_inlaunch_case(2048, 5120, 1280, dt)),
             (f"gemm_{tag}_lora1_repeat_shared_scratch", lambda dt=dt: gemm_lora_repeat_case(1024, 640, 1280, dt)),
+            (f"gemm_{tag}_lora1_repeat_shared_scratch_2048x1280x3840", lambda dt=dt: gemm_lora_repeat_case(2048, 1280, 3840, dt, rounds=8)),
             (f"conv_{tag}_lora1_2x64x128_32x32", lambda dt=dt: conv_lora_inlaunch_case(2, 64, 128, 32, 32, dt)),
             (f"conv_{tag}_lora1_rank128_stride2", lambda dt=dt: conv_lora_inlaunch_case(2, 128, 256, 32, 32, dt, ranks=(128,), stride=2)),
             (f"conv_{tag}_lora1_shortcut_tile1", lambda dt=dt: conv_lora_inlaunch_case(1, 64, 128, 24, 40, dt, ranks=(8,), shortcut=64, tile=1)),

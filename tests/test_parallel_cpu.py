@@ -96,6 +96,118 @@ def test_checkpoint_is_read_once_and_broadcast(tmp_path):
     assert all(g[1] >= 1 and g[2] == want and g[3] for g in got), got
 
 
+def _spawn(target, args_for_rank, world=2, timeout=180):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, *args_for_rank(r), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=timeout) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def _worker_fail(rank: int, world: int, port: int, mode: str, path: str, q) -> None:
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd import parallel
+
+    parallel.init_from_env("gloo")
+    outcome = "ok"
+    try:
+        if mode == "missing_file":  # only the source touches the file: its failure must reach the others instead of leaving them in the collective
+            model = fl.Chain(fl.Linear(16, 32, device="meta"), fl.Linear(32, 8, device="meta"))
+            parallel.load_and_broadcast(model, "/nonexistent/weights.safetensors", device="cpu")
+        elif mode == "different_trees":  # rank 1 built another tree: arena layouts would differ -> refuse before anything moves
+            model = fl.Chain(fl.Linear(16, 32), fl.Linear(32, 8 if rank == 0 else 4))
+            parallel.broadcast_module(model)
+        elif mode == "partial":  # strict=False, the file lacks one tensor: it must still end up on the device on EVERY rank, same list everywhere
+            model = fl.Chain(fl.Linear(16, 32, device="meta"), fl.Linear(32, 8, device="meta"))
+            n = parallel.load_and_broadcast(model, path, device="cpu", strict=False)
+            outcome = ("ok", n, sorted((k, tuple(v.shape), v.device.type) for k, v in model.state_dict().items()),
+                       float(model.state_dict()["Linear_1.weight"].double().sum()))
+    except Exception as e:  # noqa: BLE001
+        outcome = f"{type(e).__name__}: {e}"
+    q.put((rank, outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_source_only_failure_reaches_every_rank():
+    got = _spawn(_worker_fail, lambda r: ("missing_file", ""))
+    assert all(isinstance(o, str) and o != "ok" for _, o in got), got
+    assert "rank 0" in got[1][1]  # the receiver's message names the failing rank
+
+
+def test_different_tensor_lists_are_refused_before_the_broadcast():
+    got = _spawn(_worker_fail, lambda r: ("different_trees", ""))
+    assert all(isinstance(o, str) and "differs from rank 0" in o for _, o in got), got
+
+
+def test_partial_checkpoint_keeps_the_ranks_consistent(tmp_path):
+    from safetensors.torch import save_file
+
+    import refiners_amd.fluxion.layers as fl
+
+    torch.manual_seed(6)
+    ref = fl.Chain(fl.Linear(16, 32), fl.Linear(32, 8))
+    sd = {k: v.contiguous() for k, v in ref.state_dict().items() if k != "Linear_2.bias"}
+    path = tmp_path / "partial.safetensors"
+    save_file(sd, str(path))
+    got = _spawn(_worker_fail, lambda r: ("partial", str(path)))
+    (_, a), (_, b) = got
+    assert a[0] == b[0] == "ok" and a[1] == b[1] >= 1 and a[2] == b[2] and a[3] == b[3] == float(ref.state_dict()["Linear_1.weight"].double().sum())
+    assert all(dev == "cpu" for _, _, dev in a[2])
+
+
+class _ToyPipe:
+    """Stands in for CompiledSDXL in the CPU dry run of bench.py's multi-process flow: x <- 0.9 x + unet(x) per step."""
+
+    def __init__(self, unet, x):
+        self.unet, self.x = unet, x
+
+    def step(self, i):
+        with torch.no_grad():
+            self.x = 0.9 * self.x + 0.01 * self.unet(self.x)
+        return self.x
+
+
+def _worker_bench(rank: int, world: int, port: int, q) -> None:
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd import parallel
+
+    r, w, _ = parallel.init_from_env("gloo")
+    torch.manual_seed(1000 + rank)  # like bench.build_pipeline: rank 0 draws the weights, the others receive them
+    unet = fl.Chain(fl.Conv2d(4, 8, 3, padding=1), fl.SiLU(), fl.Conv2d(8, 4, 3, padding=1))
+    n_b = parallel.broadcast_module(unet, src=0)
+    prompts = list(range(6))
+    mine = parallel.shard(prompts, r, w)  # independent prompts per rank, no per-step collective
+    g = torch.Generator().manual_seed(7)
+    x_all = torch.randn(len(prompts), 4, 8, 8, generator=g)
+    pipe = _ToyPipe(unet, x_all[mine[0] : mine[-1] + 1].clone())
+    elapsed = bench.timed_steps(pipe, steps=4, warmup=1, world=w, dev="cpu")  # barrier + max over ranks, as on the GPUs
+    allx = parallel.gather_latents(pipe.x, dst=0)
+    want = _ToyPipe(unet, x_all.clone())
+    for i in range(5):
+        want.step(i)
+    q.put((rank, n_b, elapsed, None if allx is None else float((allx - want.x).abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_shaped_dry_run_world2():
+    """bench.py --gpus 2 on CPU tensors: weights broadcast once, prompts sharded, the timed loop between barriers with the max over
+    ranks, latents gathered on rank 0 -- and the gathered result equals the single-process run (the path shards without any exchange)."""
+    (_, n0, e0, d0), (_, n1, e1, d1) = _spawn(_worker_bench, lambda r: ())
+    assert n0 == n1 >= 1 and e0 == e1 > 0  # both ranks report the same (max-over-ranks) time
+    assert d0 is not None and d0 < 1e-6 and d1 is None
+
+
 def test_shard_range_covers_everything():
     from refiners_amd.parallel import shard_range
 

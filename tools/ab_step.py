@@ -51,7 +51,8 @@ def main() -> None:
         native.attention_pipeline_from_env()
         tuning.enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
         tuning._table = None
-        p = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=True, lora_mode=args.lora_mode)
+        mode = name.split("@", 1)[1] if "@" in name else args.lora_mode  # "name@merged=..." / "name@fused=...": the variant's LoRA mode (same process, same weights)
+        p = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=True, lora_mode=mode)
         p.inputs, p.x = inputs, x0.clone()
         p._tables(dev)
         p.step(0)

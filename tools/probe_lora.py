@@ -3,6 +3,8 @@
   full       producers + tiles, epoch bumped before every launch (what lora_mode="fused" runs)
   nowait     the same launches WITHOUT the bump: the flags still hold the epoch, no tile ever waits (producers still run)
   tail       nowait + producers exit at once (mi355x_set_option lora_dbg 1): only the tiles' hand-off + up-projection remain
+  as-plain / hooks-only / mma-only   tail minus: everything (the LoRA kernel variant doing an un-adapted launch's work) / the post-loop product /
+             the hand-off (timing only; the results are then wrong by construction)
   bump+plain the un-adapted launch behind a bump kernel (the extra launch boundary `full` pays in this probe, not in the engine)."""
 import sys
 from pathlib import Path
@@ -37,7 +39,7 @@ def graph_time(fn, iters=20):
     return best  # us per launch
 
 
-def case(M, K, N, *, geglu=False, ln=False, qkv=False, tile=0, ranks=(16, 16)):
+def case(M, K, N, *, geglu=False, ln=False, qkv=False, tile=0, ranks=(16, 16), only=None):
     x = torch.randn(M, K, device=dev).to(dt)
     w = native.KBlocked((torch.randn(N, K, device=dev) * K ** -0.5).to(dt))
     R = native.lora_rank(sum(ranks))
@@ -87,22 +89,35 @@ def case(M, K, N, *, geglu=False, ln=False, qkv=False, tile=0, ranks=(16, 16)):
     lib = native.load()
     res = {}
     res["plain"] = graph_time(plain)
-    res["bump+plain"] = graph_time(bump_plain)
-    res["full"] = graph_time(full)
+    if only is None:
+        res["bump+plain"] = graph_time(bump_plain)
+        res["full"] = graph_time(full)
     sync.bump()
     native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, lora=lora, lora_sync=(t, flags, sync), **kw)  # flags now hold the epoch
     torch.cuda.synchronize()
-    res["nowait"] = graph_time(nowait)
-    lib.mi355x_set_option(b"lora_dbg", 1)
-    res["tail"] = graph_time(nowait)
+    if only is None:
+        res["nowait"] = graph_time(nowait)
+    for name, bits in (("tail", 1), ("as-plain", 1 | 4), ("hooks-only", 1 | 8), ("mma-only", 1 | 16)):
+        if only is not None and name not in only:
+            continue
+        lib.mi355x_set_option(b"lora_dbg", bits)
+        res[name] = graph_time(nowait)
     lib.mi355x_set_option(b"lora_dbg", 0)
     fl = 2.0 * M * K * N
     print(f"M={M} K={K} N={N} geglu={int(geglu)} ln={int(ln)} qkv={int(qkv)} tile={tile} R={R}: " + "  ".join(f"{k} {v:6.2f} us" for k, v in res.items())
-          + f"   | plain {fl / res['plain'] / 1e6:.0f} TF, full-(bump+plain) = {res['full'] - res['bump+plain']:+.2f} us", flush=True)
+          + (f"   | plain {fl / res['plain'] / 1e6:.0f} TF, full-(bump+plain) = {res['full'] - res['bump+plain']:+.2f} us" if only is None else ""), flush=True)
 
 
 def main():
+    if "--lib" in sys.argv:  # a bisect build of the library (scratch/bisect/lib_b<n>.so): only the as-plain variants are meaningful with it
+        native.load(sys.argv[sys.argv.index("--lib") + 1])
     native.load()
+    if "--bisect" in sys.argv:
+        case(2048, 1280, 1280, tile=1, only=("plain", "as-plain"))
+        return
+    if "--ablate" in sys.argv:
+        case(2048, 1280, 1280, tile=1)
+        return
     for tile in (0, 1):
         case(2048, 1280, 1280, tile=tile)
     case(2048, 1280, 1280, ln=True)

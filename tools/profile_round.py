@@ -64,61 +64,61 @@ def kernel_rows(db: str) -> list[tuple[str, int, int]]:
     return [(n, int(s), int(d)) for n, s, d in con.execute(f"select name, {start}, duration from kernels order by {start}")]
 
 
-def inplace(db: str, program: list[dict], tag: str) -> None:
-    rows = kernel_rows(db)
-    ours = [(n, s, d) for n, s, d in rows if "mi355x" in n or family(n) or "_kernel" in n and "at::" not in n]
+def is_ours(n: str) -> bool:
+    return "mi355x" in n or family(n) is not None or ("_kernel" in n and "at::" not in n)
+
+
+def step_map(rows: list[tuple], program: list[dict], max_steps: int = 4) -> list[list[tuple[dict, list]]]:
+    """rows: (kernel name, start, payload) of every dispatch of the traced process, in start order.  Returns, for up to `max_steps` of
+    the LAST full replays of the step program, the program entries paired with the payloads of the dispatches they issued (a split-K conv
+    = 2 dispatches, a GroupNorm = 3) -- i.e. the prologue, the warm-up and every torch kernel are left out.  Steps are delimited by the
+    CFG + solver kernel that closes each of them."""
+    ours = [(n, s, x) for n, s, x in rows if is_ours(n)]
     ends = [i for i, (n, _, _) in enumerate(ours) if "cfg_ddim_kernel" in n or "cfg_linear_step_kernel" in n]
     if len(ends) < 3:
-        print("in-place mapping: could not find the per-step boundary kernels", file=sys.stderr)
-        return
+        return []
     period = ends[-1] - ends[-2]
-    steps = []
-    for e in ends[-4:]:
-        if e - period + 1 >= 0:
-            steps.append(ours[e - period + 1 : e + 1])
-    per_class: dict[str, list[float]] = {}
-    used_steps = 0
-    for st in steps:
-        i = 0
-        ok = True
-        acc: dict[str, float] = {}
+    out = []
+    for e in ends[-max_steps:]:
+        if e - period + 1 < 0:
+            continue
+        st = ours[e - period + 1 : e + 1]
+        i, ok, mapped = 0, True, []
         for ent in program:
             what = ent["what"]
             if i >= len(st):
                 ok = False
                 break
-            fam_want = what
-            dur = 0.0
-            n, _, d = st[i]
+            n = st[i][0]
+            take = 1
             if what.startswith("mi355x_gemm"):
                 if "gemm_kernel" not in n:
                     ok = False
                     break
-                dur += d
-                i += 1
-                if i < len(st) and "splitk_reduce_kernel" in st[i][0] and ent.get("ksplit", 1) > 1:
-                    dur += st[i][2]
-                    i += 1
+                if i + 1 < len(st) and "splitk_reduce_kernel" in st[i + 1][0] and ent.get("ksplit", 1) > 1:
+                    take = 2
             elif what == "mi355x_groupnorm":
-                if "gn_fused_kernel" in n:
-                    dur += d
-                    i += 1
-                else:
-                    for _ in range(3):
-                        dur += st[i][2]
-                        i += 1
-            else:
-                dur += d
-                i += 1
-            acc.setdefault(ent["key"], 0.0)
-            acc[ent["key"]] += dur
+                take = 1 if "gn_fused_kernel" in n else 3
+            mapped.append((ent, [x for _, _, x in st[i : i + take]]))
+            i += take
         if ok:
-            used_steps += 1
-            for k, v in acc.items():
-                per_class.setdefault(k, []).append(v)
-    if not used_steps:
-        print("in-place mapping: program / trace mismatch", file=sys.stderr)
+            out.append(mapped)
+    return out
+
+
+def inplace(db: str, program: list[dict], tag: str) -> None:
+    steps = step_map([(n, s, d) for n, s, d in kernel_rows(db)], program)
+    if not steps:
+        print("in-place mapping: program / trace mismatch (or fewer than three step boundaries)", file=sys.stderr)
         return
+    per_class: dict[str, list[float]] = {}
+    for mapped in steps:
+        acc: dict[str, float] = {}
+        for ent, durs in mapped:
+            acc[ent["key"]] = acc.get(ent["key"], 0.0) + sum(durs)
+        for k, v in acc.items():
+            per_class.setdefault(k, []).append(v)
+    used_steps = len(steps)
     counts: dict[str, int] = {}
     for ent in program:
         counts[ent["key"]] = counts.get(ent["key"], 0) + 1
@@ -133,17 +133,44 @@ def inplace(db: str, program: list[dict], tag: str) -> None:
     print("\n".join(lines[:24]))
 
 
-def pmc_families(db: str) -> dict:
+def pmc_families(db: str, program: list[dict] | None = None) -> dict:
+    """Counter sums per kernel family -- and, with the recorded step program, per shape class -- over the dispatches of the STEP PROGRAM
+    only (the last full replays of it in the traced process: no prologue, no warm-up, no set-up kernels).  Without a program (the
+    calibration launch) every dispatch of the process counts.  Returns {"scope", "families": {family: {counter: {dispatches, sum}}},
+    "classes": {class key: {counter: {dispatches, sum, launches}}}}."""
     con = sqlite3.connect(db)
-    out: dict = {}
-    for name, counter, n, total, dur in con.execute("select name, counter_name, count(*), sum(counter_value), avg(duration) from pmc_events group by name, counter_name"):
-        f = family(name)
-        if f is None:
-            continue
-        d = out.setdefault(f, {}).setdefault(counter, {"dispatches": 0, "sum": 0.0})
-        d["dispatches"] += n
-        d["sum"] += total
-    return out
+    per: dict[int, dict] = {}
+    for did, name, start, counter, val in con.execute("select dispatch_id, name, min(start), counter_name, sum(counter_value) from pmc_events group by dispatch_id, counter_name"):
+        d = per.setdefault(did, {"name": name, "start": start, "c": {}})
+        d["c"][counter] = val  # (one row per XCD instance of a dispatch: summed)
+    rows = sorted(((d["name"], d["start"], d["c"]) for d in per.values()), key=lambda r: r[1])
+    fams: dict = {}
+    classes: dict = {}
+
+    def add(store: dict, key: str, cs: dict, launches: int = 0) -> None:
+        for counter, val in cs.items():
+            e = store.setdefault(key, {}).setdefault(counter, {"dispatches": 0, "sum": 0.0, "launches": 0})
+            e["dispatches"] += 1
+            e["sum"] += val
+        for counter in cs:
+            store[key][counter]["launches"] += launches
+
+    steps = step_map(rows, program) if program else []
+    if steps:
+        scope = f"step program only: {len(steps)} full replay(s) of the {len(program)} recorded launches"
+        for mapped in steps:
+            for ent, payloads in mapped:
+                f = {"mi355x_gemm(conv)": "mi355x_gemm(conv)"}.get(ent["what"], ent["what"])
+                for j, cs in enumerate(payloads):
+                    add(fams, f, cs)
+                    add(classes, ent["key"], cs, launches=1 if j == 0 else 0)
+    else:
+        scope = "whole process (no step program given, or it did not match the trace)"
+        for name, _, cs in rows:
+            f = family(name)
+            if f is not None:
+                add(fams, f, cs)
+    return {"scope": scope, "families": fams, "classes": classes}
 
 
 def main() -> None:
@@ -172,13 +199,18 @@ def main() -> None:
     passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
               "sq": ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES"]}
     got: dict[str, dict] = {}
+    got_cls: dict[str, dict] = {}
+    scope = None
+    program = json.loads(prog_path.read_text()) if prog_path.exists() else None
     for name, counters in passes.items():
         rc = run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", str(prof / name), "--", *bench, "--steps", "2", "--warmup", "1"], prof / f"{name}.log")
         db = find_db(prof / name)
         print("pmc pass", name, "rc", rc, "db", db)
         if db:
             try:
-                got[name] = pmc_families(db)
+                r = pmc_families(db, program)
+                got[name], got_cls[name], scope = r["families"], r["classes"], r["scope"]
+                print("  scope:", scope)
             except Exception as exc:  # noqa: BLE001
                 print("  failed to read", exc)
     if "fetch" in got and "write" in got:
@@ -191,7 +223,15 @@ def main() -> None:
                     calls = d["dispatches"]
                     kb = d["sum"] / calls
                     fams[f][counter] = {"dispatches": calls, "raw_kb_per_launch": kb, "bytes_per_launch": kb * 1024 * (2 if counter == "FETCH_SIZE" else 1)}
-        (OUT / f"{tag}_pmc_traffic.json").write_text(json.dumps({"how": how, "units": "counter values are KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); per KERNEL dispatch (GroupNorm: per kernel, not per call)", "families": fams}, indent=1))
+        cls = {}
+        for k in set(got_cls.get("fetch", {})) | set(got_cls.get("write", {})):
+            row = {}
+            for counter, src in (("FETCH_SIZE", got_cls.get("fetch", {})), ("WRITE_SIZE", got_cls.get("write", {}))):
+                d = src.get(k, {}).get(counter)
+                if d and d["launches"]:
+                    row[counter] = {"launches": d["launches"], "bytes_per_launch": d["sum"] / d["launches"] * 1024 * (2 if counter == "FETCH_SIZE" else 1)}
+            cls[k] = row
+        (OUT / f"{tag}_pmc_traffic.json").write_text(json.dumps({"how": how, "scope": scope, "units": "counter values are KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); families: per KERNEL dispatch (GroupNorm: per kernel, not per call); classes: per program launch (all its kernels)", "families": fams, "classes": cls}, indent=1))
         print({f: {c: round(v["bytes_per_launch"] / 1e6, 2) for c, v in cs.items()} for f, cs in fams.items()})
     # calibration of the MFMA-busy counter on a launch whose MFMA count is known exactly (tools/probe_mfma_cal.py)
     cal = None
@@ -199,7 +239,7 @@ def main() -> None:
     db = find_db(prof / "cal")
     if db:
         try:
-            c = pmc_families(db).get("mi355x_gemm", {})
+            c = pmc_families(db)["families"].get("mi355x_gemm", {})
             n_launch = c["SQ_VALU_MFMA_BUSY_CYCLES"]["dispatches"]
             busy = c["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / n_launch
             gui = c["GRBM_GUI_ACTIVE"]["sum"] / n_launch
@@ -227,7 +267,12 @@ def main() -> None:
             if busy and sq:
                 row["mfma_busy_over_sq_busy"] = busy / sq
             fams[f] = row
-        (OUT / f"{tag}_pmc_mfma.json").write_text(json.dumps({"how": how, "note": "mfma_util = (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the family) / (the same ratio of the calibration launch) x the calibration launch's known utilisation", "calibration": cal, "families": fams}, indent=1))
+        cls = {}
+        for k, cs in got_cls.get("mfma", {}).items():  # per shape class: the same anchored ratio
+            busy, gui = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("sum"), cs.get("GRBM_GUI_ACTIVE", {}).get("sum")
+            if busy and gui and cal:
+                cls[k] = {"launches": cs["GRBM_GUI_ACTIVE"]["launches"], "mfma_util": cal["mfma_util_by_construction"] * (busy / gui) / cal["SQ_VALU_MFMA_BUSY_CYCLES_over_GRBM_GUI_ACTIVE"]}
+        (OUT / f"{tag}_pmc_mfma.json").write_text(json.dumps({"how": how, "scope": scope, "classes": cls, "note": "mfma_util = (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the family) / (the same ratio of the calibration launch) x the calibration launch's known utilisation", "calibration": cal, "families": fams}, indent=1))
         print({f: {k: (round(v, 4) if isinstance(v, float) and v < 10 else v) for k, v in r.items()} for f, r in fams.items()})
     if "sq" in got:
         fams = {}
@@ -239,7 +284,7 @@ def main() -> None:
                     if c in cs:
                         row[c + "_frac_of_wave_cycles"] = cs[c]["sum"] / w
             fams[f] = row
-        (OUT / f"{tag}_pmc_sq.json").write_text(json.dumps({"how": how, "families": fams}, indent=1))
+        (OUT / f"{tag}_pmc_sq.json").write_text(json.dumps({"how": how, "scope": scope, "families": fams}, indent=1))
         print({f: {k: round(v, 3) for k, v in r.items() if k.endswith("frac_of_wave_cycles")} for f, r in fams.items()})
 
 
