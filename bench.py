@@ -104,7 +104,6 @@ def program_entry(e) -> dict:
 
     fn, args, what, _ = e
     a = getattr(args[0], "_obj", None)
-    what = what.split("@")[0]
     if what.startswith("mi355x_gemm"):
         return {"what": what, "key": native.gemm_signature(a) + (f":tile{a.tile}/{a.stages}" if a.tile else ""), "ksplit": int(a.ksplit)}
     if what == "mi355x_attention":
@@ -213,7 +212,7 @@ def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict
     groups: dict[str, list] = {}
     for e in low.step:
         if e[0] is not None:
-            groups.setdefault(e[2].split("@")[0], []).append(e)  # launches on the side stream belong to the same family
+            groups.setdefault(e[2], []).append(e)
     fam = {}
     for name, ops in groups.items():
         sec = time_ops(ops)

@@ -110,12 +110,9 @@ typedef struct {
     const void* res;        /* [M][ldres] or NULL */
     int64_t ldres;
     const void* zeros;      /* >= 256 zero bytes in device memory; required when conv == 1 */
-    int32_t tile;           /* 0 = let the library choose; 1: 128x128  2: 128x64  3: 64x128  4: 64x64  5: 256x128 (M x N);
+    int32_t tile;           /* 0 = let the library choose; 1: 128x128  2: 128x64  3: 64x128  4: 64x64 (M x N);
                                6: 128x128 computed by 8 waves in two K groups (even / odd K blocks, summed through LDS in a fixed order):
-                               for launches with fewer output tiles than CUs;
-                               7: 256x128, 8 waves in two groups that run one barrier slot apart (one group's MFMA section overlaps the other's
-                               LDS-read / load-issue section), 3 LDS stages: for launches with many tiles;
-                               8: the same with two barrier slots per K block (32-MFMA sections) instead of four */
+                               for launches with fewer output tiles than CUs */
     int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
                                partial sums into `ws`, a second launch adds them in a fixed order (deterministic) and
                                applies the epilogue.  Not combinable with geglu. */
@@ -130,7 +127,7 @@ typedef struct {
     int32_t prefetch_blocks;
     int32_t out_kblocked;   /* geglu == 1 only: store the [M][N/2] result K-blocked, [(N/2)*sizeof/128][M][128 bytes] (ldo ignored), ready to be
                                the x operand (kblocked bit 1) of the next GEMM -- FeedForward's second Linear reads 10 KB rows otherwise */
-    int32_t stages;         /* LDS pipeline depth: 0 = let the library choose, 2..4 (tiles 5 and 6: 2 or 3 / 2 only) */
+    int32_t stages;         /* LDS pipeline depth: 0 = let the library choose, 2..4 (tile 6: 2 only) */
     /* Transposed column group (conv == 0): when out_t != NULL, output columns n >= nt_begin (a multiple of 128) are written as
        out_t[(n - nt_begin) * ldt + m] (the V^T [C][B*L] layout mi355x_attention wants) and only columns < nt_begin go to `out`.
        One launch over the stacked weights [Wq; Wk; Wv] then yields Q | K row-major and V transposed: the three projections of
@@ -169,7 +166,7 @@ typedef struct {
          lora_flags int32[groups * ceil(M / 32)], zeroed once by the caller and private to this call site (they keep the last epoch),
          lora_epoch device pointer to an int32 whose value differs from every value left in lora_flags: increment it (mi355x_epoch_bump)
                     before each launch, or once per replay of a recorded program whose LoRA launches each own their flags,
-       and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with xattn_kv, out_f32 or the 8-wave tiles;
+       and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with out_f32 or the 8-wave tile;
        with ksplit the first split carries the LoRA term.
        With ln_stats (x un-normalised): lora_a carries gamma like w does (A' = A . diag(gamma)) and the caller adds
          lora_ls[g][r] = sum_k A'_g[r][k],   lora_lc[g][r] = sum_k beta[k] A_g[r][k]        (float32, [groups][lora_r]). */
@@ -183,20 +180,6 @@ typedef struct {
     void* lora_t;
     int32_t* lora_flags;
     const int32_t* lora_epoch;
-    /* Cross-attention in the epilogue of its q-projection (since ABI 4) -- the second Residual of CrossAttentionBlock,
-       src/refiners/foundationals/latent_diffusion/cross_attention.py:25-73: Attention(Linear_q(LayerNorm(x)), K, V) with the text keys
-       (and, with the IP-Adapter, Sum(SDPA, ImageCrossAttention), image_prompt.py:237-309) -- for K / V that are constant over the
-       sampling loop and SHORT: at most 80 keys per stream and 96 in total (rounded up to 16 per stream).  The launch computes
-       Q = x W^T (+ bias | LayerNorm correction), rounds it to `dtype` like the reference's Linear output, and writes
-         out[m][h*64 + :] = sum_s out_scale_s * softmax_k(xattn_scale * Q[m, h] . K_s[b, k, h]) V_s[b, k, h],     b = m / xattn_lq
-       instead of Q: a 128 x 128 output tile is 128 queries x 2 heads, Q never reaches memory and the separate attention launch is gone.
-       xattn_kv: `const mi355x_kv_stream[xattn_nstream]` (declared below; same K / V^T layouts and padding rule as mi355x_attention, head
-       dim 64), NULL = off.  M and xattn_lq multiples of 128, N a multiple of 128; one segment; no conv / ksplit / geglu / rowbias / res /
-       out_t / stats_out / out_f32 / in-launch LoRA.  `tile` / `stages` are ignored (the 128 x 128 tile is the only one that fits). */
-    const void* xattn_kv;
-    int32_t xattn_nstream;
-    int32_t xattn_lq;
-    float xattn_scale;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

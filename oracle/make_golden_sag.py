@@ -51,5 +51,53 @@ def main() -> None:
     save_file(out, str(GOLD / "sdxl_sag.safetensors"))
 
 
+def main_solvers() -> None:
+    """The same guidance through the solvers whose add_noise / remove_noise the reference can evaluate besides DDIM (self_attention_guidance.py:
+    86-95 calls solver.remove_noise / add_noise): DPM-Solver++ (two consecutive steps: first- then second-order update) and LCMSolver (one
+    step; its re-noising draw comes from the global CPU generator, seeded here).  Euler is not in the file: refiners raises IndexError there
+    (float timesteps used as table indices).  -> tests/golden/sdxl_sag_solvers.safetensors"""
+    from refiners.foundationals.latent_diffusion.solvers import DPMSolver, LCMSolver
+
+    shapes = synth.model_shapes(SDXLUNet(4, device="meta"))
+    out = {}
+    with torch.no_grad():
+        unet = reference_model(SDXLUNet, shapes, CFG["weight_seed"])
+        inp = synth.sdxl_inputs(1, CFG["latent_hw"], CFG["input_seed"])
+        kw = dict(clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], condition_scale=CFG["condition_scale"])
+        sd = StableDiffusion_XL(unet=unet, lda=rfl.Chain(rfl.Identity()), clip_text_encoder=rfl.Chain(rfl.Identity()),  # type: ignore[arg-type]
+                                solver=DPMSolver(num_inference_steps=CFG["num_steps"]))
+        sd.set_self_attention_guidance(enable=True, scale=CFG["sag_scale"])
+        x1 = sd(inp["x"], step=0, **kw)
+        x2 = sd(x1, step=1, **kw)
+        out["dpm_x1"], out["dpm_x2"] = x1.contiguous(), x2.contiguous()
+        print("dpm", float(x1.abs().mean()), float(x2.abs().mean()), flush=True)
+        # (a fresh model per solver: re-injecting the adapter into a tree it was ejected from leaves the reference's attention-map context unset)
+        unet = reference_model(SDXLUNet, shapes, CFG["weight_seed"])
+        sd = StableDiffusion_XL(unet=unet, lda=rfl.Chain(rfl.Identity()), clip_text_encoder=rfl.Chain(rfl.Identity()),  # type: ignore[arg-type]
+                                solver=LCMSolver(num_inference_steps=4))
+        sd.set_self_attention_guidance(enable=True, scale=CFG["sag_scale"])
+        torch.manual_seed(CFG["input_seed"] + 7)
+        out["lcm_x1"] = sd(inp["x"], step=0, **dict(kw, condition_scale=1.5)).contiguous()
+        sd.set_self_attention_guidance(enable=True, scale=0.0)  # the guidance term times zero
+        torch.manual_seed(CFG["input_seed"] + 7)
+        out["lcm_x1_without_sag"] = sd(inp["x"], step=0, **dict(kw, condition_scale=1.5)).contiguous()
+        print("lcm", float((out["lcm_x1"] - out["lcm_x1_without_sag"]).abs().mean()), flush=True)
+        unet = reference_model(SDXLUNet, shapes, CFG["weight_seed"])
+        sd = StableDiffusion_XL(unet=unet, lda=rfl.Chain(rfl.Identity()), clip_text_encoder=rfl.Chain(rfl.Identity()))  # type: ignore[arg-type]
+        try:
+            from refiners.foundationals.latent_diffusion.solvers import Euler
+
+            sd.solver = Euler(num_inference_steps=CFG["num_steps"])
+            sd.set_self_attention_guidance(enable=True, scale=CFG["sag_scale"])
+            sd(inp["x"], step=0, **kw)
+            raise SystemExit("the reference evaluated SAG with Euler: the mirror's refusal is wrong")
+        except IndexError as e:
+            print("euler: the reference raises IndexError:", str(e)[:80])
+    save_file(out, str(GOLD / "sdxl_sag_solvers.safetensors"))
+
+
 if __name__ == "__main__":
-    main()
+    if "--solvers" in sys.argv:
+        main_solvers()
+    else:
+        main()

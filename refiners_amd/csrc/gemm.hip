@@ -151,7 +151,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     }
     if (a->lora_b) {
         if (a->ksplit > 1 && a->geglu) return MI355X_ESHAPE;
-        if ((a->ln_stats && (!a->lora_ls || !a->lora_lc)) || a->out_f32 || a->xattn_kv || a->lora_groups < 1 || a->lora_groups > 3 || a->lora_nb[0] != 0 ||
+        if ((a->ln_stats && (!a->lora_ls || !a->lora_lc)) || a->out_f32 || a->lora_groups < 1 || a->lora_groups > 3 || a->lora_nb[0] != 0 ||
             !aligned16(a->lora_b) || (a->lora_r != 32 && a->lora_r != 64 && a->lora_r != 128) || !a->lora_t || !aligned16(a->lora_t) || !a->lora_flags ||
             !a->lora_epoch || (a->conv && a->lora_groups != 1))
             return MI355X_ESHAPE;
@@ -176,33 +176,6 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     if (a->stats_out) {
         if (a->conv || a->ksplit > 1 || a->geglu == 1 || has_t || !vec || a->N % 64 || (reinterpret_cast<uintptr_t>(a->stats_out) & 7)) return MI355X_ESHAPE;
         p.stats_out = static_cast<float*>(a->stats_out);
-    }
-    if (a->xattn_kv) {
-        // cross-attention in the epilogue: 128 x 128 tiles = 128 queries x 2 heads of 64, nothing else in the epilogue but bias / LayerNorm
-        const mi355x_kv_stream* kv = static_cast<const mi355x_kv_stream*>(a->xattn_kv);
-        if (a->conv || a->nseg != 1 || a->ksplit > 1 || a->geglu || a->rowbias || a->res || has_t || a->stats_out || a->out_f32 || a->lora_b || a->out_kblocked || !a->out || !vec ||
-            a->M % 128 || a->N % 128 || a->xattn_lq <= 0 || a->xattn_lq % 128 || a->M % a->xattn_lq || a->xattn_nstream < 1 || a->xattn_nstream > 2)
-            return MI355X_ESHAPE;
-        int blocks = 0;
-        for (int s = 0; s < a->xattn_nstream; ++s) {
-            const mi355x_kv_stream& k = kv[s];
-            if (!k.k || !k.vt || k.Lk <= 0 || k.Lk > 16 * mi355x::XA_SB || !aligned16(k.k) || !aligned16(k.vt) || (k.ldk * es) % 16 || (k.ldvt * es) % 16 ||
-                (k.k_batch_stride * es) % 16 || (k.vt_batch_stride * es) % 16)
-                return MI355X_ESHAPE;
-            blocks += (k.Lk + 15) / 16;
-            p.xa.k[s] = static_cast<const char*>(k.k);
-            p.xa.vt[s] = static_cast<const char*>(k.vt);
-            p.xa.ldkb[s] = k.ldk * es;
-            p.xa.kbsb[s] = k.k_batch_stride * es;
-            p.xa.ldvtb[s] = k.ldvt * es;
-            p.xa.vtbsb[s] = k.vt_batch_stride * es;
-            p.xa.Lk[s] = k.Lk;
-            p.xa.out_scale[s] = k.out_scale;
-        }
-        if (blocks > mi355x::XA_MAXB) return MI355X_ESHAPE;
-        p.xa.nstream = a->xattn_nstream;
-        p.xa.Lq = a->xattn_lq;
-        p.xa.c = a->xattn_scale * 1.44269504088896340736f;
     }
     for (int i = 0; i < MI355X_MAX_PREFETCH; ++i) {
         p.pf_ptr[i] = static_cast<const char*>(a->prefetch[i]);

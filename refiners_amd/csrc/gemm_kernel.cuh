@@ -18,12 +18,6 @@
 //     group with its own LDS ring; the two partial tiles are added through LDS in a fixed order.  For launches with fewer
 //     tiles than CUs this puts two waves on every SIMD (twice the bytes in flight, each wave's LDS / barrier stalls
 //     covered by the other) without the HBM round trip of a split-K across workgroups;
-//   * STAG ("tile 7": 256 x 128, 8 waves, 3 LDS stages): the two 4-wave groups (rows 0-127 / 128-255, sharing the weight tile) run ONE
-//     BARRIER SLOT APART.  Every wave alternates a memory section (8 ds_read_b128 of the half K block it multiplies next + half of its
-//     share of the global->LDS loads two blocks ahead) with a matrix section (16 MFMAs), sections separated by workgroup barriers; group 1
-//     executes one extra barrier up front, so at any time one group is in its matrix section while the other reads / issues loads on the
-//     same SIMDs (the 8-phase schedule of the vendor guide, section 5, on this kernel's loader and epilogue).  One workgroup per CU
-//     streams 25 % fewer bytes per FLOP through the L2 -> LDS path than two co-resident 128 x 128 workgroups;
 //   * conv mode gathers the activation rows straight from the NHWC image (zero padding comes from a zero page, nearest
 //     2x upsampling and stride 2 are address arithmetic), so no im2col buffer, no materialised upsample / concat;
 //   * LayerNorm folded in: a launch whose x is LN(r) reads r itself; the weights carry gamma (W' = W . diag(gamma)) and the
@@ -119,16 +113,6 @@ struct GemmP {
     int pf_blocks, pf_mode;  // pf_mode: 1 = plain loads, 2 = non-temporal loads (L2 evict-first)
     int pn, hm, hn;          // XCD rasterisation: the 8 XCDs own a pm x pn grid of hm x hn-tile regions
     int vec_ok;
-    // cross-attention in the epilogue (XATT kernels): the tile's 128 rows x 2 heads of Q never reach memory
-    struct Xatt {
-        const char* k[2];
-        const char* vt[2];
-        int64_t ldkb[2], kbsb[2], ldvtb[2], vtbsb[2];  // bytes
-        int Lk[2];
-        float out_scale[2];
-        int nstream, Lq;
-        float c;  // scale * log2(e)
-    } xa;
 };
 
 // Chan's pairwise update of (count, mean, M2); exact for empty operands.
@@ -139,272 +123,6 @@ MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, flo
         mean += d * f;
         m2 += m2b + d * d * n * f;
         n = nt;
-    }
-}
-
-// lane <-> lane ^ 16 / lane ^ 32 exchanges as row / half swaps (see attention.hip): after the call a and b hold the two partners' values
-MI_DEV void xa_swap16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-MI_DEV void xa_swap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-MI_DEV float xa_group_max(float x) {
-    float a = x, b = x;
-    xa_swap16(a, b);
-    a = fmaxf(a, b), b = a;
-    xa_swap32(a, b);
-    return fmaxf(a, b);
-}
-MI_DEV float xa_group_sum(float x) {
-    float a = x, b = x;
-    xa_swap16(a, b);
-    a = a + b, b = a;
-    xa_swap32(a, b);
-    return a + b;
-}
-
-// ---- cross-attention in the epilogue of its q-projection -------------------------------------------------------------------------
-// CrossAttentionBlock's second Residual (cross_attention.py:25-73): Q = Linear(LayerNorm(x)); out = SDPA(Q, K_text, V_text) (+ scale * SDPA(Q,
-// K_ip, V_ip), image_prompt.py:237-309) with 77 (+ 4 / 16) keys that are constant over the sampling loop.  A 128 x 128 output tile of the
-// projection IS 128 queries x 2 heads of 64, one head per wave column, and in the A = weights / B = activations orientation a lane owns, per
-// 16-query block i, the 16 consecutive head-dim values 16 g .. 16 g + 15 of query c16: MMA step s takes elements 16 g + EPC s .. as the B
-// fragment, and the key row's 16-byte chunk (16 / EPC) g + s as the A fragment (the same head-dim permutation on both sides of the dot
-// product).  K / V^T of the two heads are staged into the drained K-loop ring in 16-key blocks (at most 5 per stream, 6 in total); a
-// stream's scores fit in registers, so its softmax is a plain (not online) one.  The S^T = K Q^T orientation, the P -> B-operand packing, the
-// permuted V^T rows and the store mapping are those of attn_kernel (attention.hip).
-constexpr int XA_MAXB = 6;  // key blocks of 16 per workgroup head: e.g. 5 (77 text keys) + 1 (4 or 16 image-prompt keys)
-constexpr int XA_SB = 5;    // key blocks of one stream
-
-template <typename T> constexpr int xa_head_bytes() { return XA_MAXB * 16 * 64 * (int)sizeof(T) + XA_MAXB * 64 * 16 * (int)sizeof(T); }
-
-template <typename T, int MT, int NT>
-MI_DEV void xatt_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], char* smem, const float* rowstat, int m0, int n0, int wm, int wn, int tid) {
-    static_assert(MT == 4 && NT == 4, "cross-attention epilogue: 64 x 64 per wave");
-    constexpr int EPC = DT<T>::EPC, ES = sizeof(T), NS = 16 / EPC;
-    constexpr int ROWB = 64 * ES, CPR = ROWB / 16;
-    constexpr int KHEAD = XA_MAXB * 16 * ROWB;  // K rows of one head: [key block][16 keys][64 d], rows swizzled like every K tile
-    constexpr int VROWB = 16 * ES;              // one V^T row of one key block: 16 keys
-    constexpr int VBLK = 64 * VROWB;            // [64 d (permuted row order)][16 keys]
-    constexpr int HEADB = KHEAD + XA_MAXB * VBLK;
-    constexpr bool IS_BF16 = (ES == 2);
-    const int lane = tid & 63, g = lane >> 4, c16 = lane & 15;
-    const GemmP::Xatt& xa = p.xa;
-    const int nb0 = (xa.Lk[0] + 15) >> 4, nb1 = xa.nstream > 1 ? (xa.Lk[1] + 15) >> 4 : 0, nbt = nb0 + nb1;
-    const int b = m0 / xa.Lq;  // sample of this row tile
-    const int h0 = n0 >> 6;    // first of the tile's two heads
-    const T* bias = reinterpret_cast<const T*>(p.bias);
-
-    // ---- Q: bias / LayerNorm correction, rounded to T (the reference's Linear output), kept as B-operand fragments ----
-    frag_t qf[MT][NS];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int mrow = wm * 64 + 16 * i + c16;
-        const int n = n0 + wn * 64 + 16 * g;
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
-        if (p.ln_stats) {
-            const float mean = rowstat[2 * mrow], rstd = rowstat[2 * mrow + 1];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 sv = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4 * c), cv = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * c + e] = rstd * (v[4 * c + e] - mean * sv[e]) + cv[e];
-            }
-        } else if (bias) {
-#pragma unroll
-            for (int c = 0; c < 16 / EPC; ++c) {
-                Vec16<T> bv = load16<T>(bias + n + c * EPC);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            Vec16<T> qv;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) qv.set(e, v[EPC * s + e]);
-            qf[i][s] = __builtin_bit_cast(frag_t, qv.v);
-        }
-    }
-
-    __syncthreads();  // every wave has left the K loop (and read rowstat): the ring can be overwritten
-
-    // ---- K and V^T of the tile's two heads -> LDS (global -> registers -> LDS, all loads of a pass in flight) ----
-    {
-        constexpr int KIT = 2 * XA_MAXB * 16 * CPR / 256;  // K chunks per thread at full occupancy of the 6 blocks
-        const int krows = nbt * 16, ktot = 2 * krows * CPR;
-        frag_t kr[KIT];
-#pragma unroll
-        for (int it = 0; it < KIT; ++it) {
-            const int idx = it * 256 + tid;
-            if (idx < ktot) {
-                const int hh = idx / (krows * CPR), r2 = idx - hh * (krows * CPR);
-                const int row = r2 / CPR, pch = r2 - row * CPR;
-                const int blk = row >> 4, sidx = blk >= nb0 ? 1 : 0;
-                int key = 16 * (sidx ? blk - nb0 : blk) + (row & 15);
-                key = key < xa.Lk[sidx] ? key : xa.Lk[sidx] - 1;
-                kr[it] = *reinterpret_cast<const frag_t*>(xa.k[sidx] + (int64_t)b * xa.kbsb[sidx] + (int64_t)key * xa.ldkb[sidx] + (int64_t)(h0 + hh) * ROWB + pch * 16);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < KIT; ++it) {
-            const int idx = it * 256 + tid;
-            if (idx < ktot) {
-                const int hh = idx / (krows * CPR), r2 = idx - hh * (krows * CPR);
-                const int row = r2 / CPR, pch = r2 - row * CPR;
-                *reinterpret_cast<frag_t*>(smem + hh * HEADB + tile_off<ROWB>(row, pch)) = kr[it];
-            }
-        }
-        constexpr int VCH = VROWB / 16;                     // 16-byte chunks per V^T row of one key block
-        constexpr int VIT = 2 * XA_MAXB * 64 * VCH / 256;
-        const int vper = nbt * 64 * VCH, vtot = 2 * vper;
-        frag_t vr[VIT];
-#pragma unroll
-        for (int it = 0; it < VIT; ++it) {
-            const int idx = it * 256 + tid;
-            if (idx < vtot) {
-                const int hh = idx / vper, r2 = idx - hh * vper;
-                const int blk = r2 / (64 * VCH), r3 = r2 - blk * (64 * VCH);
-                const int row = r3 / VCH, ch = r3 - row * VCH;
-                const int sidx = blk >= nb0 ? 1 : 0, lb = sidx ? blk - nb0 : blk;
-                const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
-                const int d = 16 * a + 4 * j + bb;  // head-dim index stored in LDS row `row` (attn_kernel's permutation: 16 consecutive outputs per lane)
-                vr[it] = *reinterpret_cast<const frag_t*>(xa.vt[sidx] + ((int64_t)(h0 + hh) * 64 + d) * xa.ldvtb[sidx] + (int64_t)b * xa.vtbsb[sidx] + (int64_t)(16 * lb) * ES + ch * 16);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < VIT; ++it) {
-            const int idx = it * 256 + tid;
-            if (idx < vtot) {
-                const int hh = idx / vper, r2 = idx - hh * vper;
-                const int blk = r2 / (64 * VCH), r3 = r2 - blk * (64 * VCH);
-                const int row = r3 / VCH, ch = r3 - row * VCH;
-                *reinterpret_cast<frag_t*>(smem + hh * HEADB + KHEAD + blk * VBLK + row * VROWB + ch * 16) = vr[it];
-            }
-        }
-    }
-    __syncthreads();
-
-    const char* kb = smem + wn * HEADB;
-    const char* vb = kb + KHEAD;
-    T* out = reinterpret_cast<T*>(p.out);
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {  // the wave's four 16-query blocks, two at a time (registers)
-        f32x4 res[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) res[i][0] = res[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            if (sidx < xa.nstream) {
-                const int nb = sidx ? nb1 : nb0, boff = sidx ? nb0 : 0, Lk = xa.Lk[sidx];
-                // ---- S^T = K Q^T for every key block of the stream ----
-                f32x4 st[XA_SB + 1][2];  // + 1: the zero partner of an odd last block in the P V product
-#pragma unroll
-                for (int t = 0; t <= XA_SB; ++t) {
-                    st[t][0] = st[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (t < nb) {  // wave-uniform: absent blocks cost nothing (their P stays 0)
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) {
-                            const frag_t kf = lds_read_frag(kb, tile_off<ROWB>(16 * (boff + t) + c16, NS * g + s));
-#pragma unroll
-                            for (int jq = 0; jq < 2; ++jq) mma_step<T>(st[t][jq], kf, qf[2 * pr + jq][s]);
-                        }
-                        if (16 * t + 16 > Lk) {  // the stream's ragged last block
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (16 * t + 4 * g + r >= Lk) st[t][0][r] = st[t][1][r] = -INFINITY;
-                        }
-                    }
-                }
-                // ---- softmax over the stream's keys (base 2, scale folded), P left in st ----
-                float inv[2];
-#pragma unroll
-                for (int jq = 0; jq < 2; ++jq) {
-                    float mx = st[0][jq][0];
-#pragma unroll
-                    for (int t = 0; t < XA_SB; ++t)
-                        if (t < nb) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][jq][r]);
-                        }
-                    mx = xa_group_max(mx);
-                    const float mc = mx * xa.c;
-                    float ps = 0.f;
-#pragma unroll
-                    for (int t = 0; t < XA_SB; ++t)
-                        if (t < nb) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float e = fast_exp2(st[t][jq][r] * xa.c - mc);
-                                st[t][jq][r] = e;
-                                ps += e;
-                            }
-                        }
-                    inv[jq] = xa.out_scale[sidx] / xa_group_sum(ps);
-                }
-                // ---- O^T = V^T P^T ----
-                f32x4 o[4][2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i][0] = o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (IS_BF16) {
-#pragma unroll
-                    for (int u = 0; u < (XA_SB + 1) / 2; ++u) {
-                        if (2 * u < nb) {
-                            frag_t pb[2];
-#pragma unroll
-                            for (int jq = 0; jq < 2; ++jq) {
-                                bf16x8 pk;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    pk[r] = (bf16_t)st[2 * u][jq][r];
-                                    pk[4 + r] = (bf16_t)st[2 * u + 1][jq][r];
-                                }
-                                pb[jq] = __builtin_bit_cast(frag_t, pk);
-                            }
-                            const int ba = boff + 2 * u, bc = boff + (2 * u + 1 < nb ? 2 * u + 1 : nb - 1);  // a missing partner block: P = 0, any finite V^T
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int row = 16 * i + c16;
-                                const half_frag_t va = lds_read_half(vb, ba * VBLK + row * VROWB + 8 * g);
-                                const half_frag_t vc = lds_read_half(vb, bc * VBLK + row * VROWB + 8 * g);
-                                const frag_t vf = frag_t{va[0], va[1], vc[0], vc[1]};
-#pragma unroll
-                                for (int jq = 0; jq < 2; ++jq) mma_step<T>(o[i][jq], vf, pb[jq]);
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < XA_SB; ++t) {
-                        if (t < nb) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const frag_t vf = lds_read_frag(vb, (boff + t) * VBLK + (16 * i + c16) * VROWB + 16 * g);
-#pragma unroll
-                                for (int jq = 0; jq < 2; ++jq) mma_step<T>(o[i][jq], vf, __builtin_bit_cast(frag_t, st[t][jq]));
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jq = 0; jq < 2; ++jq) res[i][jq] += o[i][jq] * inv[jq];
-            }
-        }
-        // ---- store: lane owns d = 16 g + 4 i + r (16 consecutive) of query 16 (2 pr + jq) + c16 ----
-#pragma unroll
-        for (int jq = 0; jq < 2; ++jq) {
-            const int m = m0 + wm * 64 + 16 * (2 * pr + jq) + c16;
-            T* op = out + (int64_t)m * p.ldo + n0 + wn * 64 + 16 * g;
-#pragma unroll
-            for (int c = 0; c < 16 / EPC; ++c) {
-                Vec16<T> ov;
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) ov.set(e, res[(c * EPC + e) >> 2][jq][(c * EPC + e) & 3]);
-                store16<T>(op + c * EPC, ov);
-            }
-        }
     }
 }
 
@@ -569,8 +287,8 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
     if (tid == 0) __hip_atomic_store(p.lora_flags + pgi * npb + tm, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
-__global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_eu(XATT ? 2 : 1))) void gemm_kernel(const GemmP p) {
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
+__global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_eu(1))) void gemm_kernel(const GemmP p) {
     constexpr int NW = WM * WN;           // waves per K group
     constexpr int NTHR = NW * 64;         // threads per K group: the loader geometry
     constexpr int NTHR_ALL = NTHR * KG;   // threads per workgroup
@@ -578,10 +296,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     constexpr int XI = BM * 8 / NTHR, WI = BN * 8 / NTHR;
     constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
-    static_assert(!LORA || (KG == 1 && NTHR == 256 && WN == 2 && !STAG && !XATT && NSTAGE == 2), "in-launch LoRA: 4 waves as 2 x 2, two LDS stages");
-    static_assert(!STAG || (BM == 256 && BN == 128 && WM == 4 && WN == 2 && NSTAGE == 3 && KG == 1 && !LORA), "staggered schedule: 256 x 128, 8 waves, 3 stages");
+    static_assert(!LORA || (KG == 1 && NTHR == 256 && WN == 2 && NSTAGE == 2), "in-launch LoRA: 4 waves as 2 x 2, two LDS stages");
     static_assert(KG == 1 || KG == 2, "one or two K groups");
-    static_assert(!XATT || (BM == 128 && BN == 128 && WM == 2 && WN == 2 && !CONV && KG == 1 && !LORA && !STAG), "cross-attention epilogue: the 128 x 128 tile, 2 x 2 waves");
     constexpr int WNE = 16 * NT;  // columns per wave
     constexpr int WME = 16 * MT;  // rows per wave
     static_assert(BM * 8 % NTHR == 0 && BN * 8 % NTHR == 0, "tile/thread mismatch");
@@ -802,25 +518,6 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         for (int a = 0; a < KG; ++a) advance();
     };
 
-    auto issue_half = [&](int buf, int half) __attribute__((always_inline)) {  // STAG: this thread's loads of one K block in two instalments
-        char* xs = smem_g + buf * STAGE;
-        char* ws = xs + XBYTES;
-#pragma unroll
-        for (int it = 0; it < XI; ++it) {
-            if ((it * 2) / XI != half) continue;
-            const char* src;
-            if constexpr (CONV) src = xbase[it] ? xbase[it] + (int64_t)cb * 128 : p.zeros + xcoff[it];
-            else src = xbase[it] + xoff;
-            glds16(src, xs + (it * NTHR + wid * 64) * 16);
-        }
-#pragma unroll
-        for (int it = 0; it < WI; ++it) {
-            if ((it * 2) / WI != half) continue;
-            glds16(wbase[it] + woff, ws + (it * NTHR + wid * 64) * 16);
-        }
-        if (half == 1) advance();
-    };
-
     // ---- software pipeline: NSTAGE LDS buffers, D = NSTAGE - 1 K blocks in flight -------------------------------------
     // per iteration: counted vmcnt (block t has landed, the D-1 younger ones stay in flight) -> raw barrier (no vmcnt(0)
     // drain, guide section 5 "pipelining across barriers") -> issue block t+D into the buffer block t-1 was computed from
@@ -843,18 +540,9 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             }
         }
     }
-    if constexpr (STAG) {
 #pragma unroll
-        for (int s0 = 0; s0 < 2; ++s0)
-            if (s0 < total_kb) {
-                issue_half(s0, 0);
-                issue_half(s0, 1);
-            }
-    } else {
-#pragma unroll
-        for (int s0 = 0; s0 < D; ++s0)
-            if (s0 < my_kb) issue(s0);
-    }
+    for (int s0 = 0; s0 < D; ++s0)
+        if (s0 < my_kb) issue(s0);
 
     if (p.ln_stats) {
         // LayerNorm consumer: (mean, rstd) of the tile's BM rows from the producer's 32-column partials, TPR threads per row,
@@ -1051,149 +739,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             trips(std::false_type{}, 0, max_kb);
         }
     };
-    // ---- the staggered schedule (STAG): 4 barrier slots per K block; group 0 = waves 0-3 (wm 0, 1), group 1 = waves 4-7 one slot behind ---
-    //   slot     group 0                 group 1
-    //   4t       MEM_a(t)                MMA_b(t-1)          MEM_a(t): ds_read F0(t), issue first half of block t+2
-    //   4t+1     MMA_a(t)                MEM_a(t)            MEM_b(t): ds_read F1(t), issue second half of block t+2, vmcnt: block t+1 landed
-    //   4t+2     MEM_b(t)                MMA_a(t)
-    //   4t+3     MMA_b(t)                MEM_b(t)
-    // Block t+1 is first read in slot 4t+4; every wave has waited for its own part of it by the end of slot 4t+3.  Block t+2 goes into
-    // the buffer of block t-1, whose last reads (group 1's MEM_b(t-1), slot 4t-1) are retired by the lgkmcnt(0) in front of that slot's
-    // closing barrier.  Both groups execute the same number of barriers (group 1 one up front, group 0 one at the end).
-    auto stagloop = [&](auto trc) {
-        constexpr bool TR = decltype(trc)::value;
-        constexpr int HL = LPS / 2;  // loads per thread per half block
-        static_assert(XI % 2 == 0 && WI % 2 == 0, "loads split in two instalments");
-        frag_t xf[MT], wf[NT];
-        const int grp = wid / (NW / 2);
-        auto read_half = [&](int blk, int kk) {
-            const char* xs = smem_g + (blk % NSTAGE) * STAGE;
-            const char* ws = xs + XBYTES;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) xf[i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wf[j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
-        };
-        auto mma_half = [&]() {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if constexpr (TR) mma_step<T>(acc[i][j], xf[i], wf[j]);
-                    else mma_step<T>(acc[i][j], wf[j], xf[i]);
-                }
-        };
-        auto slot_end = [&]() {  // retire this wave's LDS reads, meet the other group, pin the section boundary for the scheduler
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // blocks 0 and 1 were issued whole by the prologue below; block 0 must have landed before slot 0
-        if (total_kb > 1) wait_vm<LPS>();
-        else wait_vm0();
-        slot_end();
-        if (grp == 1) {
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        for (int t = 0; t < total_kb; ++t) {
-            const bool more = t + 2 < total_kb;
-            read_half(t, 0);  // MEM_a(t)
-            if (more) issue_half((t + 2) % NSTAGE, 0);
-            slot_end();
-            __builtin_amdgcn_s_setprio(1);
-            mma_half();       // MMA_a(t)
-            __builtin_amdgcn_s_setprio(0);
-            slot_end();
-            read_half(t, 1);  // MEM_b(t)
-            if (more) {
-                issue_half((t + 2) % NSTAGE, 1);
-                wait_vm<LPS>();  // this wave's part of block t+1 has landed (block t+2's loads stay in flight)
-            } else {
-                wait_vm0();
-            }
-            slot_end();
-            __builtin_amdgcn_s_setprio(1);
-            mma_half();       // MMA_b(t)
-            __builtin_amdgcn_s_setprio(0);
-            slot_end();
-        }
-        if (grp == 0) {
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        (void)HL;
-    };
-    // The same with TWO slots per K block (STAG == 2): MEM(t) reads all 16 fragments of block t, issues this thread's 6 loads of block
-    // t+2 and waits for its part of block t+1; MMA(t) is 32 MFMAs.  Half the barriers, twice the fragment registers.
-    //   slot 2t: group 0 MEM(t), group 1 MMA(t-1);   slot 2t+1: group 0 MMA(t), group 1 MEM(t)
-    auto stagloop2 = [&](auto trc) {
-        constexpr bool TR = decltype(trc)::value;
-        frag_t xf[2][MT], wf[2][NT];
-        const int grp = wid / (NW / 2);
-        auto slot_end = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if (total_kb > 1) wait_vm<LPS>();
-        else wait_vm0();
-        slot_end();
-        if (grp == 1) {
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        for (int t = 0; t < total_kb; ++t) {
-            const char* xs = smem_g + (t % NSTAGE) * STAGE;
-            const char* ws = xs + XBYTES;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) xf[kk][i] = lds_read_frag(xs, tile_off<128>(wm * WME + 16 * i + c16, 4 * kk + g));
-#pragma unroll
-                for (int j = 0; j < NT; ++j) wf[kk][j] = lds_read_frag(ws, tile_off<128>(wn * WNE + 16 * j + c16, 4 * kk + g));
-            }
-            if (t + 2 < total_kb) {
-                issue_half((t + 2) % NSTAGE, 0);
-                issue_half((t + 2) % NSTAGE, 1);
-                wait_vm<LPS>();
-            } else {
-                wait_vm0();
-            }
-            slot_end();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        if constexpr (TR) mma_step<T>(acc[i][j], xf[kk][i], wf[kk][j]);
-                        else mma_step<T>(acc[i][j], wf[kk][j], xf[kk][i]);
-                    }
-            __builtin_amdgcn_s_setprio(0);
-            slot_end();
-        }
-        if (grp == 0) {
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    if constexpr (STAG == 2) {
-        if constexpr (CONV) {
-            stagloop2(std::false_type{});
-        } else {
-            if (tr) stagloop2(std::true_type{});
-            else stagloop2(std::false_type{});
-        }
-    } else if constexpr (STAG == 1) {
-        if constexpr (CONV) {
-            stagloop(std::false_type{});
-        } else {
-            if (tr) stagloop(std::true_type{});
-            else stagloop(std::false_type{});
-        }
-    } else if constexpr (CONV) {
+    if constexpr (CONV) {
         mainloop(std::false_type{});
     } else {
         if (tr) mainloop(std::true_type{});
@@ -1331,11 +877,6 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             }
             return;
         }
-    }
-
-    if constexpr (XATT) {
-        xatt_epilogue<T, MT, NT>(p, acc, smem, rowstat, m0, n0, wm, wn, tid);
-        return;
     }
 
     // every lane owns RUN = 4*NT consecutive columns of MT rows
@@ -1551,13 +1092,13 @@ extern int g_tile;       // 0 = heuristic / caller's hint, 1..6 = force a tile c
 extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS pipeline depth
 extern int g_lora_dbg;   // probing: see GemmP::lora_dbg
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false, int STAG = 0, bool XATT = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
     constexpr int LDS0 = KG * NSTAGE * (BM + BN) * 128 + BM * 8 + (LORA ? BN * LORA_RC * (int)sizeof(T) : 0);
-    constexpr int LDS = XATT && 2 * xa_head_bytes<T>() > LDS0 ? 2 * xa_head_bytes<T>() : LDS0;  // the epilogue's K / V^T of two heads reuse the ring
+    constexpr int LDS = LDS0;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(KG == 1 || (BM / WM / 16) * (BN / WN / 16) * WM * WN * 1024 <= KG * NSTAGE * (BM + BN) * 128, "partial-tile exchange must fit the stage buffers");
-    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG, LORA, STAG, XATT>;
+    auto kfn = gemm_kernel<T, BM, BN, WM, WN, CONV, NSTAGE, KG, LORA>;
     static bool attr_set[64] = {};  // per device: the attribute belongs to the device's copy of the code object
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1609,7 +1150,7 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
     const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), (q.ln_stats || XATT) ? LDS : LDS - BM * 8, stream, q);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), q.ln_stats ? LDS : LDS - BM * 8, stream, q);
     if (q.ksplit > 1) {
         const int64_t work = (int64_t)q.M * ((q.N + 3) / 4);
         int64_t rb = (work + 255) / 256;
@@ -1620,14 +1161,16 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
 }
 
 // Tile configurations:  1: 128x128   2: 128x64   3: 64x128   4: 64x64   (4 waves, 2 x 2)
-//                       5: 256x128 (8 waves, 4 x 2)          6: 128x128 with two K groups (8 waves, intra-workgroup split-K)
-//                       7: 256x128, 8 waves in two groups one barrier slot apart (staggered memory / matrix sections), 3 LDS stages
+//                       6: 128x128 with two K groups (8 waves, intra-workgroup split-K)
+// (5: 256x128 with 8 lockstep waves and 7 / 8: the same tile with its two 4-wave groups one barrier slot apart were measured level with
+//  or behind two co-resident 128x128 workgroups on every shape of the step -- profiles/r02_i_probe_tiles.log, r02_g_autotune_merged.log --
+//  and removed in round 3.)
 // The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
 // how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.  The engine
 // passes measured choices per shape (refiners_amd/engine/tuning.py); this heuristic is the fallback.
 inline int pick_tile(const GemmP& p, bool conv) {
-    if (g_tile >= 1 && g_tile <= 8) return g_tile;
-    if (p.tile_hint >= 1 && p.tile_hint <= 8) return p.tile_hint;
+    if ((g_tile >= 1 && g_tile <= 4) || g_tile == 6) return g_tile;
+    if ((p.tile_hint >= 1 && p.tile_hint <= 4) || p.tile_hint == 6) return p.tile_hint;
     const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (conv) return 3;  // 64 x 128 wins for every conv shape of the UNet (r01_b probe: 339 / 540 / 570 TF at 32^2 / 64^2 / 128^2)
     if (p.geglu) return 1;
@@ -1655,9 +1198,6 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
     int tile = pick_tile(p, CONV);
     if (p.geglu && (tile == 2 || tile == 4)) tile = 3;  // the GEGLU epilogue needs 64 packed columns per wave
     const int st = pick_stages(p);
-    if constexpr (!CONV) {
-        if (p.xa.nstream) return launch_cfg<T, 128, 128, 2, 2, false, 2, 1, false, 0, true>(p, stream);  // cross-attention epilogue: the tile that holds 128 queries x 2 heads
-    }
     if (p.lora_b) {  // in-launch LoRA: the 4-wave tiles, two LDS stages; a stacked rank above 64 needs the 128-column tiles (the producers stage R weight rows)
         if (p.lora_r > 64 && (tile == 2 || tile == 4)) tile = tile == 2 ? 1 : 3;
         if constexpr (CONV) {
@@ -1675,10 +1215,7 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
         case 1: return launch_stages<T, 128, 128, CONV>(p, st, stream);
         case 2: return launch_stages<T, 128, 64, CONV>(p, st, stream);
         case 3: return launch_stages<T, 64, 128, CONV>(p, st, stream);
-        case 5: return st == 3 ? launch_cfg<T, 256, 128, 4, 2, CONV, 3>(p, stream) : launch_cfg<T, 256, 128, 4, 2, CONV, 2>(p, stream);
         case 6: return launch_cfg<T, 128, 128, 2, 2, CONV, 2, 2>(p, stream);
-        case 7: return launch_cfg<T, 256, 128, 4, 2, CONV, 3, 1, false, 1>(p, stream);
-        case 8: return launch_cfg<T, 256, 128, 4, 2, CONV, 3, 1, false, 2>(p, stream);
         default: return launch_stages<T, 64, 64, CONV>(p, st, stream);
     }
 }

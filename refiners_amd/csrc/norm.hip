@@ -275,114 +275,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-// Small slabs (the 32 x 32 and most 64 x 64 feature maps of a CFG pair): ONE launch instead of three.  A workgroup owns
-// `gpw` whole groups of one sample -- HW rows of NV 16-byte vectors, a few hundred KB that stay in L2 between the two passes --
-// and does statistics (same pivoted per-channel sums and Chan merge as gn_partial / gn_finalize, fixed-order LDS reductions:
-// deterministic), then normalise + affine (+ SiLU).  At these sizes the three-kernel path is launch-latency bound (3 dependent
-// launches of a few microseconds of work each: 28.7 us per call for 5 MB of traffic).
-template <typename T>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo, int HW, int C, int G, int gpw,
-                                                        const T* __restrict__ gamma, const T* __restrict__ beta, float eps, int silu) {
-    constexpr int EPC = DT<T>::EPC;
-    __shared__ float red[256 * EPC * 2];
-    __shared__ float mean_c[256], m2_c[256], gstat[8];
-    const int cg = C / G;
-    const int NV = gpw * cg / EPC;          // 16-byte vectors per slab row (<= 32)
-    const int RL = 256 / NV;                // row lanes
-    const int tid = threadIdx.x;
-    const int v = tid % NV, rl = tid / NV;
-    const bool on = rl < RL;
-    const int b = blockIdx.y, c0 = blockIdx.x * gpw * cg;
-    const T* xb = x + (int64_t)b * HW * ldx + c0 + v * EPC;
-    T* ob = out + (int64_t)b * HW * ldo + c0 + v * EPC;
-    const float n = (float)HW;
-    float piv[EPC], s1[EPC], s2[EPC];
-    {
-        Vec16<T> pv = load16<T>(xb);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) piv[e] = pv.get(e), s1[e] = 0.f, s2[e] = 0.f;
-    }
-    if (on) {
-        int px = rl;
-        for (; px + 3 * RL < HW; px += 4 * RL) {  // four independent 16-byte loads in flight
-            Vec16<T> t0 = load16<T>(xb + (int64_t)px * ldx), t1 = load16<T>(xb + (int64_t)(px + RL) * ldx), t2 = load16<T>(xb + (int64_t)(px + 2 * RL) * ldx),
-                     t3 = load16<T>(xb + (int64_t)(px + 3 * RL) * ldx);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float d0 = t0.get(e) - piv[e], d1 = t1.get(e) - piv[e], d2 = t2.get(e) - piv[e], d3 = t3.get(e) - piv[e];
-                s1[e] += (d0 + d1) + (d2 + d3);
-                s2[e] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            }
-        }
-        for (; px < HW; px += RL) {
-            Vec16<T> t0 = load16<T>(xb + (int64_t)px * ldx);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float d0 = t0.get(e) - piv[e];
-                s1[e] += d0;
-                s2[e] += d0 * d0;
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        red[(tid * EPC + e) * 2 + 0] = on ? s1[e] : 0.f;
-        red[(tid * EPC + e) * 2 + 1] = on ? s2[e] : 0.f;
-    }
-    __syncthreads();
-    const int nch = gpw * cg;  // channels of the slab (<= 256)
-    if (tid < nch) {
-        const int vv = tid / EPC, e = tid % EPC;
-        float a1 = 0.f, a2 = 0.f;
-        for (int q = 0; q < RL; ++q) {
-            a1 += red[((q * NV + vv) * EPC + e) * 2 + 0];
-            a2 += red[((q * NV + vv) * EPC + e) * 2 + 1];
-        }
-        const float pc = to_f32(x[(int64_t)b * HW * ldx + c0 + tid]);
-        mean_c[tid] = pc + a1 / n;
-        m2_c[tid] = fmaxf(a2 - a1 * a1 / n, 0.f);
-    }
-    __syncthreads();
-    if (tid < gpw) {
-        float mg = 0.f;
-        for (int q = 0; q < cg; ++q) mg += mean_c[tid * cg + q];
-        mg /= (float)cg;
-        float m2 = 0.f;
-        for (int q = 0; q < cg; ++q) {
-            const float d = mean_c[tid * cg + q] - mg;
-            m2 += m2_c[tid * cg + q] + n * d * d;
-        }
-        gstat[2 * tid] = mg;
-        gstat[2 * tid + 1] = rsqrtf(m2 / (n * (float)cg) + eps);
-    }
-    __syncthreads();
-    if (!on) return;
-    float sc[EPC], sh[EPC];
-    {
-        Vec16<T> gv = load16<T>(gamma + c0 + v * EPC), bv = load16<T>(beta + c0 + v * EPC);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const int gi = (v * EPC + e) / cg;
-            sc[e] = gstat[2 * gi + 1] * gv.get(e);
-            sh[e] = bv.get(e) - gstat[2 * gi] * sc[e];
-        }
-    }
-    for (int px = rl; px < HW; px += RL) {
-        Vec16<T> t = load16<T>(xb + (int64_t)px * ldx), o;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            float y = t.get(e) * sc[e] + sh[e];
-            if (silu) y = silu_f(y);
-            o.set(e, y);
-        }
-        store16<T>(ob + (int64_t)px * ldo, o);
-    }
-}
-
-int g_gn_fused = 0;                       // single-launch kernel OFF: once the three kernels keep several loads in flight per thread they beat it on every
-                                          // SDXL shape when timed inside a HIP graph (tools/probe_gn.py, profiles/r02_p_probe_gn.log); mi355x_groupnorm_set_fused switches
-int64_t g_gn_fused_max_bytes = 160 << 10;  // largest slab the single-launch kernel is used for when it is switched on
-
 inline int gn_ppc(int B, int HW, int C, int es) {
     const int nv = C * es / 16;
     const int pl = nv >= 256 ? 1 : 256 / nv;
@@ -417,24 +309,6 @@ template <typename T>
 int run_groupnorm(const mi355x_groupnorm_args* a, hipStream_t st) {
     constexpr int EPC = DT<T>::EPC;
     const int es = sizeof(T);
-    {   // small slabs: the single-launch kernel (see gn_fused_kernel)
-        const int cg = a->C / a->G;
-        int gpw = 0;
-        for (int cand = 1; cand <= 4; cand *= 2)
-            if (a->G % cand == 0 && (cand * cg * es) % 16 == 0) {
-                gpw = cand;
-                break;
-            }
-        if (gpw && g_gn_fused) {
-            const int nv = gpw * cg * es / 16;
-            const int64_t slab = (int64_t)a->HW * gpw * cg * es;
-            if (nv <= 32 && gpw * cg <= 256 && slab <= g_gn_fused_max_bytes && al16(a->gamma)) {
-                hipLaunchKernelGGL((gn_fused_kernel<T>), dim3(a->G / gpw, a->B), dim3(256), 0, st, static_cast<const T*>(a->x), a->ldx, static_cast<T*>(a->out), a->ldo, a->HW,
-                                   a->C, a->G, gpw, static_cast<const T*>(a->gamma), static_cast<const T*>(a->beta), a->eps, a->silu);
-                return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
-            }
-        }
-    }
     const int ppc = gn_ppc(a->B, a->HW, a->C, es);
     const int nchunk = (a->HW + ppc - 1) / ppc;
     float* part = a->ws;
@@ -458,12 +332,6 @@ extern "C" int mi355x_layernorm(const mi355x_layernorm_args* a, void* stream) {
     if (!al16(a->x) || !al16(a->out) || !al16(a->gamma) || !al16(a->beta)) return MI355X_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return a->dtype == MI355X_F32 ? run_layernorm<float>(a, st) : run_layernorm<bf16_t>(a, st);
-}
-
-extern "C" int mi355x_groupnorm_set_fused(int enabled, int64_t max_slab_bytes) {  // probing / A-B only, not part of the stable contract
-    g_gn_fused = enabled;
-    if (max_slab_bytes > 0) g_gn_fused_max_bytes = max_slab_bytes;
-    return MI355X_OK;
 }
 
 extern "C" int64_t mi355x_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C) {

@@ -27,7 +27,8 @@ from torch import Tensor
 
 from .. import native
 from ..fluxion.tree import tree_epoch
-from .lowering import PackCache, UNetIO, UNetLowering, Unsupported, isa, kids, launches  # noqa: F401
+from .packing import PackCache, Unsupported, isa, kids, launches  # noqa: F401
+from .unet_lowering import UNetIO, UNetLowering  # noqa: F401
 
 TOKEN_CONTEXTS = (("cross_attention_block", "clip_text_embedding"), ("ip_adapter", "clip_image_embedding"))
 
@@ -315,6 +316,13 @@ class CompiledSDXL:
         self.coef_table = torch.tensor(rows, dtype=torch.float32, device=device)
         self.coef = torch.zeros(8, dtype=torch.float32, device=device)
         self.ts_table = self.solver.timesteps.to(device=device, dtype=torch.float32)
+        # Self-Attention Guidance degrades the latents through Solver.remove_noise / add_noise: (-, scale_t, std_t) per step, for mi355x_sag_degrade.
+        # A solver whose add_noise / remove_noise the reference itself cannot evaluate (Euler: float timesteps) has no table; SAG then raises.
+        try:
+            self.sag_table = torch.tensor([[0.0, *self.solver.sag_coefficients(s)] for s in range(self.solver.num_inference_steps)], dtype=torch.float32, device=device)
+        except (IndexError, AttributeError):
+            self.sag_table = None
+        self.sag_coef = torch.zeros(3, dtype=torch.float32, device=device)
 
     def set_inputs(self, x: Tensor, *, clip_text_embedding: Tensor, pooled_text_embedding: Optional[Tensor] = None, time_ids: Optional[Tensor] = None,
                    clip_image_embedding: Optional[Tensor] = None, conditions: Optional[dict[str, Tensor]] = None,
@@ -363,19 +371,21 @@ class CompiledSDXL:
         io, low = eng.io, eng.low
         assert io is not None and low is not None
         self.coef.copy_(self.coef_table[step])
-        if self.linear:
-            return self._linear_step(step, io, low, eng)
         sag = self._sag_adapter()
-        tail = (lambda: None) if sag is None else self._prepare_sag(sag, got, n, io, low)
+        tail = None if sag is None else self._prepare_sag(sag, got, n, io, low, step)
+        # everything a captured graph holds by value or by address: both programs, and for self-attention guidance the host-side ratio
+        # sag.scale / condition_scale and the blur weights' tensor (kernel_size, sigma)
+        gkey = (eng.key, None if self.engine2 is None or sag is None else (self.engine2.key, float(sag.scale) / float(self.condition_scale), int(sag.kernel_size), float(sag.sigma)))
+        if self.linear:
+            return self._linear_step(step, io, low, eng, tail, gkey)
+        if tail is None:
+            tail = lambda: None  # noqa: E731
         if not self.use_graph:
             self._fill()
             native.replay(low.step)
             tail()
             native.cfg_ddim_step(self.x, io.out, self.coef)
             return self.x
-        # everything a captured graph holds by value or by address: both programs, and for self-attention guidance the host-side ratio
-        # sag.scale / condition_scale and the blur weights' tensor (kernel_size, sigma)
-        gkey = (eng.key, None if self.engine2 is None or sag is None else (self.engine2.key, float(sag.scale) / float(self.condition_scale), int(sag.kernel_size), float(sag.sigma)))
         if self.graph is None or self.graph_key != gkey:
             keep = self.x.clone()
             self._fill()
@@ -402,13 +412,17 @@ class CompiledSDXL:
             p = getattr(p, "parent", None)
         return None
 
-    def _prepare_sag(self, sag: Any, got: dict[str, Any], n: int, io: Any, low: Any) -> Any:
+    def _prepare_sag(self, sag: Any, got: dict[str, Any], n: int, io: Any, low: Any, step: int) -> Any:
         """Stage the second UNet pass of Self-Attention Guidance and return the closure that runs between the CFG pass and the
         guidance + DDIM kernel: degraded latents (mask from the tapped attention's column mass, Gaussian blur, re-noising: one
         kernel) -> unconditional UNet pass on them (a second lowered program, batch n) -> cond += (sag / cfg) * (uncond - degraded),
         which makes the unchanged CFG kernel produce eps_cfg + sag_scale * (eps_uncond - eps_degraded)   (model.py:147-155)."""
-        assert not self.linear, "self-attention guidance on the compiled loop is lowered for DDIM only"
+        if self.sag_table is None:  # the reference raises the same way (Solver.remove_noise indexes integer tables with the solver's timesteps)
+            raise IndexError(f"{type(self.solver).__name__}: add_noise / remove_noise are not defined for this solver's timesteps, so Self-Attention Guidance "
+                             "cannot be evaluated (refiners raises here as well)")
+        # (ControlLora / T2I conditions: the reference's own second pass feeds the 2n-row control images to an n-row batch and fails; refused loudly here)
         assert self.condition_scale != 0.0 and not got["conditions"] and not got.get("t2i"), "SAG with ControlLora / T2I conditions or a zero guidance scale is not lowered"
+        self.sag_coef.copy_(self.sag_table[step])
         assert getattr(low, "sag", None) is not None and getattr(low, "sag_shape", None) is not None, "SAG adapter present but its taps were not found in the lowered tree"
         if self.engine2 is None:
             self.engine2 = CompiledUNet(self.unet, use_graph=False, lora_mode=self.engine.lora_mode)
@@ -438,15 +452,20 @@ class CompiledSDXL:
         u, c = io.out[:n], io.out[n:]
 
         def tail() -> None:
-            native.sag_degrade(x, u, mass, (ah, aw), self.coef, self._sag_w1, io2.x)
+            # x is the UNSCALED latent (model.py:146: the guidance sees x, not scale_model_input(x)), and so is what the second pass is fed
+            native.sag_degrade(x, u, mass, (ah, aw), self.sag_coef, self._sag_w1, io2.x)
             native.replay(low2.step)
             native.axpby(u, ratio, c, 1.0, c)
             native.axpby(io2.out, -ratio, c, 1.0, c)
 
         return tail
 
-    def _linear_step(self, step: int, io: Any, low: Any, eng: Any) -> Tensor:
-        """Euler / DPM-Solver++ / LCM: the UNet program then ONE kernel (guidance, update, history, next model input)."""
+    def _linear_step(self, step: int, io: Any, low: Any, eng: Any, tail: Any = None, gkey: Any = None) -> Tensor:
+        """Euler / DPM-Solver++ / LCM: the UNet program (then the Self-Attention Guidance pass, `tail`) then ONE kernel (guidance, update,
+        history, next model input)."""
+        gkey = gkey if gkey is not None else eng.key
+        if tail is None:
+            tail = lambda: None  # noqa: E731
         assert self.x is not None and self.hist is not None
         if getattr(self.solver, "needs_noise", None) is not None and self.solver.needs_noise(step):
             # LCMSolver re-noises the consistency estimate (solvers/lcm.py:143-150): same draw as the reference (shape, device,
@@ -465,16 +484,19 @@ class CompiledSDXL:
             self.primed, self.primed_key = True, eng.key
         if not self.use_graph:
             native.replay(low.step)
+            tail()
             native.cfg_linear_step(self.x, io.out, self.hist, io.x, self.coef)
             return self.x
-        if self.graph is None or self.graph_key != eng.key:
+        if self.graph is None or self.graph_key != gkey:
             native.replay(low.step)  # warm-up outside capture; reads io.x only
+            tail()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 native.replay(low.step)
+                tail()
                 native.cfg_linear_step(self.x, io.out, self.hist, io.x, self.coef)
-            self.graph, self.graph_key = g, eng.key
+            self.graph, self.graph_key = g, gkey
         self.graph.replay()
         return self.x
 

@@ -26,7 +26,9 @@ from .. import native
 from ..fluxion import layers as fl
 from ..fluxion.adapters import Adapter
 from ..fluxion.tree import tree_epoch
-from .lowering import Act, Lowering, PackCache, UNetContext, isa, kids
+from .lowering_blocks import BlockLowering as Lowering
+from .packing import Act, PackCache, isa, kids
+from .unet_lowering import UNetContext
 
 
 class _FusedBlock(fl.Chain):

@@ -23,7 +23,7 @@ from torch import Tensor
 from .. import native
 from ..fluxion.tree import tree_epoch
 from .compiled import Program
-from .lowering import PackCache, _expect, isa, kids, launches
+from .packing import PackCache, _expect, isa, kids, launches
 from .text import TextLowering
 
 

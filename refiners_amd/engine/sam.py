@@ -32,7 +32,8 @@ from torch import Tensor
 from .. import native
 from ..fluxion.tree import tree_epoch
 from .compiled import Program
-from .lowering import Act, Lowering, PackCache, Unsupported, _expect, cname, isa, kids, launches
+from .lowering_blocks import BlockLowering as Lowering
+from .packing import Act, PackCache, Unsupported, _expect, cname, isa, kids, launches
 
 
 class SAMLowering(Lowering):

@@ -25,7 +25,8 @@ from torch import Tensor
 from .. import native
 from ..fluxion.tree import tree_epoch
 from .compiled import Program
-from .lowering import Lowering, PackCache, _expect, cname, isa, kids, launches
+from .lowering_blocks import BlockLowering as Lowering
+from .packing import PackCache, _expect, cname, isa, kids, launches
 
 
 class TextLowering(Lowering):

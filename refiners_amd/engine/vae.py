@@ -17,7 +17,8 @@ import torch
 from torch import Tensor
 
 from .. import native
-from .lowering import Act, PackCache, UNetContext, UNetLowering, _expect, cname, isa, kids, launches
+from .packing import Act, PackCache, _expect, cname, isa, kids, launches
+from .unet_lowering import UNetContext, UNetLowering
 
 
 class VAEDecoderLowering(UNetLowering):

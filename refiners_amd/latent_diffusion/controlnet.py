@@ -4,7 +4,7 @@ the conditioning picture) runs in front of the UNet and adds its thirteen scaled
 
 Host mirror, CPU oracle and goldens only for now: the engine does NOT lower this tree yet (CompiledUNet raises
 `Unsupported` on a `Controlnet` child -- loudly, there is no silent fallback); its shape of work is the ControlLora's,
-which is lowered (refiners_amd/engine/lowering.py: control_lora).
+which is lowered (refiners_amd/engine/unet_lowering.py: control_lora).
 """
 from __future__ import annotations
 

@@ -63,6 +63,11 @@ class DDIM:
     def scale_model_input(self, x: Tensor, step: int) -> Tensor:
         return x
 
+    def sag_coefficients(self, step: int) -> tuple[float, float]:
+        """(cumulative scale factor, noise std) that add_noise / remove_noise use at `step` (see refiners_amd.latent_diffusion.solvers)."""
+        t = self.timesteps[step]
+        return float(self.cumulative_scale_factors[t]), float(self.noise_std[t])
+
     def add_noise(self, x: Tensor, noise: Tensor, step: int) -> Tensor:
         t = self.timesteps[step]
         return self.cumulative_scale_factors[t] * x + self.noise_std[t] * noise

@@ -43,6 +43,24 @@ class _Schedule:
     def inference_steps(self) -> list[int]:
         return list(range(self.num_inference_steps))[self.first_inference_step:]
 
+    # -- Solver.add_noise / remove_noise (solvers/solver.py:244-319): what Self-Attention Guidance degrades the latents through -----------
+    def _noise_index(self, step: int) -> Any:
+        """The base class indexes its train-time tables with the step's TIMESTEP (solver.py:261-263, 312-314)."""
+        return self.timesteps[step]
+
+    def sag_coefficients(self, step: int) -> tuple[float, float]:
+        """(cumulative scale factor, noise std) that add_noise / remove_noise use at `step`: the two numbers mi355x_sag_degrade needs."""
+        i = self._noise_index(step)
+        return float(self.cumulative_scale_factors[i]), float(self.noise_std[i])
+
+    def add_noise(self, x: Tensor, noise: Tensor, step: int) -> Tensor:
+        i = self._noise_index(step)
+        return self.cumulative_scale_factors[i] * x + self.noise_std[i] * noise
+
+    def remove_noise(self, x: Tensor, noise: Tensor, step: int) -> Tensor:
+        i = self._noise_index(step)
+        return (x - self.noise_std[i] * noise) / self.cumulative_scale_factors[i]
+
     def _move(self, names: tuple[str, ...], device: Any, dtype: Any) -> None:
         for n in names:
             setattr(self, n, getattr(self, n).to(device=device, dtype=dtype))
@@ -66,6 +84,12 @@ class Euler(_Schedule):
     @property
     def init_noise_sigma(self) -> Tensor:
         return self.sigmas.max()
+
+    def _noise_index(self, step: int) -> Any:
+        # Euler's timesteps are FLOATS (linspace, euler.py:46-50) and the reference's add_noise / remove_noise index integer tables with them:
+        # refiners itself raises here (so Self-Attention Guidance cannot be combined with Euler in the reference either)
+        raise IndexError("tensors used as indices must be long, int, byte or bool tensors (Euler's float timesteps: the reference's "
+                         "Solver.add_noise / remove_noise, and with them Self-Attention Guidance, do not work with this solver)")
 
     def scale_model_input(self, x: Tensor, step: int) -> Tensor:
         if step == -1:
@@ -132,9 +156,9 @@ class DPMSolver(_Schedule):
     def input_scale(self, step: int) -> float:
         return 1.0
 
-    def add_noise(self, x: Tensor, noise: Tensor, step: int) -> Tensor:
-        """DPMSolver._add_noise (dpm.py:171-191): the tables are indexed by inference STEP here, not by train timestep."""
-        return self.cumulative_scale_factors[step] * x + self.noise_std[step] * noise
+    def _noise_index(self, step: int) -> Any:
+        """DPMSolver._add_noise / remove_noise (dpm.py:171-202): the tables are indexed by inference STEP here, not by train timestep."""
+        return step
 
     def _first_order(self, step: int) -> bool:
         return step == self.first_inference_step or (self.last_step_first_order and step == self.num_inference_steps - 1)

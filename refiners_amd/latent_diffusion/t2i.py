@@ -5,7 +5,7 @@ Two halves with very different costs:
   * `ConditionEncoderXL`: a small conv net that turns the conditioning picture (depth, canny, ...) into four feature maps,
     ONCE per image (`compute_condition_features`); it stays on torch.
   * `T2IFeatures`: four `x + scale * features[i]` nodes inside the UNet (three down blocks and the middle block), hit on
-    EVERY denoising step; the engine lowers them to one fused add each (refiners_amd/engine/lowering.py).
+    EVERY denoising step; the engine lowers them to one fused add each (refiners_amd/engine/unet_lowering.py).
 State-dict keys of the encoder equal the reference's (tests/golden/t2i_keys.json).
 """
 from __future__ import annotations

@@ -149,10 +149,6 @@ class GemmArgs(C.Structure):
         ("lora_t", C.c_void_p),
         ("lora_flags", C.c_void_p),
         ("lora_epoch", C.c_void_p),
-        ("xattn_kv", C.c_void_p),
-        ("xattn_nstream", C.c_int32),
-        ("xattn_lq", C.c_int32),
-        ("xattn_scale", C.c_float),
     ]
 
 
@@ -324,7 +320,6 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_pointwise_nchw.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     lib.mi355x_relpos_pack.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
-    lib.mi355x_groupnorm_set_fused.argtypes = [C.c_int, C.c_int64]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
     if lib.mi355x_abi_version() != 5:
@@ -332,8 +327,6 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     _lib = lib
     import os
 
-    if os.environ.get("REFINERS_AMD_GN_FUSED", "0") == "1":  # A/B: the single-launch GroupNorm for slabs up to 160 KB
-        lib.mi355x_groupnorm_set_fused(1, 0)
     attention_pipeline_from_env()
     return lib
 
@@ -442,70 +435,12 @@ def matmul_f32(x: Tensor, w: Tensor, res: Optional[Tensor] = None) -> Tensor:
     return out
 
 
-_side_depth = 0
-_side_streams: dict[int, "torch.cuda.Stream"] = {}
-SIDE = "@side"  # suffix of the name of a recorded launch that runs on the side stream
-
-
-class side_branch:
-    """Context manager for the recorder: launches recorded inside run on a second stream, concurrently with what the main
-    stream records between `fork()` and `join()`.  At the SDXL step's problem sizes (CFG pair: 2048 rows) single GEMMs do
-    not fill 256 CUs, so independent ones -- the packed Q|K projection and the V^T projection of a self-attention -- are
-    issued side by side; under HIP-graph capture the fork / join events become graph edges."""
-
-    def __enter__(self) -> None:
-        global _side_depth
-        _side_depth += 1
-
-    def __exit__(self, *exc: object) -> None:
-        global _side_depth
-        _side_depth -= 1
-
-
-def side_stream() -> "torch.cuda.Stream":
-    dev = torch.cuda.current_device()
-    if dev not in _side_streams:
-        _side_streams[dev] = torch.cuda.Stream(device=dev)
-    return _side_streams[dev]
-
-
-def fork() -> None:
-    """Recorded point after which the side stream may start: it waits for everything the main stream has issued so far."""
-    ev = None
-
-    def run() -> None:
-        nonlocal ev
-        if ev is None:
-            ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        side_stream().wait_event(ev)
-
-    if not record_python(run, "fork" + SIDE):
-        run()
-
-
-def join() -> None:
-    """Recorded point at which the main stream waits for everything issued on the side stream."""
-    ev = None
-
-    def run() -> None:
-        nonlocal ev
-        if ev is None:
-            ev = torch.cuda.Event()
-        ev.record(side_stream())
-        torch.cuda.current_stream().wait_event(ev)
-
-    if not record_python(run, "join" + SIDE):
-        run()
-
-
 def _launch(sym: str, args: tuple, what: str, keep: tuple = ()) -> None:
     fn = getattr(load(), sym)
     if _recorder is not None:
-        _recorder.append((fn, args, what + SIDE if _side_depth else what, keep))
+        _recorder.append((fn, args, what, keep))
         return
-    s = side_stream().cuda_stream if _side_depth else stream_ptr()
-    check(fn(*args, s), what)
+    check(fn(*args, stream_ptr()), what)
 
 
 def record_python(fn, what: str = "python") -> bool:
@@ -520,17 +455,11 @@ def record_python(fn, what: str = "python") -> bool:
 def replay(ops: list) -> None:
     """Launch a recorded program on the current stream."""
     s = stream_ptr()
-    s2 = None
     for fn, args, what, _ in ops:
         if fn is None:
             args()
             continue
-        if what.endswith(SIDE):
-            if s2 is None:
-                s2 = side_stream().cuda_stream
-            st = fn(*args, s2)
-        else:
-            st = fn(*args, s)
+        st = fn(*args, s)
         if st:
             check(st, what)
 
@@ -664,11 +593,8 @@ def gemm(
     out_f32: bool = False,
     lora: Optional[tuple[Sequence[tuple[int, "KBlocked"]], Tensor]] = None,
     lora_sync: Optional[tuple] = None,
-    xattn: Optional[tuple[Sequence[tuple[Tensor, Tensor, int, float]], int, Optional[float]]] = None,
 ) -> Optional[Tensor]:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
-    xattn = (streams, queries per sample, scale | None): cross-attention in the epilogue (see the header): `out` receives
-    sum_s out_scale_s softmax(scale Q K_s^T) V_s instead of Q; streams as for attention(): (k [B, Lk(+), N] view, vt [N, B, Lkp] view, Lk, out_scale).
     weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch.
     out_t / nt_begin: columns >= nt_begin are written transposed, out_t[n - nt_begin][m] (`out` then has nt_begin columns).
     ln = (stats [parts, M, 2] float32, s [N] float32, c [N] float32, eps): LayerNorm of x folded into this launch (see the header);
@@ -717,18 +643,6 @@ def gemm(
         assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= (a.N // 32) * a.M * 2 and a.N % 64 == 0
         a.stats_out = stats_out.data_ptr()
         keep.append(stats_out)
-    if xattn is not None:
-        streams, lq, scale = xattn
-        kvs = (KvStream * 2)()
-        for s, (k, vt, Lk, osc) in enumerate(streams):
-            assert k.dim() == 3 and vt.dim() == 3 and k.stride(2) == 1 and vt.stride(2) == 1 and k.shape[2] == a.N and vt.shape[0] == a.N
-            kv = kvs[s]
-            kv.k, kv.ldk, kv.k_batch_stride = k.data_ptr(), k.stride(1), k.stride(0)
-            kv.vt, kv.ldvt, kv.vt_batch_stride = vt.data_ptr(), vt.stride(0), vt.stride(1)
-            kv.Lk, kv.out_scale = Lk, osc
-        a.xattn_kv, a.xattn_nstream, a.xattn_lq = C.addressof(kvs), len(streams), lq
-        a.xattn_scale = scale if scale is not None else 64 ** -0.5
-        keep.append((kvs, streams))
     _fill_split(a, tile, ksplit, ws, stages)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm", keep=tuple(keep))
     return out
@@ -835,7 +749,7 @@ def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 1
 def gemm_signature(a: GemmArgs) -> str:
     """Shape class of a GEMM / conv launch: the key of the measured tile table (refiners_amd/engine/tuning.py)."""
     k = sum(int(a.seg[s].k) * (int(a.seg[s].ksize) ** 2 if a.conv else 1) for s in range(a.nseg))
-    flags = ("geglu" if a.geglu == 1 else "") + ("T%d" % a.nt_begin if a.out_t else "") + ("ln" if a.ln_stats else "") + ("st" if a.stats_out else "") + ("lora" if a.lora_b else "") + ("xa" if a.xattn_kv else "")
+    flags = ("geglu" if a.geglu == 1 else "") + ("T%d" % a.nt_begin if a.out_t else "") + ("ln" if a.ln_stats else "") + ("st" if a.stats_out else "") + ("lora" if a.lora_b else "")
     return f"{'conv' if a.conv else 'gemm'}:{'f32' if a.dtype == 0 else 'bf16'}:{a.M}x{a.N}x{k}:s{a.nseg}:{flags}"
 
 

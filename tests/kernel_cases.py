@@ -225,47 +225,6 @@ def conv_first_case(B, H, W, dtype, seed=60):
 
 
 # ------------------------------------------------------------------------------------------------ q-projection + cross-attention in one launch
-def gemm_xattn_case(B, Lq, K, H, Lk, dtype, *, ip_tokens=0, ip_scale=0.6, ln=False, bias=True, seed=300):
-    """out = SDPA(Linear_q(x) [or Linear_q(LayerNorm(x))], K_text, V_text) (+ ip_scale SDPA(., K_ip, V_ip)) as ONE mi355x_gemm launch
-    (xattn epilogue) vs the two-step float32 reference on the same (rounded) operands."""
-    Cc, M = 64 * H, B * Lq
-    x = _rand(M, K, dtype=dtype, seed=seed) * (1.5 if ln else 1.0) + (0.7 if ln else 0.0)
-    w = _rand(Cc, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
-    b = _rand(Cc, dtype=dtype, seed=seed + 2) if bias and not ln else None
-    k = _rand(B, Lk, Cc, dtype=dtype, seed=seed + 3)
-    v = _rand(B, Lk, Cc, dtype=dtype, seed=seed + 4)
-    streams = [(k, _vt_from_v(v, (Lk + 63) // 64 * 64), Lk, 1.0)]
-    kvs = [(k, v, 1.0)]
-    if ip_tokens:
-        k2 = _rand(B, ip_tokens, Cc, dtype=dtype, seed=seed + 5)
-        v2 = _rand(B, ip_tokens, Cc, dtype=dtype, seed=seed + 6)
-        streams.append((k2, _vt_from_v(v2, (ip_tokens + 63) // 64 * 64), ip_tokens, ip_scale))
-        kvs.append((k2, v2, ip_scale))
-    out = torch.full((M, Cc), float("nan"), dtype=dtype, device=DEV)
-    if ln:
-        eps = 1e-5
-        gamma = (1 + 0.1 * _rand(K, dtype=torch.float32, seed=seed + 7)).to(dtype)
-        beta = (0.1 * _rand(K, dtype=torch.float32, seed=seed + 8)).to(dtype)
-        bq = _rand(Cc, dtype=dtype, seed=seed + 2)
-        xf = x.float()
-        xc = xf.reshape(M, K // 32, 32)  # the producer-side format: (mean, M2) of every 32-column chunk of the row
-        cm = xc.mean(dim=2)
-        stats = torch.stack([cm, ((xc - cm[:, :, None]) ** 2).sum(dim=2)], dim=2).permute(1, 0, 2).contiguous()  # [K / 32, M, 2]
-        wl = (w.float() * gamma.float()[None, :]).to(dtype).contiguous()
-        ls = wl.float().sum(dim=1).contiguous()
-        lc = (w.float() @ beta.float() + bq.float()).contiguous()
-        native.gemm([(x, native.KBlocked(wl))], out, ln=(stats, ls, lc, eps), xattn=(streams, Lq, None))
-        xn = torch.nn.functional.layer_norm(xf, (K,), gamma.float(), beta.float(), eps)
-        q = xn @ w.float().t() + bq.float()
-    else:
-        native.gemm([(x, native.KBlocked(w))], out, bias=b, xattn=(streams, Lq, None))
-        q = x.float() @ w.float().t() + (b.float() if b is not None else 0)
-    q = q.to(dtype).reshape(B, Lq, Cc)  # the reference's Linear output is a tensor of the compute dtype
-    ref = sum(sc * _sdpa_ref(q, kk, vv, H) for kk, vv, sc in kvs)
-    return _cmp(out.reshape(B, Lq, Cc), ref, dtype)
-
-
-# ------------------------------------------------------------------------------------------------ attention
 def _vt_from_v(v: torch.Tensor, Lkp: int) -> torch.Tensor:
     B, Lk, Cc = v.shape
     vt = torch.zeros(Cc, B, Lkp, dtype=v.dtype, device=v.device)
@@ -379,19 +338,12 @@ def layernorm_case(M, Cc, dtype, seed=80):
     return _cmp(out, ref, dtype)
 
 
-def groupnorm_case(B, Cc, HW, dtype, silu=True, eps=1e-5, seed=90, single_launch=False):
-    """single_launch: the one-workgroup-per-group-set kernel (off by default) instead of partial / finalize / apply."""
+def groupnorm_case(B, Cc, HW, dtype, silu=True, eps=1e-5, seed=90):
     x = _rand(B, HW, Cc, dtype=dtype, seed=seed) * 1.5 + 3.0  # large mean: stresses the variance computation
     g = (1 + 0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 1)).to(dtype)
     b = (0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 2)).to(dtype)
     out = torch.empty_like(x)
-    if single_launch:
-        native.load().mi355x_groupnorm_set_fused(1, 1 << 30)
-    try:
-        native.groupnorm_nhwc(x, g, b, 32, eps, silu, out)
-    finally:
-        if single_launch:
-            native.load().mi355x_groupnorm_set_fused(0, 160 << 10)
+    native.groupnorm_nhwc(x, g, b, 32, eps, silu, out)
     xr = x.float().permute(0, 2, 1)  # [B, C, HW]
     ref = F.group_norm(xr, 32, g.float(), b.float(), eps)
     if silu:
@@ -881,12 +833,6 @@ def all_cases():
             for code in (0x20001, 0x20011):
                 cases.append((f"attn_{tag}_kvsplit{code & 0xff:02x}_{nm}", lambda dt=dt, args=args, kw=kw, code=code: attention_case(*args, dt, pipe=code, **kw)))
         cases += [
-            (f"xattn_{tag}_77_bias", lambda dt=dt: gemm_xattn_case(2, 128, 640, 4, 77, dt)),
-            (f"xattn_{tag}_77_ip4_bias", lambda dt=dt: gemm_xattn_case(2, 256, 1280, 6, 77, dt, ip_tokens=4, seed=301)),
-            (f"xattn_{tag}_77_ip16_ln", lambda dt=dt: gemm_xattn_case(1, 384, 640, 10, 77, dt, ip_tokens=16, ln=True, seed=302)),
-            (f"xattn_{tag}_Lk80_nobias", lambda dt=dt: gemm_xattn_case(2, 128, 320, 2, 80, dt, bias=False, seed=303)),
-            (f"xattn_{tag}_Lk1_ip1", lambda dt=dt: gemm_xattn_case(1, 128, 320, 2, 1, dt, ip_tokens=1, seed=304)),
-            (f"xattn_{tag}_Lk33_ln", lambda dt=dt: gemm_xattn_case(1, 128, 1280, 20, 33, dt, ln=True, seed=305)),
         ]
         # launches of at most three K/V tiles take the all-tiles-up-front kernel by default (the cases above: cross_77, cross_77_ip4, 1tile, 3tiles,
         # Lq_edge_200); 0x40000 switches it off, so the same shapes also run through the general tile loop; and its remaining slot layouts
@@ -906,7 +852,6 @@ def all_cases():
             ]
         cases += [
             (f"attng_{tag}_d40_self", lambda dt=dt: attention_general_case(2, 8, 1024, 1024, 40, 40, dt)),
-            (f"attng_{tag}_d40_cross77", lambda dt=dt: attention_general_case(2, 8, 320, 77, 40, 40, dt)),
             (f"attng_{tag}_d80_self", lambda dt=dt: attention_general_case(2, 8, 256, 256, 80, 80, dt, spike=True)),
             (f"attng_{tag}_d160_self", lambda dt=dt: attention_general_case(2, 8, 64, 64, 160, 160, dt)),
             (f"attng_{tag}_d160_cross77", lambda dt=dt: attention_general_case(1, 8, 200, 77, 160, 160, dt)),
@@ -925,8 +870,6 @@ def all_cases():
             (f"groupnorm_{tag}_960_4096", lambda dt=dt: groupnorm_case(1, 960, 4096, dt)),
             (f"groupnorm_{tag}_640_333_ragged", lambda dt=dt: groupnorm_case(3, 640, 333, dt, seed=91)),  # pixel counts that are no multiple of the 4-deep unroll
             (f"groupnorm_{tag}_320_16384", lambda dt=dt: groupnorm_case(2, 320, 16384, dt, seed=92)),
-            (f"groupnorm_{tag}_1280_1024_single_launch", lambda dt=dt: groupnorm_case(2, 1280, 1024, dt, single_launch=True)),
-            (f"groupnorm_{tag}_320_1024_single_launch", lambda dt=dt: groupnorm_case(2, 320, 1024, dt, silu=False, single_launch=True)),
             (f"layout_{tag}", lambda dt=dt: layout_case(2, 4, 32, 32, dt)),
             (f"layout_{tag}_320", lambda dt=dt: layout_case(1, 320, 16, 24, dt)),
             (f"concat_axpby_{tag}", lambda dt=dt: concat_axpby_case(1000, 640, 320, dt)),
@@ -947,29 +890,10 @@ def all_cases():
             (f"sinusoidal_{tag}_timestep", lambda dt=dt: sinusoidal_case(2, 320, 1, dt)),
             (f"sinusoidal_{tag}_time_ids", lambda dt=dt: sinusoidal_case(12, 256, 6, dt)),
         ]
-        for tile in (1, 2, 3, 4, 5, 6, 7, 8):
-            for st in ((2,) if tile == 6 else (3,) if tile in (7, 8) else (2, 3) if tile == 5 else (2, 3, 4)):
+        for tile in (1, 2, 3, 4, 6):
+            for st in ((2,) if tile == 6 else (2, 3, 4)):
                 cases.append((f"gemm_{tag}_tile{tile}_s{st}_300x1472x328", lambda dt=dt, tile=tile, st=st: gemm_tile_case(300, 1472, 328, dt, tile, st)))
         cases += [
-            (f"gemm_{tag}_tile7_2048x10240x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 2560, dt, 7, 3, prefetch=True)),
-            (f"gemm_{tag}_tile8_oneblock", lambda dt=dt: gemm_tile_case(300, 128 // (4 if dt == torch.float32 else 2), 136, dt, 8, 3)),
-            (f"gemm_{tag}_tile8_twoblocks", lambda dt=dt: gemm_tile_case(520, 2 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 8, 3)),
-            (f"gemm_{tag}_tile8_threeblocks", lambda dt=dt: gemm_tile_case(520, 3 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 8, 3)),
-            (f"gemm_{tag}_tile8_2048x2560x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 2560, dt, 8, 3, prefetch=True)),
-            (f"conv_{tag}_tile8_splitk2", lambda dt=dt: conv_tile_case(1, 640, 256, 16, 16, dt, 8, 3, ksplit=2)),
-            (f"conv_{tag}_tile8", lambda dt=dt: conv_tile_case(2, 320, 320, 32, 32, dt, 8, 3)),
-            (f"gemm_{tag}_qkv_tile8", lambda dt=dt: gemm_qkv_case(1024, 1280, 640, dt, tile=8)),
-            (f"gemm_{tag}_ln_chain_geglu_tile8", lambda dt=dt: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile1=8, tile2=8)),
-            (f"gemm_{tag}_tile7_oneblock", lambda dt=dt: gemm_tile_case(300, 128 // (4 if dt == torch.float32 else 2), 136, dt, 7, 3)),
-            (f"gemm_{tag}_tile7_twoblocks", lambda dt=dt: gemm_tile_case(520, 2 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 7, 3)),
-            (f"gemm_{tag}_tile7_threeblocks", lambda dt=dt: gemm_tile_case(520, 3 * 128 // (4 if dt == torch.float32 else 2), 264, dt, 7, 3)),
-            (f"gemm_{tag}_tile7_splitk3", lambda dt=dt: gemm_splitk_case(600, 1920, 264, dt, 3, tile=7)),
-            (f"conv_{tag}_tile7", lambda dt=dt: conv_tile_case(2, 320, 320, 32, 32, dt, 7, 3)),
-            (f"conv_{tag}_tile7_splitk2", lambda dt=dt: conv_tile_case(1, 640, 256, 16, 16, dt, 7, 3, ksplit=2)),
-            (f"gemm_{tag}_qkv_tile7", lambda dt=dt: gemm_qkv_case(1024, 1280, 640, dt, tile=7)),
-            (f"gemm_{tag}_geglu_tile7", lambda dt=dt: gemm_geglu_case(520, 640, 2560, dt, tile=7)),
-            (f"gemm_{tag}_ln_chain_tiles_7_7", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=7, tile2=7)),
-            (f"gemm_{tag}_ln_chain_geglu_tile7", lambda dt=dt: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile2=7)),
             (f"gemm_{tag}_tile6_2048x1280x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 1280, dt, 6, 2, prefetch=True)),
             (f"gemm_{tag}_tile6_oneblock", lambda dt=dt: gemm_tile_case(200, 128 // (4 if dt == torch.float32 else 2), 136, dt, 6, 2)),
             (f"gemm_{tag}_tile1_s4_short_k", lambda dt=dt: gemm_tile_case(256, 2 * 128 // (4 if dt == torch.float32 else 2), 256, dt, 1, 4)),
@@ -977,21 +901,19 @@ def all_cases():
             (f"conv_{tag}_tile6", lambda dt=dt: conv_tile_case(2, 320, 320, 16, 16, dt, 6, 2)),
             (f"conv_{tag}_tile6_splitk2", lambda dt=dt: conv_tile_case(1, 640, 256, 16, 16, dt, 6, 2, ksplit=2)),
             (f"conv_{tag}_tile1_s3", lambda dt=dt: conv_tile_case(2, 320, 384, 16, 24, dt, 1, 3)),
-            (f"conv_{tag}_tile5_s3", lambda dt=dt: conv_tile_case(2, 320, 320, 32, 32, dt, 5, 3)),
             (f"gemm_{tag}_qkv_2048x1280", lambda dt=dt: gemm_qkv_case(2048, 1280, 1280, dt)),
             (f"gemm_{tag}_qkv_2048x1280_padded_vt", lambda dt=dt: gemm_qkv_case(2048, 1280, 1280, dt, pad=64)),
             (f"gemm_{tag}_qkv_1000x640_padded_vt_tile4", lambda dt=dt: gemm_qkv_case(1000, 640, 640, dt, tile=4, bias=True, pad=32, seed=231)),
             (f"gemm_{tag}_qkv_1000x640_bias_tile4", lambda dt=dt: gemm_qkv_case(1000, 640, 640, dt, tile=4, bias=True)),
             (f"gemm_{tag}_qkv_tile6", lambda dt=dt: gemm_qkv_case(512, 640, 384, dt, tile=6)),
-            (f"gemm_{tag}_qkv_tile5", lambda dt=dt: gemm_qkv_case(520, 640, 256, dt, tile=5)),
             (f"gemm_{tag}_t_only_ragged", lambda dt=dt: gemm_t_only_case(77 * 2, 2048, 640, dt)),
             (f"gemm_{tag}_t_only_tile2_small_n", lambda dt=dt: gemm_t_only_case(300, 640, 72, dt, tile=2)),
             (f"gemm_{tag}_ln_chain_2048x1280", lambda dt=dt: gemm_ln_chain_case(2048, 1280, 1280, dt)),
             (f"gemm_{tag}_ln_chain_geglu", lambda dt=dt: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True)),
             (f"gemm_{tag}_ln_chain_tiles_4_6", lambda dt=dt: gemm_ln_chain_case(1000, 640, 640, dt, tile1=4, tile2=6)),
             (f"gemm_{tag}_ln_chain_tiles_6_2", lambda dt=dt: gemm_ln_chain_case(300, 320, 384, dt, tile1=6, tile2=2)),
-            (f"gemm_{tag}_ln_chain_tiles_5_3", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=5, tile2=3)),
-            (f"gemm_{tag}_ln_chain_tiles_2_5", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=2, tile2=5)),
+            (f"gemm_{tag}_ln_chain_tiles_1_3", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=1, tile2=3)),
+            (f"gemm_{tag}_ln_chain_tiles_2_1", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=2, tile2=1)),
             (f"gemm_{tag}_lora1_2048x1280x1280", lambda dt=dt: gemm_lora_inlaunch_case(2048, 1280, 1280, dt)),
             (f"gemm_{tag}_lora1_rank8_tile4_edges", lambda dt=dt: gemm_lora_inlaunch_case(300, 640, 200, dt, ranks=(8,), tile=4)),
             (f"gemm_{tag}_lora1_tile2", lambda dt=dt: gemm_lora_inlaunch_case(520, 320, 384, dt, ranks=(16, 4), tile=2)),

@@ -55,7 +55,8 @@ def test_controlnet_mirror_matches_reference(cn_inputs):
     assert l2 < TOL and mx < TOL, (l2, mx)
     # dry lowering (meta device): the branch becomes launches -- 13 residual taps -- and nothing falls back; without its
     # condition image the engine refuses loudly rather than skip the branch
-    from refiners_amd.engine.lowering import UNetIO, UNetLowering, Unsupported, launches
+    from refiners_amd.engine.packing import Unsupported, launches
+    from refiners_amd.engine.unet_lowering import UNetIO, UNetLowering
 
     dev = torch.device("meta")
 

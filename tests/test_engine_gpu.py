@@ -807,6 +807,50 @@ def test_fine_grained_image_prompt_on_the_engine():
             assert mx < tol
 
 
+def test_self_attention_guidance_through_dpm_and_lcm_on_the_engine():
+    """Self-Attention Guidance with the solvers other than DDIM whose add_noise / remove_noise the reference can evaluate
+    (self_attention_guidance.py:86-95): DPM-Solver++ against the REAL reference's two consecutive steps (first- and second-order update,
+    tests/golden/sdxl_sag_solvers.safetensors), direct replay and HIP graph; LCMSolver against the mirror's unfused step on the same GPU (its
+    re-noising draw comes from the CUDA generator there, so the CPU golden's stream does not apply); Euler raises like the reference does."""
+    from refiners_amd.latent_diffusion.sag import SDXLSAGAdapter
+    from refiners_amd.latent_diffusion.sampling import SDXLDenoiser
+    from refiners_amd.latent_diffusion.solvers import DPMSolver, Euler, LCMSolver
+    from tests.golden_cases import SAG_CASE as CFG
+
+    gold = S.golden("sdxl_sag_solvers")
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", CFG["weight_seed"]), device="cuda", dtype=torch.float32)
+    SDXLSAGAdapter(target=unet, scale=CFG["sag_scale"]).inject()
+    inp = {k: v.cuda() for k, v in S.synth.sdxl_inputs(1, CFG["latent_hw"], CFG["input_seed"]).items()}
+    kw = dict(clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"])
+    for use_graph in (False, True):
+        sd = CompiledSDXL(unet, condition_scale=CFG["condition_scale"], solver=DPMSolver(CFG["num_steps"], device="cuda"), use_graph=use_graph)
+        sd.set_inputs(inp["x"], **kw)
+        x1 = sd.step(0).clone()
+        x2 = sd.step(1).clone()
+        for got, key in ((x1, "dpm_x1"), (x2, "dpm_x2")):
+            l2, mx = S.rel_err(got, gold[key])
+            print(f"sag dpm {key} f32 graph={use_graph}: l2 {l2:.2e} max {mx:.2e}")
+            assert l2 < F32_TOL and mx < F32_TOL, (key, use_graph, l2, mx)
+        assert sd.engine.stats["fallback_nodes"] == [] and sd.engine2.stats["fallback_nodes"] == []
+    # LCM: same CUDA generator state for the engine and for the mirror's unfused step
+    ref = SDXLDenoiser(unet, LCMSolver(4, device="cuda"))
+    torch.manual_seed(77)
+    with torch.no_grad():
+        want = ref(inp["x"], 0, condition_scale=1.5, **kw)
+    sd = CompiledSDXL(unet, condition_scale=1.5, solver=LCMSolver(4, device="cuda"))
+    sd.set_inputs(inp["x"], **kw)
+    torch.manual_seed(77)
+    got = sd.step(0)
+    l2, mx = S.rel_err(got, want)
+    print(f"sag lcm f32 vs the mirror's unfused step: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, ("lcm", l2, mx)
+    sd = CompiledSDXL(unet, condition_scale=CFG["condition_scale"], solver=Euler(CFG["num_steps"], device="cuda"))
+    sd.set_inputs(inp["x"], **kw)
+    with pytest.raises(IndexError):
+        sd.step(0)
+
+
 @pytest.mark.parametrize("tag", ["plain", "ip"])
 def test_self_attention_guidance_on_the_engine(tag):
     """Self-Attention Guidance (self_attention_guidance.py:22-105, xl/model.py:164-250) on the compiled

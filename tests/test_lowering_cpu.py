@@ -11,7 +11,7 @@ import torch
 import refiners_amd
 from refiners_amd import native, synth
 from refiners_amd.engine.compiled import CompiledUNet
-from refiners_amd.engine.lowering import UNetIO, UNetLowering
+from refiners_amd.engine.unet_lowering import UNetIO, UNetLowering
 from refiners_amd.fluxion.tree import tree_epoch
 from refiners_amd.latent_diffusion.sd1 import SD1UNet
 from refiners_amd.latent_diffusion.sdxl import SDXLUNet

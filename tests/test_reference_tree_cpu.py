@@ -66,7 +66,7 @@ def test_prompt_side_lowerings_accept_the_real_refiners_trees():
 
     from refiners_amd.clip_image import CLIPImageEncoderH
     from refiners_amd.engine.image_prompt import ImagePromptLowering
-    from refiners_amd.engine.lowering import UNetIO, UNetLowering
+    from refiners_amd.engine.unet_lowering import UNetIO, UNetLowering
     from refiners_amd.engine.sam import SAMLowering
     from refiners_amd.engine.text import TextLowering
     from refiners_amd.engine.vae import VAEDecoderLowering

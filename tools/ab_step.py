@@ -22,7 +22,7 @@ from refiners_amd import native  # noqa: E402
 from refiners_amd.engine import tuning  # noqa: E402
 from refiners_amd.engine.compiled import CompiledSDXL  # noqa: E402
 
-KEYS = ("REFINERS_AMD_GN_FUSED", "REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH", "REFINERS_AMD_TIME_BATCH", "REFINERS_AMD_ATTN_PIPE", "REFINERS_AMD_VT_PAD", "REFINERS_AMD_XATTN_FUSE")
+KEYS = ("REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH", "REFINERS_AMD_TIME_BATCH", "REFINERS_AMD_ATTN_PIPE")
 
 
 def main() -> None:
@@ -47,7 +47,6 @@ def main() -> None:
         for kv in filter(None, envs.split(",")):
             k, v = kv.split(":")
             os.environ[k] = v
-        native.load().mi355x_groupnorm_set_fused(int(os.environ.get("REFINERS_AMD_GN_FUSED", "0") == "1"), 0)  # decided at launch / capture time
         native.attention_pipeline_from_env()
         tuning.enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
         tuning._table = None

@@ -42,7 +42,7 @@ def main():
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
         o = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=dt)
         best = None
-        for tile in (1, 2, 3, 4, 5):
+        for tile in (1, 2, 3, 4, 6):
             if geglu and tile in (2, 4):
                 continue
             line = f"gemm M={M:5d} K={K:5d} N={N:5d} geglu={int(geglu)} tile={tile}:"

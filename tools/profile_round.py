@@ -98,7 +98,7 @@ def step_map(rows: list[tuple], program: list[dict], max_steps: int = 4) -> list
                 if i + 1 < len(st) and "splitk_reduce_kernel" in st[i + 1][0] and ent.get("ksplit", 1) > 1:
                     take = 2
             elif what == "mi355x_groupnorm":
-                take = 1 if "gn_fused_kernel" in n else 3
+                take = 3  # partial sums, finalize, apply
             mapped.append((ent, [x for _, _, x in st[i : i + take]]))
             i += take
         if ok:
