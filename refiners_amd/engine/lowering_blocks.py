@@ -374,7 +374,7 @@ class BlockLowering(Lowering):
         else:
             sc = self.conv_spec(ch[1])
             _expect(sc.ksize == 1 and sc.time is None, "unexpected shortcut")
-            if sc.lora is None and c2.lora is None:
+            if sc.lora is None and (c2.lora is None or (c2.lora.a_kb is not None and self.lora_inlaunch)):  # (an in-launch LoRA adapts segment 0: the shortcut rides along)
                 both = self.cache.get(("bias_sum",) + PackCache.ident(c2.b, sc.b), lambda: (c2.b.float() + sc.b.float()).to(self.dtype))
                 out = self.conv(g2, c2, shortcut=(a, sc), bias=both)
             else:

@@ -143,17 +143,23 @@ def pmc_families(db: str, program: list[dict] | None = None) -> dict:
     for did, name, start, counter, val in con.execute("select dispatch_id, name, min(start), counter_name, sum(counter_value) from pmc_events group by dispatch_id, counter_name"):
         d = per.setdefault(did, {"name": name, "start": start, "c": {}})
         d["c"][counter] = val  # (one row per XCD instance of a dispatch: summed)
-    rows = sorted(((d["name"], d["start"], d["c"]) for d in per.values()), key=lambda r: r[1])
+    rows = sorted(((d["name"], d["start"], dict(d["c"], _name=d["name"])) for d in per.values()), key=lambda r: r[1])
     fams: dict = {}
     classes: dict = {}
+    kernels: dict = {}
 
     def add(store: dict, key: str, cs: dict, launches: int = 0) -> None:
         for counter, val in cs.items():
+            if counter == "_name":
+                continue
             e = store.setdefault(key, {}).setdefault(counter, {"dispatches": 0, "sum": 0.0, "launches": 0})
             e["dispatches"] += 1
             e["sum"] += val
-        for counter in cs:
-            store[key][counter]["launches"] += launches
+            e["launches"] += launches
+
+    def short(n: str) -> str:
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        return n if len(n) < 120 else n[:117] + "..."
 
     steps = step_map(rows, program) if program else []
     if steps:
@@ -164,13 +170,14 @@ def pmc_families(db: str, program: list[dict] | None = None) -> dict:
                 for j, cs in enumerate(payloads):
                     add(fams, f, cs)
                     add(classes, ent["key"], cs, launches=1 if j == 0 else 0)
+                    add(kernels, short(cs["_name"]), cs)
     else:
         scope = "whole process (no step program given, or it did not match the trace)"
         for name, _, cs in rows:
             f = family(name)
             if f is not None:
                 add(fams, f, cs)
-    return {"scope": scope, "families": fams, "classes": classes}
+    return {"scope": scope, "families": fams, "classes": classes, "kernels": kernels}
 
 
 def main() -> None:
@@ -210,6 +217,13 @@ def main() -> None:
             try:
                 r = pmc_families(db, program)
                 got[name], got_cls[name], scope = r["families"], r["classes"], r["scope"]
+                if name == "sq":  # which kernel VARIANT loses LDS cycles to bank conflicts (the family figure hides it)
+                    by_k = {k: {c: v["sum"] for c, v in cs.items()} for k, cs in r["kernels"].items()}
+                    for k, cs in by_k.items():
+                        if cs.get("SQ_LDS_IDX_ACTIVE"):
+                            cs["lds_conflict_frac"] = cs.get("SQ_LDS_BANK_CONFLICT", 0.0) / cs["SQ_LDS_IDX_ACTIVE"]
+                    (OUT / f"{tag}_pmc_sq_by_kernel.json").write_text(json.dumps({"how": how, "scope": scope, "kernels": by_k}, indent=1))
+                    print({k[:60]: round(v.get("lds_conflict_frac", 0.0), 3) for k, v in by_k.items() if "attn" in k})
                 print("  scope:", scope)
             except Exception as exc:  # noqa: BLE001
                 print("  failed to read", exc)
