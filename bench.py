@@ -150,6 +150,37 @@ WORKLOADS = {
 }
 
 
+def stage_inputs(pipe, specs: dict, n_img: int, seed: int, dev: torch.device) -> None:
+    from refiners_amd import synth
+
+    inp = synth.sdxl_inputs(n_img, LATENT, seed=seed)
+    kw = {}
+    if specs["ip"] is not None:
+        kw["clip_image_embedding"] = specs["ip"]["tokens"].to(dev)
+    if specs["control"]:
+        kw["conditions"] = {c["name"]: c["condition"].to(dev) for c in specs["control"]}
+    pipe.set_inputs(inp["x"].to(dev), clip_text_embedding=inp["text"].to(dev), pooled_text_embedding=inp["pooled"].to(dev),
+                    time_ids=inp["time_ids"].to(dev), **kw)
+
+
+def replica_check(pipe, specs: dict, n_img: int, dev: torch.device) -> dict:
+    """N > 1 only, after the timed region: every rank runs ONE step on the SAME inputs and the outputs are compared across ranks -- the
+    replicas hold broadcast weights and broadcast packed weights (K-blocked / merged / folded on rank 0 only), so a hand-over bug shows up
+    here as a rank whose step differs.  Not bit-exact by design (split-K partial sums land in arrival order): 1e-3 relative."""
+    stage_inputs(pipe, specs, n_img, 100, dev)
+    pipe.step(0)
+    x = pipe.x.double()
+    mine = torch.stack([x.sum(), x.abs().sum(), x.square().sum()]).to(dev)
+    world = torch.distributed.get_world_size()
+    got = [torch.empty_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(got, mine)
+    ref = got[0]
+    dev_max = max(float(((g - ref).abs() / ref.abs().clamp_min(1e-30)).max()) for g in got)
+    if not dev_max < 1e-3:
+        raise RuntimeError(f"replicas disagree on the same inputs: checksums {[g.tolist() for g in got]}")
+    return {"max_rel_checksum_deviation": dev_max, "ranks": world}
+
+
 def build_pipeline(workload: str, n_img: int, rank: int, dev: torch.device, dtype: torch.dtype, lora_mode: str, use_graph: bool, broadcast: bool = True):
     """UNet (random init in HBM) + adapters injected through the Chain API + one CompiledSDXL with its inputs staged."""
     import refiners_amd
@@ -174,16 +205,18 @@ def build_pipeline(workload: str, n_img: int, rank: int, dev: torch.device, dtyp
     n_bcast = parallel.broadcast_module(unet, src=0) if broadcast else 0
     torch.cuda.synchronize()
     bcast_s = time.time() - tb
-    inp = synth.sdxl_inputs(n_img, LATENT, seed=100 + rank)
     pipe = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=use_graph, lora_mode=lora_mode)
-    kw = {}
-    if specs["ip"] is not None:
-        kw["clip_image_embedding"] = specs["ip"]["tokens"].to(dev)
-    if specs["control"]:
-        kw["conditions"] = {c["name"]: c["condition"].to(dev) for c in specs["control"]}
-    pipe.set_inputs(inp["x"].to(dev), clip_text_embedding=inp["text"].to(dev), pooled_text_embedding=inp["pooled"].to(dev),
-                    time_ids=inp["time_ids"].to(dev), **kw)
-    return unet, specs, bare_sd, pipe, {"weights_broadcast_s": round(bcast_s, 3), "broadcast_launches": n_bcast}
+    stage_inputs(pipe, specs, n_img, 100 + rank, dev)
+    info = {"weights_broadcast_s": round(bcast_s, 3), "broadcast_launches": n_bcast}
+    if broadcast and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        # every rank lowers its own program (it holds local addresses); only rank 0 K-blocks / merges / LayerNorm-folds the weights, the packed
+        # copies then travel over xGMI like the weights did (refiners_amd.parallel.broadcast_packs)
+        torch.cuda.synchronize()
+        tp = time.time()
+        n_pk = parallel.broadcast_packs(pipe.lower_now, pipe.engine.cache, src=0)
+        torch.cuda.synchronize()
+        info.update(packs_broadcast_s=round(time.time() - tp, 3), packs_broadcast_launches=n_pk)
+    return unet, specs, bare_sd, pipe, info
 
 
 def timed_steps(pipe, steps: int, warmup: int, world: int, dev: torch.device) -> float:
@@ -340,6 +373,10 @@ def main() -> None:
     rank, world, local = parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    if os.environ.get("REFINERS_AMD_DIST_BACKEND") == "gloo":
+        # rehearsal on a one-GPU box: every rank drives cuda:0 and the collectives go through gloo (host-staged).  It exercises the N > 1
+        # control flow (arena broadcast, pack broadcast, barriers, max-over-ranks clock) end to end; its throughput means nothing.
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     native.load()
@@ -353,6 +390,8 @@ def main() -> None:
     elapsed = timed_steps(pipe, args.steps, args.warmup, world, dev)
     setup_s = time.time() - t0 - elapsed
     finite = bool(torch.isfinite(pipe.x.float()).all())
+    if world > 1:
+        bc["replica_check"] = replica_check(pipe, specs, n_img, dev)
 
     if rank != 0:
         if world > 1:
@@ -479,6 +518,8 @@ def main() -> None:
         "step_latency_ms": round(ms_per_step, 3),
         "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
     }
+    if os.environ.get("REFINERS_AMD_DIST_BACKEND") == "gloo":
+        line["config"]["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
     print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -351,6 +351,16 @@ class CompiledSDXL:
         if self.coef_table is None or self.coef_table.device != x.device:
             self._tables(x.device)
 
+    def lower_now(self) -> None:
+        """Build the launch programs for the staged inputs without running anything (refiners_amd.parallel.broadcast_packs lowers on every
+        rank but lets only the source compute the packed weights: the prologue must not run before they have arrived)."""
+        assert self.x is not None, "call set_inputs first"
+        if self.coef_table is None or self.coef_table.device != self.x.device:
+            self._tables(self.x.device)
+        n = self.x.shape[0]
+        self.engine.prepare_explicit((2 * n,) + tuple(self.x.shape[1:]), self.x.device, dict(self.inputs, timestep=self.ts_table[0:1]))
+        self.engine.prologue_key = None  # staged, not yet run: the first step() re-stages and runs the prologue
+
     def _fill(self) -> None:
         io = self.engine.io
         n = self.x.shape[0]  # type: ignore[union-attr]

@@ -173,12 +173,23 @@ class _Src:
 
 class PackCache:
     """Packed / converted copies of leaf weights, keyed on the identity and version of the source tensors (which the key
-    keeps alive, see _Src), so that a re-lowering after inject / eject / scale change only re-packs what actually changed."""
+    keeps alive, see _Src), so that a re-lowering after inject / eject / scale change only re-packs what actually changed.
+
+    Multi-GPU (refiners_amd.parallel.broadcast_packs): only the source rank COMPUTES the packs.  It lowers normally and publishes
+    `manifest()` -- for every entry, in creation order, either "alias" (the value is the leaf's own storage: every rank makes it
+    itself, nothing to move) or the shapes / dtypes of the tensors inside the value; the other ranks lower with `adopt(manifest)`,
+    which answers each miss with uninitialised storage of that description instead of calling `make()` (no K-blocking, merging,
+    LayerNorm folding, concatenation on the receivers), and one bucketed broadcast then fills `leaves()` in place (in place: the
+    recorded programs already hold the tensors' addresses)."""
 
     def __init__(self) -> None:
         self.store: dict[tuple, Any] = {}
         self.hits = 0
         self.used: set[tuple] = set()
+        self.order: list[tuple] = []          # keys in creation order (what the manifest walks)
+        self._adopt: Optional[list] = None    # receiver side: the source's manifest
+        self._cursor = 0
+        self.made = 0                         # make() calls that really ran here (receivers: aliases only)
 
     @staticmethod
     def ident(*tensors: Optional[Tensor]) -> tuple:
@@ -189,12 +200,99 @@ class PackCache:
         if key in self.store:
             self.hits += 1
             return self.store[key]
-        v = make()
+        if self._adopt is not None:
+            assert self._cursor < len(self._adopt), "the source rank lowered fewer packed weights than this rank asks for (different trees?)"
+            spec = self._adopt[self._cursor]
+            self._cursor += 1
+            if spec[0] == "alias":
+                v = make()
+                self.made += 1
+            else:
+                v = _build(spec[1], _key_device(key))
+        else:
+            v = make()
+            self.made += 1
         self.store[key] = v
+        self.order.append(key)
         return v
 
     def sweep(self) -> None:
         for k in list(self.store):
             if k not in self.used:
                 del self.store[k]
+        self.order = [k for k in self.order if k in self.store]
         self.used = set()
+
+    # -- multi-GPU hand-over ----------------------------------------------------------------------------------------------------
+    def manifest(self) -> list:
+        """Source side: one picklable description per entry, in creation order."""
+        out = []
+        for key in self.order:
+            v = self.store[key]
+            src = {s.t.data_ptr() for s in key if isinstance(s, _Src)}
+            leaves = _leaves(v)
+            if not leaves or any(t.data_ptr() in src for t in leaves):
+                out.append(("alias",))
+            else:
+                out.append(("recv", _describe(v)))
+        return out
+
+    def adopt(self, manifest: list) -> None:
+        """Receiver side, BEFORE lowering: answer misses from the source's manifest."""
+        self._adopt, self._cursor = manifest, 0
+
+    def leaves(self, manifest: list) -> list[Tensor]:
+        """The tensors of every "recv" entry, in manifest order: what the broadcast writes (source) / fills (receivers)."""
+        assert len(manifest) == len(self.order), (len(manifest), len(self.order))
+        out: list[Tensor] = []
+        for key, spec in zip(self.order, manifest):
+            if spec[0] == "recv":
+                out.extend(_leaves(self.store[key]))
+        self._adopt = None
+        return out
+
+
+def _key_device(key: tuple) -> torch.device:
+    return next((s.t.device for s in key if isinstance(s, _Src)), torch.device("cpu"))
+
+
+def _leaves(v: Any) -> list[Tensor]:
+    if isinstance(v, Tensor):
+        return [v]
+    if isinstance(v, native.KBlocked):
+        return [v.t]
+    if isinstance(v, LoraPack):
+        return [t for f in ("a_cat", "bs_cat", "a_kb", "bs_r") for t in _leaves(getattr(v, f))]
+    if isinstance(v, (tuple, list)):
+        return [t for x in v for t in _leaves(x)]
+    return []
+
+
+def _describe(v: Any) -> Any:
+    if isinstance(v, Tensor):
+        return ("T", tuple(v.shape), str(v.dtype).replace("torch.", ""))
+    if isinstance(v, native.KBlocked):
+        return ("KB", v.N, v.K, _describe(v.t))
+    if isinstance(v, LoraPack):
+        return ("LP", _describe(v.a_cat), _describe(v.bs_cat), v.conv, _describe(v.a_kb), _describe(v.bs_r))
+    if isinstance(v, tuple):
+        return ("tuple", [_describe(x) for x in v])
+    if isinstance(v, list):
+        return ("list", [_describe(x) for x in v])
+    assert v is None or isinstance(v, (int, float, str, bool)), f"PackCache value of type {type(v).__name__} cannot be handed to another rank"
+    return ("V", v)
+
+
+def _build(spec: Any, device: torch.device) -> Any:
+    kind = spec[0]
+    if kind == "T":
+        return torch.empty(spec[1], dtype=getattr(torch, spec[2]), device=device)
+    if kind == "KB":
+        return native.KBlocked(_build(spec[3], device), _adopt=(spec[1], spec[2]))
+    if kind == "LP":
+        return LoraPack(_build(spec[1], device), _build(spec[2], device), None if spec[3] is None else tuple(spec[3]), _build(spec[4], device), _build(spec[5], device))
+    if kind == "tuple":
+        return tuple(_build(x, device) for x in spec[1])
+    if kind == "list":
+        return [_build(x, device) for x in spec[1]]
+    return spec[1]

@@ -27,14 +27,15 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # REFINERS_AMD_DIST_BACKEND=gloo: rehearsal of the N > 1 flow where RCCL cannot run (several ranks on ONE GPU, see bench.py)
+            backend = os.environ.get("REFINERS_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
-def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int = 512 << 20, align: int = 256) -> int:
+def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int = 512 << 20, align: int = 256, repoint: bool = True) -> int:
     """In-place broadcast of many tensors through ONE flat arena per (dtype, device), sent in large bucket-sized pieces.
 
     No staging copies on the receivers: every tensor's storage is RE-POINTED into the arena (`t.data = arena[off : off + n]`,
@@ -42,7 +43,8 @@ def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int
     rank pays one copy-in pass.  The arena stays the weights' home afterwards (one allocation instead of thousands, which is
     also what a packed / direct-to-GPU checkpoint load wants).  Each `dist.broadcast` moves up to `bucket_bytes`; RCCL
     pipelines a large message over all its channels / xGMI links by itself, so fewer, larger messages are the lever here
-    (SURVEY.md section 8(e)).  Returns the number of collective launches."""
+    (SURVEY.md section 8(e)).  `repoint=False`: the tensors keep their storage (somebody already holds their addresses -- the packed
+    weights of a lowered program) and the receivers copy out of the arena instead.  Returns the number of collective launches."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     rank = dist.get_rank()
@@ -66,11 +68,15 @@ def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int
             view = arena[off : off + t.numel()].view(t.shape)
             if rank == src:
                 view.copy_(t.detach())
-            t.data = view  # the parameter now lives in the arena (no copy-back after the collective)
+            if repoint:
+                t.data = view  # the parameter now lives in the arena (no copy-back after the collective)
         per = max(bucket_bytes // es, 1)
         for lo in range(0, total, per):
             dist.broadcast(arena[lo : min(lo + per, total)], src=src)
             launches += 1
+        if not repoint and rank != src:
+            for t, off in zip(items, offs):
+                t.copy_(arena[off : off + t.numel()].view(t.shape))
     return launches
 
 
@@ -113,6 +119,37 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 
 
         bump_epoch()
     return n
+
+
+def broadcast_packs(lower: Any, cache: Any, src: int = 0, bucket_bytes: int = 512 << 20) -> int:
+    """Lower on every rank, pack on ONE: `lower()` builds this rank's launch program(s) against `cache` (a refiners_amd.engine.packing.PackCache);
+    the source runs it normally and publishes the cache's manifest, the others run it with the cache in adopt mode (uninitialised storage
+    of the published shapes instead of K-blocking / merging / LayerNorm folding / concatenating the weights themselves), then one bucketed
+    broadcast fills the packed weights IN PLACE (the programs already hold their addresses).  Call it after broadcast_module (the leaves the
+    aliasing entries point at must already hold the source's values).  Returns the number of collective launches (0 single-process)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        lower()
+        return 0
+    rank = dist.get_rank()
+    err: BaseException | None = None
+    box: list[Any] = [None]
+    try:
+        if rank == src:
+            lower()
+            box[0] = cache.manifest()
+    except BaseException as e:  # noqa: BLE001
+        err = e
+    propagate_failure(err, "broadcast_packs: lowering on the source rank")
+    dist.broadcast_object_list(box, src=src)
+    manifest = box[0]
+    try:
+        if rank != src:
+            cache.adopt(manifest)
+            lower()
+    except BaseException as e:  # noqa: BLE001
+        err = e
+    propagate_failure(err, "broadcast_packs: lowering on a receiving rank")
+    return broadcast_tensors(cache.leaves(manifest), src=src, bucket_bytes=bucket_bytes, repoint=False)
 
 
 def load_and_broadcast(module: torch.nn.Module, tensors_path: Any, device: torch.device | str, src: int = 0, strict: bool = True) -> int:

@@ -208,6 +208,57 @@ def test_bench_shaped_dry_run_world2():
     assert d0 is not None and d0 < 1e-6 and d1 is None
 
 
+def _worker_packs(rank: int, world: int, port: int, q) -> None:
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd import native, parallel
+    from refiners_amd.engine.lowering_blocks import BlockLowering
+    from refiners_amd.engine.packing import Act, PackCache, _leaves
+    from refiners_amd.engine.unet_lowering import UNetContext
+    from refiners_amd.fluxion.adapters import LinearLora, LoraAdapter
+    from refiners_amd.latent_diffusion.blocks import CrossAttentionBlock2d, ResidualBlock
+
+    native.load()
+    parallel.init_from_env("gloo")
+    torch.manual_seed(100 + rank)  # different weights per rank until the broadcast
+    tree = fl.Chain(ResidualBlock(64, 128), CrossAttentionBlock2d(channels=128, context_embedding_dim=64, context_key="clip_text_embedding", num_attention_heads=2, use_bias=False, use_linear_projection=True))
+    for lin in [m for m in tree.layers(fl.Linear) if m.in_features == 128 and m.out_features == 128][:3]:  # live LoRAs: stacked / K-blocked packs
+        lo = LinearLora("l", in_features=128, out_features=128, rank=8)
+        torch.nn.init.normal_(lo.up.weight)
+        LoraAdapter(lin, lo).inject()
+    parallel.broadcast_module(tree, src=0)
+    cache = PackCache()
+    B, H, W = 2, 8, 8
+
+    def lower() -> None:
+        low = BlockLowering(torch.device("cpu"), torch.float32, cache)
+        ctx = UNetContext(low, B)
+        ctx.text[("cross_attention_block", "clip_text_embedding")] = (torch.zeros(B * 64, 64), 7)
+        with low.in_step():
+            a = Act(low.pool.get(B * H * W, 64), B, H, W)
+            a = low.residual_block(tree[0], a, ctx)
+            low.cross_attention_2d(tree[1], a, ctx)
+        cache.sweep()
+
+    n = parallel.broadcast_packs(lower, cache, src=0, bucket_bytes=4096)
+    man = cache.manifest()
+    digest = sum(float(t.double().sum()) for key in cache.order for t in _leaves(cache.store[key]))
+    q.put((rank, n, cache.made, sum(1 for m in man if m[0] == "recv"), len(man), digest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_only_the_source_rank_packs_the_weights():
+    """PackCache contents (K-blocked copies, stacked LoRA rows, LayerNorm-folded weights, merged biases ...) are computed on
+    rank 0 only and broadcast; the receivers' lowering makes nothing but the aliasing entries (views of leaves the weight broadcast already
+    filled), and ends up with identical packed weights."""
+    (_, n0, made0, recv0, len0, d0), (_, n1, made1, recv1, len1, d1) = _spawn(_worker_packs, lambda r: ())
+    assert n0 == n1 >= 1 and len0 == len1 and recv0 == recv1 > 5
+    assert made0 == len0  # the source made everything ...
+    assert made1 == len1 - recv1  # ... the receiver only the aliases
+    assert d0 == d1
+
+
 def test_shard_range_covers_everything():
     from refiners_amd.parallel import shard_range
 
