@@ -171,9 +171,10 @@ def replica_check(pipe, specs: dict, n_img: int, dev: torch.device) -> dict:
     pipe.step(0)
     x = pipe.x.double()
     mine = torch.stack([x.sum(), x.abs().sum(), x.square().sum()]).to(dev)
+    from refiners_amd import parallel
+
     world = torch.distributed.get_world_size()
-    got = [torch.empty_like(mine) for _ in range(world)]
-    torch.distributed.all_gather(got, mine)
+    got = parallel.all_gather(mine)
     ref = got[0]
     dev_max = max(float(((g - ref).abs() / ref.abs().clamp_min(1e-30)).max()) for g in got)
     if not dev_max < 1e-3:

@@ -96,8 +96,64 @@ def main_solvers() -> None:
     save_file(out, str(GOLD / "sdxl_sag_solvers.safetensors"))
 
 
+def main_conditions() -> None:
+    """The guidance together with spatial conditions.  The second (degraded) UNet pass runs on n rows while the CFG pass ran on 2n, and the
+    ControlLora / T2I-Adapter stay injected with their contexts set (xl/model.py:186-246 only swaps the text / pooled / time-id / image
+    embeddings): a batch-1 control picture / batch-1 T2I features broadcast into both passes, a 2n-row control picture cannot be added to an
+    n-row batch.  Stored: one DDIM step each for ControlLora (own rank-8 LoRA, scale 0.9) and SDXLT2IAdapter with batch-1 conditions, with
+    the guidance and with its scale at zero; the 2n-row ControlLora case is run to confirm that the reference raises.
+    -> tests/golden/sdxl_sag_conditions.safetensors"""
+    from refiners.foundationals.latent_diffusion.stable_diffusion_xl.t2i_adapter import SDXLT2IAdapter
+
+    from tests.golden_cases import T2I_CASE, control_lora_targets
+
+    shapes = synth.model_shapes(SDXLUNet(4, device="meta"))
+    out = {}
+    inp = synth.sdxl_inputs(1, CFG["latent_hw"], CFG["input_seed"])
+    kw = dict(clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], condition_scale=CFG["condition_scale"])
+
+    def pipeline(unet):  # noqa: ANN001, ANN202
+        return StableDiffusion_XL(unet=unet, lda=rfl.Chain(rfl.Identity()), clip_text_encoder=rfl.Chain(rfl.Identity()),  # type: ignore[arg-type]
+                                  solver=DDIM(num_inference_steps=CFG["num_steps"]))
+
+    with torch.no_grad():
+        for batch in (1, 2):
+            unet = reference_model(SDXLUNet, shapes, CFG["weight_seed"])
+            own = synth.lora_spec(shapes, "ctl_canny", 1.0, rank=8, seed=CFG["weight_seed"] + 101, targets=control_lora_targets(shapes))
+            ctl = synth.control_spec("canny", 0.9, batch, CFG["latent_hw"], seed=CFG["weight_seed"] + 100, loras=[own])
+            synth.apply_adapters(unet, REF_API, loras=[], ip=None, control=[ctl])
+            sd = pipeline(unet)
+            sd.set_self_attention_guidance(enable=True, scale=CFG["sag_scale"])
+            if batch == 2:
+                try:
+                    sd(inp["x"], step=CFG["step"], **kw)
+                    raise SystemExit("the reference evaluated SAG with a 2n-row control picture: the engine's refusal is wrong")
+                except RuntimeError as e:
+                    print("control picture with 2n rows: the reference raises RuntimeError:", str(e)[:120])
+                continue
+            out["control_x1"] = sd(inp["x"], step=CFG["step"], **kw).contiguous()
+            sd.set_self_attention_guidance(enable=True, scale=0.0)
+            out["control_x1_without_sag"] = sd(inp["x"], step=CFG["step"], **kw).contiguous()
+            print("control", float((out["control_x1"] - out["control_x1_without_sag"]).abs().mean()), float(out["control_x1"].abs().mean()), flush=True)
+        unet = reference_model(SDXLUNet, shapes, CFG["weight_seed"])
+        adapter = SDXLT2IAdapter(unet, name="depth", scale=T2I_CASE["scale"]).inject()
+        eshapes = synth.model_shapes(adapter.condition_encoder)
+        adapter.condition_encoder.load_state_dict(synth.synth_state_dict(eshapes, T2I_CASE["weight_seed"] + 7), assign=True)
+        picture = torch.rand((1, 3, 8 * CFG["latent_hw"][0], 8 * CFG["latent_hw"][1]), generator=synth._gen("t2i.condition", CFG["input_seed"]))
+        adapter.set_condition_features(adapter.compute_condition_features(picture))
+        sd = pipeline(unet)
+        sd.set_self_attention_guidance(enable=True, scale=CFG["sag_scale"])
+        out["t2i_x1"] = sd(inp["x"], step=CFG["step"], **kw).contiguous()
+        sd.set_self_attention_guidance(enable=True, scale=0.0)
+        out["t2i_x1_without_sag"] = sd(inp["x"], step=CFG["step"], **kw).contiguous()
+        print("t2i", float((out["t2i_x1"] - out["t2i_x1_without_sag"]).abs().mean()), float(out["t2i_x1"].abs().mean()), flush=True)
+    save_file(out, str(GOLD / "sdxl_sag_conditions.safetensors"))
+
+
 if __name__ == "__main__":
-    if "--solvers" in sys.argv:
+    if "--conditions" in sys.argv:
+        main_conditions()
+    elif "--solvers" in sys.argv:
         main_solvers()
     else:
         main()

@@ -328,7 +328,7 @@ class CompiledSDXL:
                    clip_image_embedding: Optional[Tensor] = None, conditions: Optional[dict[str, Tensor]] = None,
                    t2i_features: Optional[dict[str, Any]] = None, generator: Optional[torch.Generator] = None) -> None:
         """x: (N, 4, H, W) initial latents; embeddings are [negative ; conditional] stacks of 2N rows;
-        `conditions` maps a ControlLora name to its (2N, 3, 8H, 8W) control image; `t2i_features` maps a T2I-Adapter name to
+        `conditions` maps a ControlLora name to its control image, (2N, 3, 8H, 8W) or ONE picture (1, 3, 8H, 8W) for the whole batch; `t2i_features` maps a T2I-Adapter name to
         the tuple its `compute_condition_features` returned (batch 1 or 2N)."""
         self.generator = generator  # stochastic solvers (LCM) draw their per-step noise from it, in the reference's order
         tokens = {("cross_attention_block", "clip_text_embedding"): clip_text_embedding}
@@ -430,8 +430,14 @@ class CompiledSDXL:
         if self.sag_table is None:  # the reference raises the same way (Solver.remove_noise indexes integer tables with the solver's timesteps)
             raise IndexError(f"{type(self.solver).__name__}: add_noise / remove_noise are not defined for this solver's timesteps, so Self-Attention Guidance "
                              "cannot be evaluated (refiners raises here as well)")
-        # (ControlLora / T2I conditions: the reference's own second pass feeds the 2n-row control images to an n-row batch and fails; refused loudly here)
-        assert self.condition_scale != 0.0 and not got["conditions"] and not got.get("t2i"), "SAG with ControlLora / T2I conditions or a zero guidance scale is not lowered"
+        assert self.condition_scale != 0.0, "SAG with a zero guidance scale is not lowered"
+        # ControlLora pictures / T2I-Adapter features stay in their contexts for the second pass (xl/model.py:186-246 swaps only the text, pooled,
+        # time-id and image embeddings), which has n rows after the CFG pass's 2n: batch-1 conditions broadcast into both, anything else cannot be
+        # added to the n-row stem -- torch raises RuntimeError in the reference (oracle/make_golden_sag.py --conditions), so does this
+        for name, rows in [(k, v.shape[0]) for k, v in got["conditions"].items()] + [(k, f.shape[0]) for k, feats in got.get("t2i", {}).items() for f in feats]:
+            if rows not in (1, n):
+                raise RuntimeError(f"Self-Attention Guidance runs its second UNet pass on {n} row(s): condition '{name}' has {rows} rows and cannot be "
+                                   "broadcast to it (give one picture / one set of features for the whole batch; refiners fails on this shape as well)")
         self.sag_coef.copy_(self.sag_table[step])
         assert getattr(low, "sag", None) is not None and getattr(low, "sag_shape", None) is not None, "SAG adapter present but its taps were not found in the lowered tree"
         if self.engine2 is None:
@@ -445,7 +451,7 @@ class CompiledSDXL:
             half = lambda t: None if t is None else t[: t.shape[0] // 2]  # noqa: E731
             halves = (self.inputs, {"pooled": half(got["pooled"]), "time_ids": half(got["time_ids"]), "tokens": {k: half(v) for k, v in got["tokens"].items()}})
             self._sag_halves = halves
-        got2 = {"timestep": got["timestep"], **halves[1], "conditions": {}, "t2i": {}}
+        got2 = {"timestep": got["timestep"], **halves[1], "conditions": got["conditions"], "t2i": got.get("t2i", {})}
         x = self.x
         if e2.prepare_explicit((n,) + tuple(x.shape[1:]), x.device, got2):
             e2.run_prologue()

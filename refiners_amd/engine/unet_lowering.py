@@ -391,6 +391,16 @@ class UNetLowering(BlockLowering):
         _expect(cond is not None, f"no condition image registered for {cname_}")
         with self.in_prologue():
             e = self.condition_encoder(enc, cond)
+            if e.B == 1 and cur.B > 1:
+                # ONE control picture for the whole batch: the reference's Sum broadcasts it (and it is the only form its Self-Attention
+                # Guidance pass, n rows after a 2n-row CFG pass, can take): encode once, repeat the rows once per prompt, here
+                _expect((e.H, e.W, e.C) == (cur.H, cur.W, cur.C), "ConditionEncoder output does not match the UNet stem")
+                full = self.pool.get(cur.M, cur.C)
+                hw = cur.H * cur.W
+                for b in range(cur.B):
+                    native.axpby(e.t, 1.0, e.t, 0.0, full[b * hw : (b + 1) * hw])
+                self.pool.put(e.t)
+                e = Act(full, cur.B, cur.H, cur.W)
             self.pool.pin(e.t)
         _expect((e.B, e.H, e.W, e.C) == (cur.B, cur.H, cur.W, cur.C), "ConditionEncoder output does not match the UNet stem")
         out = self.pool.get(cur.M, cur.C)

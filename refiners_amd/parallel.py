@@ -35,6 +35,29 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local
 
 
+def _staged(t: Tensor) -> bool:
+    """gloo moves host memory: device tensors are staged through the host (the one-GPU rehearsal of bench.py; RCCL takes them as they are)."""
+    return t.device.type != "cpu" and dist.get_backend() == "gloo"
+
+
+def _broadcast(t: Tensor, src: int) -> None:
+    if not _staged(t):
+        dist.broadcast(t, src=src)
+        return
+    h = t.cpu()
+    dist.broadcast(h, src=src)
+    if dist.get_rank() != src:
+        t.copy_(h)
+
+
+def all_gather(t: Tensor) -> list[Tensor]:
+    """Every rank's `t` (same shape and dtype everywhere), on t's device."""
+    h = t.cpu() if _staged(t) else t
+    parts = [torch.empty_like(h) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, h)
+    return [p.to(t.device) for p in parts]
+
+
 def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int = 512 << 20, align: int = 256, repoint: bool = True) -> int:
     """In-place broadcast of many tensors through ONE flat arena per (dtype, device), sent in large bucket-sized pieces.
 
@@ -72,7 +95,7 @@ def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int
                 t.data = view  # the parameter now lives in the arena (no copy-back after the collective)
         per = max(bucket_bytes // es, 1)
         for lo in range(0, total, per):
-            dist.broadcast(arena[lo : min(lo + per, total)], src=src)
+            _broadcast(arena[lo : min(lo + per, total)], src)
             launches += 1
         if not repoint and rank != src:
             for t, off in zip(items, offs):
@@ -210,13 +233,11 @@ def gather_latents(x: Tensor, dst: int = 0) -> Tensor | None:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
     world = dist.get_world_size()
-    counts = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+    counts = all_gather(torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
     most = int(max(int(c) for c in counts))
     padded = torch.zeros((most,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     padded[: x.shape[0]] = x
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded)
+    parts = all_gather(padded)
     if dist.get_rank() != dst:
         return None
     return torch.cat([p[: int(c)] for p, c in zip(parts, counts)])
@@ -225,6 +246,6 @@ def gather_latents(x: Tensor, dst: int = 0) -> Tensor | None:
 def max_over_ranks(value: float, device: torch.device | str = "cpu") -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)

@@ -934,6 +934,59 @@ def test_self_attention_guidance_through_dpm_and_lcm_on_the_engine():
         sd.step(0)
 
 
+@pytest.mark.parametrize("tag", ["control", "t2i"])
+def test_self_attention_guidance_with_spatial_conditions_on_the_engine(tag):
+    """the guidance with a ControlLora (own rank-8 LoRA) / a T2I-Adapter injected.  The conditions stay in their contexts
+    for the second pass (xl/model.py:186-246 swaps embeddings only): one control picture / one set of features broadcasts into the 2n-row CFG
+    program and into the n-row degraded program; a 2n-row picture raises RuntimeError as in the reference.  float32 vs the REAL reference's
+    step (tests/golden/sdxl_sag_conditions.safetensors), direct replay and HIP graph."""
+    import json
+
+    from refiners_amd.latent_diffusion.sag import SDXLSAGAdapter
+    from tests.golden_cases import SAG_CASE as CFG
+    from tests.golden_cases import T2I_CASE, control_lora_targets
+
+    gold = S.golden("sdxl_sag_conditions")
+    unet = SDXLUNet(4, device="meta")
+    S.load_mirror_weights(unet, S.weights("sdxl", CFG["weight_seed"]), device="cuda", dtype=torch.float32)
+    shapes = S.key_shapes("sdxl")
+    kw = {}
+    if tag == "control":
+        own = S.synth.lora_spec(shapes, "ctl_canny", 1.0, rank=8, seed=CFG["weight_seed"] + 101, targets=control_lora_targets(shapes))
+        ctl = S.synth.control_spec("canny", 0.9, 1, CFG["latent_hw"], seed=CFG["weight_seed"] + 100, loras=[own])
+        S.synth.apply_adapters(unet, refiners_amd.namespace(), device="cuda", dtype=torch.float32, loras=[], ip=None, control=[ctl])
+        kw["conditions"] = {"canny": ctl["condition"].cuda()}
+    else:
+        from refiners_amd.latent_diffusion.t2i import SDXLT2IAdapter
+
+        adapter = SDXLT2IAdapter(unet, name="depth", scale=T2I_CASE["scale"]).inject()
+        eshapes = {k: tuple(v) for k, v in json.loads((S.GOLD / "t2i_keys.json").read_text()).items()}
+        adapter.condition_encoder.load_state_dict({k: v.cuda() for k, v in S.synth.synth_state_dict(eshapes, T2I_CASE["weight_seed"] + 7).items()}, assign=True)
+        picture = torch.rand((1, 3, 8 * CFG["latent_hw"][0], 8 * CFG["latent_hw"][1]), generator=S.synth._gen("t2i.condition", CFG["input_seed"])).cuda()
+        with torch.no_grad():
+            kw["t2i_features"] = {"depth": adapter.compute_condition_features(picture)}
+    SDXLSAGAdapter(target=unet, scale=CFG["sag_scale"]).inject()
+    inp = {k: v.cuda() for k, v in S.synth.sdxl_inputs(1, CFG["latent_hw"], CFG["input_seed"]).items()}
+    emb = dict(clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"])
+    outs = []
+    for use_graph in (False, True):
+        sd = CompiledSDXL(unet, num_inference_steps=CFG["num_steps"], condition_scale=CFG["condition_scale"], use_graph=use_graph)
+        sd.set_inputs(inp["x"], **emb, **kw)
+        x1 = sd.step(CFG["step"]).clone()
+        l2, mx = S.rel_err(x1, gold[f"{tag}_x1"])
+        print(f"sag + {tag} f32 graph={use_graph}: l2 {l2:.2e} max {mx:.2e}; launches {sd.engine.stats['step_ops']} + {sd.engine2.stats['step_ops']}")
+        assert l2 < F32_TOL and mx < F32_TOL, (tag, use_graph, l2, mx)
+        assert sd.engine.stats["fallback_nodes"] == [] and sd.engine2.stats["fallback_nodes"] == []
+        outs.append(x1)
+    assert torch.equal(outs[0], outs[1])
+    assert S.rel_err(outs[0], gold[f"{tag}_x1_without_sag"])[0] > 5e-3
+    if tag == "control":
+        sd = CompiledSDXL(unet, num_inference_steps=CFG["num_steps"], condition_scale=CFG["condition_scale"], use_graph=False)
+        sd.set_inputs(inp["x"], **emb, conditions={"canny": torch.cat([kw["conditions"]["canny"]] * 2)})
+        with pytest.raises(RuntimeError):
+            sd.step(CFG["step"])
+
+
 @pytest.mark.parametrize("tag", ["plain", "ip"])
 def test_self_attention_guidance_on_the_engine(tag):
     """Self-Attention Guidance (self_attention_guidance.py:22-105, xl/model.py:164-250) on the compiled

@@ -11,6 +11,7 @@ import torch
 import refiners_amd
 from refiners_amd import native, synth
 from refiners_amd.engine.compiled import CompiledUNet
+from refiners_amd.engine.packing import launches
 from refiners_amd.engine.unet_lowering import UNetIO, UNetLowering
 from refiners_amd.fluxion.tree import tree_epoch
 from refiners_amd.latent_diffusion.sd1 import SD1UNet
@@ -37,7 +38,7 @@ def test_library_exports_every_symbol_of_the_header():
     assert lib.mi355x_abi_version() == 5
 
 
-def _dry(unet, B, H, W, dtype, tokens, pooled=True, conditions=()):
+def _dry(unet, B, H, W, dtype, tokens, pooled=True, conditions=(), condition_rows=None):
     dev = torch.device("meta")
     io = UNetIO(x=torch.empty(B, 4, H, W, device=dev, dtype=dtype), timestep=torch.empty(B, device=dev), out=torch.empty(B, 4, H, W, device=dev, dtype=dtype))
     if pooled:
@@ -46,7 +47,7 @@ def _dry(unet, B, H, W, dtype, tokens, pooled=True, conditions=()):
     for ck, (L, width) in tokens.items():
         io.tokens[ck] = (torch.zeros(B * ((L + 63) // 64 * 64), width, device=dev, dtype=dtype), L)
     for name in conditions:
-        io.conditions[name] = torch.empty(B, 3, 8 * H, 8 * W, device=dev, dtype=dtype)
+        io.conditions[name] = torch.empty(condition_rows or B, 3, 8 * H, 8 * W, device=dev, dtype=dtype)
     low = UNetLowering(dev, dtype)
     low.lower(unet, io)
     return low
@@ -74,6 +75,21 @@ def test_every_golden_tree_lowers_without_fallback(case, dtype):
         assert low.stats["lora_sites"] == 722 and low.stats["ip_sites"] == 70
     if case == "sdxl_bare":
         assert len(low.step) < 1000  # the reference issues ~2 700 module calls for the same work
+
+
+def test_one_control_picture_for_the_whole_batch_costs_no_step_launch():
+    """A batch-1 control picture (what the reference's Sum broadcasts, and the only form its Self-Attention Guidance pass can take) is encoded
+    once and repeated per prompt in the PROLOGUE: the step program is the one of a 2n-row picture."""
+    cfg = S.CASES["sdxl_control"]
+    progs = []
+    for rows in (None, 1):
+        unet = SDXLUNet(4, device="meta", dtype=torch.bfloat16)
+        specs = S.build_specs(cfg, S.key_shapes("sdxl"))
+        synth.apply_adapters(unet, refiners_amd.namespace(), device="meta", dtype=torch.bfloat16, **specs)
+        progs.append(_dry(unet, 2, *cfg["latent_hw"], torch.bfloat16, {("cross_attention_block", "clip_text_embedding"): (77, 2048)},
+                          conditions=[f"control_lora_{c['name']}" for c in specs["control"]], condition_rows=rows))
+    assert [e[2] for e in progs[0].step] == [e[2] for e in progs[1].step]
+    assert launches(progs[1].prologue) == launches(progs[0].prologue) + 2  # the two row copies
 
 
 def test_merged_lora_mode_adds_no_step_launch():

@@ -143,6 +143,13 @@ def pmc_families(db: str, program: list[dict] | None = None) -> dict:
     for did, name, start, counter, val in con.execute("select dispatch_id, name, min(start), counter_name, sum(counter_value) from pmc_events group by dispatch_id, counter_name"):
         d = per.setdefault(did, {"name": name, "start": start, "c": {}})
         d["c"][counter] = val  # (one row per XCD instance of a dispatch: summed)
+    try:  # the dispatch's own duration from the kernel trace of the same run (joined on the start timestamp): a pseudo counter
+        durs = {s: d for _, s, d in kernel_rows(db)}
+        for d in per.values():
+            if d["start"] in durs:
+                d["c"]["DURATION_NS"] = float(durs[d["start"]])
+    except Exception as exc:  # noqa: BLE001
+        print("  no durations:", exc)
     rows = sorted(((d["name"], d["start"], dict(d["c"], _name=d["name"])) for d in per.values()), key=lambda r: r[1])
     fams: dict = {}
     classes: dict = {}
@@ -185,6 +192,7 @@ def main() -> None:
     ap.add_argument("--tag", required=True)
     ap.add_argument("--workload", default="lora_ip")
     ap.add_argument("--skip-pmc", action="store_true")
+    ap.add_argument("--passes", default="fetch,write,mfma,sq", help="which PMC passes to run (a pass the profiler crashed in can be repeated alone)")
     args = ap.parse_args()
     OUT.mkdir(exist_ok=True)
     tag = args.tag
@@ -209,10 +217,14 @@ def main() -> None:
     got_cls: dict[str, dict] = {}
     scope = None
     program = json.loads(prog_path.read_text()) if prog_path.exists() else None
+    passes = {k: v for k, v in passes.items() if k in args.passes.split(",")}
     for name, counters in passes.items():
         rc = run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", str(prof / name), "--", *bench, "--steps", "2", "--warmup", "1"], prof / f"{name}.log")
         db = find_db(prof / name)
         print("pmc pass", name, "rc", rc, "db", db)
+        if rc != 0:  # keep what the profiler said: the raw logs stay on the box
+            tail = [ln for ln in (prof / f"{name}.log").read_text(errors="replace").splitlines() if "amdgpu.ids" not in ln][-40:]
+            (OUT / f"{tag}_pmc_{name}_failed.log").write_text("\n".join(tail) + "\n")
         if db:
             try:
                 r = pmc_families(db, program)
@@ -263,6 +275,7 @@ def main() -> None:
             cal = {"launch": "4096^3 bf16, 128x128 tile", "mfma_instructions": n_mfma, "avg_duration_us": dur / 1e3, "tflops": 2 * 4096 ** 3 / (dur * 1e-9) / 1e12,
                    "SQ_VALU_MFMA_BUSY_CYCLES_over_GRBM_GUI_ACTIVE": busy / gui}
             cal["mfma_util_by_construction"] = cal["tflops"] / 2500.0  # known MFMA count, known duration
+            cal["SQ_VALU_MFMA_BUSY_CYCLES_per_ns"] = busy / dur
             cal["note"] = ("pmc_events holds one row per XCD instance of a dispatch and GRBM_GUI_ACTIVE does not tick at the shader clock on this profiler build: "
                            "only the RATIO of the two counters is used, anchored on this launch")
             print("mfma counter calibration:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cal.items()})
@@ -280,12 +293,22 @@ def main() -> None:
                     row["mfma_util"] = cal["mfma_util_by_construction"] * row["busy_over_gui_active"] / cal["SQ_VALU_MFMA_BUSY_CYCLES_over_GRBM_GUI_ACTIVE"]
             if busy and sq:
                 row["mfma_busy_over_sq_busy"] = busy / sq
+            ns = cs.get("DURATION_NS", {}).get("sum")
+            if busy and ns and cal:
+                # the same anchoring against the dispatches' OWN durations: GRBM_GUI_ACTIVE also ticks through the profiler's per-dispatch counter
+                # start / stop (about 7-15 us per dispatch here), which dilutes 20-40 us launches far more than the 132 us calibration launch
+                row["DURATION_NS"] = ns
+                row["mfma_util_by_duration"] = cal["mfma_util_by_construction"] * (busy / ns) / cal["SQ_VALU_MFMA_BUSY_CYCLES_per_ns"]
             fams[f] = row
         cls = {}
         for k, cs in got_cls.get("mfma", {}).items():  # per shape class: the same anchored ratio
             busy, gui = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("sum"), cs.get("GRBM_GUI_ACTIVE", {}).get("sum")
             if busy and gui and cal:
                 cls[k] = {"launches": cs["GRBM_GUI_ACTIVE"]["launches"], "mfma_util": cal["mfma_util_by_construction"] * (busy / gui) / cal["SQ_VALU_MFMA_BUSY_CYCLES_over_GRBM_GUI_ACTIVE"]}
+                ns = cs.get("DURATION_NS", {}).get("sum")
+                if ns:
+                    cls[k]["avg_us_under_pmc"] = ns / 1e3 / max(cs["GRBM_GUI_ACTIVE"]["launches"], 1)
+                    cls[k]["mfma_util_by_duration"] = cal["mfma_util_by_construction"] * (busy / ns) / cal["SQ_VALU_MFMA_BUSY_CYCLES_per_ns"]
         (OUT / f"{tag}_pmc_mfma.json").write_text(json.dumps({"how": how, "scope": scope, "classes": cls, "note": "mfma_util = (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the family) / (the same ratio of the calibration launch) x the calibration launch's known utilisation", "calibration": cal, "families": fams}, indent=1))
         print({f: {k: (round(v, 4) if isinstance(v, float) and v < 10 else v) for k, v in r.items()} for f, r in fams.items()})
     if "sq" in got:
