@@ -91,9 +91,15 @@ def pmc_mfma_util(family: str):
         f = sorted((ROOT / "profiles").glob("r*_pmc_mfma.json"))[-1]
         doc = json.loads(f.read_text())
         fam = doc["families"][family]
-        return {"mfma_util": round(fam["mfma_util"], 4), "SQ_VALU_MFMA_BUSY_CYCLES": fam["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": fam["GRBM_GUI_ACTIVE"],
-                "definition": "fraction of GPU-active time with the matrix pipes busy: counter ratio anchored on a calibration launch of known MFMA count (see the file)",
-                "scope": doc.get("scope", "whole process"), "source": f"profiles/{f.name}"}
+        out = {"mfma_util": round(fam.get("mfma_util_by_duration", fam["mfma_util"]), 4), "SQ_VALU_MFMA_BUSY_CYCLES": fam["SQ_VALU_MFMA_BUSY_CYCLES"],
+               "definition": "fraction of the family's kernel time with the matrix pipes busy: SQ_VALU_MFMA_BUSY_CYCLES per ns of dispatch duration, anchored on a "
+                             "calibration launch of known MFMA count and duration (see the file)",
+               "scope": doc.get("scope", "whole process"), "source": f"profiles/{f.name}"}
+        if "mfma_util_by_duration" in fam:
+            # the round-2 definition (busy / GRBM_GUI_ACTIVE): GUI-active also ticks through the profiler's per-dispatch counter start / stop,
+            # which dilutes 20-40 us launches
+            out["mfma_util_over_gui_active"] = round(fam["mfma_util"], 4)
+        return out
     except Exception:  # noqa: BLE001 -- no committed pass
         return None
 
@@ -278,7 +284,7 @@ def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict
         pm = json.loads(sorted((ROOT / "profiles").glob("r*_pmc_mfma.json"))[-1].read_text()).get("classes", {})
         for c in top_classes:
             if c["class"] in pm:
-                c["mfma_util_pmc"] = round(pm[c["class"]]["mfma_util"], 4)
+                c["mfma_util_pmc"] = round(pm[c["class"]].get("mfma_util_by_duration", pm[c["class"]]["mfma_util"]), 4)
     except Exception:  # noqa: BLE001 -- no committed pass
         pass
     dom = max((n for n in fam if fam[n]["tflop"]), key=lambda n: fam[n]["ms"])

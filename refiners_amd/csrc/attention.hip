@@ -8,8 +8,10 @@
 //     15 local ops + 2 cross-group shuffles, the rescale factor is a per-lane scalar, and P^T is already in the
 //     register layout the second MFMA wants as its B operand (no LDS round trip, no permutes);
 //   * V arrives TRANSPOSED from the projection GEMM (the GEMM is run with its operands swapped, which costs
-//     nothing), so the V^T tile is K-contiguous like every other operand: plain swizzled LDS rows, 8/16-byte
-//     conflict-free reads, identical code for bf16 and f32 (no ds_read_tr needed);
+//     nothing), so the V^T tile is K-contiguous like every other operand: plain swizzled LDS rows, 16-byte
+//     conflict-free reads, identical code for bf16 and f32 (no ds_read_tr needed); in bf16 the K tile's rows are loaded
+//     in a permuted key order (k_row_key) so that the eight P^T values a lane holds for one MFMA step belong to eight
+//     CONSECUTIVE keys, i.e. to one 16-byte chunk of a V^T row;
 //   * the V^T tile rows are loaded in the permuted order R = 16j + 4a + b <-> d = 16a + 4j + b, so each lane ends up
 //     with 16 CONSECUTIVE head-dim outputs per query: the O store is 32/64 contiguous bytes per lane;
 //   * K and V^T tiles (64 keys) go global -> registers -> LDS (double buffered, one barrier per tile) with the loads of the next TWO
@@ -78,6 +80,14 @@ template <bool PL> MI_DEV float group_sum(float x) {
     }
 }
 
+// Key held by LDS row `row` of a 64-key K tile (bf16): LDS row 16 t + r16 holds key 32 (t >> 1) + 8 (r16 >> 2) + 4 (t & 1) + (r16 & 3).
+// S^T block t then gives lane group g the keys 8 g + 4 (t & 1) + {0..3} of its 32-key half, so the P^T fragment a lane assembles from
+// blocks 2 s, 2 s + 1 covers EIGHT CONSECUTIVE keys 32 s + 8 g .. + 7 and the matching V^T fragment is ONE 16-byte chunk (4 s + g) of the
+// row -- read with the GEMM's conflict-free ds_read_b128 pattern.  With keys in natural order the fragment was two 8-byte halves two chunks
+// apart: ds_read_b64 pairs that ran at a 2-way bank conflict (a third of the kernel's LDS cycles, profiles/r03_q_pmc_sq_by_kernel.json).
+// The permutation lives in the loader's SOURCE row (and in the tail mask); LDS addressing of the K reads is unchanged.
+MI_DEV constexpr int k_row_key(int row) { return (row & 32) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3); }
+
 template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ, int RD = 2, int OPT = 0, int ABL = 0, int KVS = 1>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 2 : 1))) void attn_kernel(const AttnP p) {
     // RD = register sets of the register-staged loader = K/V tiles in flight (1 or 2)
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
 #pragma unroll
     for (int it = 0; it < LI; ++it) {
         const int q = it * NTHR + tid, row = q / CPR, pch = q % CPR;
-        lrow[it] = row;
+        lrow[it] = IS_BF16 ? k_row_key(row) : row;  // the KEY this LDS row of the K tile holds
         lcoff[it] = (pch ^ swz<ROWB>(row)) << 4;
         const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
         vrowd[it] = 16 * a + 4 * j + bb;  // head-dim index stored in LDS row `row` of the V^T tile
@@ -293,12 +303,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int row = 16 * i + c16;
-                        const int chunk = 4 * s2 + (g >> 1);
-                        const int sw = swz<ROWB>(row);
-                        const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
-                        const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
-                        vpre[s2][i] = frag_t{va[0], va[1], vb[0], vb[1]};
+                        vpre[s2][i] = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * s2 + g));
                     }
             }
             // ---- mask the tail tile ----
@@ -308,7 +313,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 for (int t = 0; t < TT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (kv0 + 16 * (kg * TT + t) + 4 * g + r >= Lk) {
+                        const int krow = 16 * (kg * TT + t) + 4 * g + r;
+                        if (kv0 + (IS_BF16 ? k_row_key(krow) : krow) >= Lk) {
 #pragma unroll
                             for (int jq = 0; jq < NJQ; ++jq) st[t][jq][r] = -INFINITY;
                         }
@@ -377,12 +383,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
                         if constexpr (VPRE) {
                             vf = vpre[s2l][i];
                         } else {
-                            const int row = 16 * i + c16;
-                            const int chunk = 4 * s2 + (g >> 1);
-                            const int sw = swz<ROWB>(row);
-                            const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
-                            const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
-                            vf = frag_t{va[0], va[1], vb[0], vb[1]};
+                            vf = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * s2 + g));
                         }
 #pragma unroll
                         for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, pb[jq]);
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 for (int it = 0; it < LI; ++it) {
                     const int q = it * NTHR + tid, row = q / CPR, pch = q % CPR;
                     const int coff = (pch ^ swz<ROWB>(row)) << 4;
-                    int kr_ = kv0 + row;
+                    int kr_ = kv0 + (IS_BF16 ? k_row_key(row) : row);  // see k_row_key
                     kr_ = kr_ < kv.Lk ? kr_ : kv.Lk - 1;
                     kr[sl][it] = *reinterpret_cast<const frag_t*>(kbase + (int64_t)kr_ * kv.ldkb + coff);
                     const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
@@ -619,7 +620,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (kv0 + 16 * t + 4 * g + r >= Lk) {
+                        const int krow = 16 * t + 4 * g + r;
+                        if (kv0 + (IS_BF16 ? k_row_key(krow) : krow) >= Lk) {
 #pragma unroll
                             for (int jq = 0; jq < NJQ; ++jq) st[t][jq][r] = -INFINITY;
                         }
@@ -668,12 +670,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int row = 16 * i + c16;
-                        const int chunk = 4 * s2 + (g >> 1);
-                        const int sw = swz<ROWB>(row);
-                        const half_frag_t va = lds_read_half(vs, row * ROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
-                        const half_frag_t vb = lds_read_half(vs, row * ROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
-                        const frag_t vf = frag_t{va[0], va[1], vb[0], vb[1]};
+                        const frag_t vf = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * s2 + g));
 #pragma unroll
                         for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, pb[jq]);
                     }

@@ -64,6 +64,7 @@ class Lowering:
         self.es = 4 if dtype == torch.float32 else 2
         self.kblk = 128 // self.es  # K granularity of the GEMM kernel (one 128-byte block)
         self.cache = cache or PackCache()
+        self.cache.build_device = device
         # two arenas: prologue results must survive across steps, so they never share storage with step temporaries
         self.step_pool = Pool(device, dtype)
         self.prologue_pool = Pool(device, dtype)

@@ -190,6 +190,7 @@ class PackCache:
         self._adopt: Optional[list] = None    # receiver side: the source's manifest
         self._cursor = 0
         self.made = 0                         # make() calls that really ran here (receivers: aliases only)
+        self.build_device: Optional[torch.device] = None  # where a receiver allocates (the Lowering that owns the cache sets it)
 
     @staticmethod
     def ident(*tensors: Optional[Tensor]) -> tuple:
@@ -208,7 +209,7 @@ class PackCache:
                 v = make()
                 self.made += 1
             else:
-                v = _build(spec[1], _key_device(key))
+                v = _build(spec[1], self.build_device or _key_device(key))
         else:
             v = make()
             self.made += 1
@@ -231,7 +232,10 @@ class PackCache:
             v = self.store[key]
             src = {s.t.data_ptr() for s in key if isinstance(s, _Src)}
             leaves = _leaves(v)
-            if not leaves or any(t.data_ptr() in src for t in leaves):
+            if not leaves or not src or all(t.data_ptr() in src for t in leaves):
+                # nothing to move: no tensors inside, a pure function of the key (index tables: no source tensor in the key), or the source
+                # tensors' own storage -- every rank makes these itself.  (A value that mixes views and fresh tensors travels whole: its fresh
+                # part may have been computed from other packs, which a receiver does not hold yet while it lowers.)
                 out.append(("alias",))
             else:
                 out.append(("recv", _describe(v)))
@@ -270,7 +274,7 @@ def _leaves(v: Any) -> list[Tensor]:
 
 def _describe(v: Any) -> Any:
     if isinstance(v, Tensor):
-        return ("T", tuple(v.shape), str(v.dtype).replace("torch.", ""))
+        return ("T", tuple(v.shape), str(v.dtype).replace("torch.", ""), v.device.type)
     if isinstance(v, native.KBlocked):
         return ("KB", v.N, v.K, _describe(v.t))
     if isinstance(v, LoraPack):
@@ -286,7 +290,7 @@ def _describe(v: Any) -> Any:
 def _build(spec: Any, device: torch.device) -> Any:
     kind = spec[0]
     if kind == "T":
-        return torch.empty(spec[1], dtype=getattr(torch, spec[2]), device=device)
+        return torch.empty(spec[1], dtype=getattr(torch, spec[2]), device=device if spec[3] == device.type else torch.device(spec[3]))
     if kind == "KB":
         return native.KBlocked(_build(spec[3], device), _adopt=(spec[1], spec[2]))
     if kind == "LP":

@@ -219,7 +219,11 @@ def main() -> None:
     program = json.loads(prog_path.read_text()) if prog_path.exists() else None
     passes = {k: v for k, v in passes.items() if k in args.passes.split(",")}
     for name, counters in passes.items():
-        rc = run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", str(prof / name), "--", *bench, "--steps", "2", "--warmup", "1"], prof / f"{name}.log")
+        for attempt in range(3):  # the profiler's TCC / SQ collection dies with SIGSEGV at the first dispatch now and then on this pool: try again
+            rc = run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", str(prof / name), "--", *bench, "--steps", "2", "--warmup", "1"], prof / f"{name}.log")
+            if rc == 0:
+                break
+            print("pmc pass", name, "attempt", attempt + 1, "rc", rc)
         db = find_db(prof / name)
         print("pmc pass", name, "rc", rc, "db", db)
         if rc != 0:  # keep what the profiler said: the raw logs stay on the box
