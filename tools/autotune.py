@@ -35,12 +35,14 @@ def step_ms(ops, iters: int = 4, reps: int = 3) -> float:
 
 def candidates(a) -> list[tuple[int, int]]:
     out = []
-    for tile in (1, 2, 3, 4, 5, 6, 7, 8):
+    for tile in (1, 2, 3, 4, 6):  # 128x128, 128x64, 64x128, 64x64 (4 waves); 6 = 128x128 with two K groups (8 waves)
         if a.geglu == 1 and tile in (2, 4):
             continue
-        if a.lora_b and tile in (5, 6, 7, 8):  # in-launch LoRA exists for the 4-wave tiles only (the library would fall back to 128 x 128)
+        if a.lora_b and tile == 6:  # in-launch LoRA exists for the 4-wave tiles only, with two LDS stages
             continue
-        for st in ((2,) if tile == 6 else (3,) if tile in (7, 8) else (2, 3) if tile == 5 else (2, 3, 4)):
+        if a.lora_b and a.lora_r > 64 and tile in (2, 4):  # a stacked rank above 64 needs the 128-column tiles
+            continue
+        for st in ((2,) if tile == 6 or a.lora_b else (2, 3, 4)):
             out.append((tile, st))
     return out
 
