@@ -172,7 +172,7 @@ def stage_inputs(pipe, specs: dict, n_img: int, seed: int, dev: torch.device) ->
 def replica_check(pipe, specs: dict, n_img: int, dev: torch.device) -> dict:
     """N > 1 only, after the timed region: every rank runs ONE step on the SAME inputs and the outputs are compared across ranks -- the
     replicas hold broadcast weights and broadcast packed weights (K-blocked / merged / folded on rank 0 only), so a hand-over bug shows up
-    here as a rank whose step differs.  Not bit-exact by design (split-K partial sums land in arrival order): 1e-3 relative."""
+    here as a rank whose step differs.  The kernels are deterministic (fixed-order split-K), so equal GPUs give equal bits; the bar is 1e-3 relative."""
     stage_inputs(pipe, specs, n_img, 100, dev)
     pipe.step(0)
     x = pipe.x.double()
@@ -183,9 +183,10 @@ def replica_check(pipe, specs: dict, n_img: int, dev: torch.device) -> dict:
     got = parallel.all_gather(mine)
     ref = got[0]
     dev_max = max(float(((g - ref).abs() / ref.abs().clamp_min(1e-30)).max()) for g in got)
-    if not dev_max < 1e-3:
-        raise RuntimeError(f"replicas disagree on the same inputs: checksums {[g.tolist() for g in got]}")
-    return {"max_rel_checksum_deviation": dev_max, "ranks": world}
+    ok = bool(dev_max < 1e-3)
+    if not ok:  # loud, but after the timed region and without losing the measured line: the JSON carries ok = false and the checksums
+        print(f"bench.py: REPLICAS DISAGREE on the same inputs: checksums {[g.tolist() for g in got]}", file=sys.stderr, flush=True)
+    return {"ok": ok, "max_rel_checksum_deviation": dev_max, "ranks": world, **({} if ok else {"checksums": [g.tolist() for g in got]})}
 
 
 def build_pipeline(workload: str, n_img: int, rank: int, dev: torch.device, dtype: torch.dtype, lora_mode: str, use_graph: bool, broadcast: bool = True):
