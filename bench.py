@@ -18,6 +18,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import socket
 import sys
 import time
@@ -84,7 +85,7 @@ def respawn_under_torchrun(n: int) -> None:
     os.execv(sys.executable, cmd)
 
 
-def pmc_mfma_util(family: str):
+def pmc_mfma_util(family: str, family_tflop_per_step: float = 0.0):
     """MFMA utilisation of a kernel family from the latest committed counter pass (tools/profile_round.py: a separate
     `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...` run of this same command)."""
     try:
@@ -95,6 +96,10 @@ def pmc_mfma_util(family: str):
                "definition": "fraction of the family's kernel time with the matrix pipes busy: SQ_VALU_MFMA_BUSY_CYCLES per ns of dispatch duration, anchored on a "
                              "calibration launch of known MFMA count and duration (see the file)",
                "scope": doc.get("scope", "whole process"), "source": f"profiles/{f.name}"}
+        reps = re.search(r"(\d+) full replay", doc.get("scope", ""))
+        if reps and fam.get("DURATION_NS") and family_tflop_per_step:
+            # boxes differ by several per cent: the FLOP-based fraction of THE SAME profiled run is what mfma_util has to agree with
+            out["flop_frac_of_that_run"] = round(family_tflop_per_step * int(reps.group(1)) / (fam["DURATION_NS"] * 1e-9) / PEAK_BF16_TFLOPS, 4)
         if "mfma_util_by_duration" in fam:
             # the round-2 definition (busy / GRBM_GUI_ACTIVE): GUI-active also ticks through the profiler's per-dispatch counter start / stop,
             # which dilutes 20-40 us launches
@@ -294,7 +299,7 @@ def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict
     return {
         "bound": "mfma", "kernel": dom, "launches_per_step": fam[dom]["launches"], "avg_launch_us": fam[dom]["avg_us"],
         "achieved": fam[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam[dom]["tflops"] / PEAK_BF16_TFLOPS, 4),
-        "traffic": pmc_traffic(dom), "mfma_util": pmc_mfma_util(dom),
+        "traffic": pmc_traffic(dom), "mfma_util": pmc_mfma_util(dom, fam[dom]["tflop"]),
         "step": {"algorithmic_tflop": algo, "executed_tflop": round(executed_tflop, 3), "achieved": round(algo / (ms_per_step * 1e-3), 1),
                  "frac": round(algo / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)},
         "families": fam, "top_classes": top_classes,
