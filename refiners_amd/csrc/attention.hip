@@ -80,14 +80,6 @@ template <bool PL> MI_DEV float group_sum(float x) {
     }
 }
 
-// Key held by LDS row `row` of a 64-key K tile (bf16): LDS row 16 t + r16 holds key 32 (t >> 1) + 8 (r16 >> 2) + 4 (t & 1) + (r16 & 3).
-// S^T block t then gives lane group g the keys 8 g + 4 (t & 1) + {0..3} of its 32-key half, so the P^T fragment a lane assembles from
-// blocks 2 s, 2 s + 1 covers EIGHT CONSECUTIVE keys 32 s + 8 g .. + 7 and the matching V^T fragment is ONE 16-byte chunk (4 s + g) of the
-// row -- read with the GEMM's conflict-free ds_read_b128 pattern.  With keys in natural order the fragment was two 8-byte halves two chunks
-// apart: ds_read_b64 pairs that ran at a 2-way bank conflict (a third of the kernel's LDS cycles, profiles/r03_q_pmc_sq_by_kernel.json).
-// The permutation lives in the loader's SOURCE row (and in the tail mask); LDS addressing of the K reads is unchanged.
-MI_DEV constexpr int k_row_key(int row) { return (row & 32) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3); }
-
 template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ, int RD = 2, int OPT = 0, int ABL = 0, int KVS = 1>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 2 : 1))) void attn_kernel(const AttnP p) {
     // RD = register sets of the register-staged loader = K/V tiles in flight (1 or 2)

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
 
     auto issue = [&](int tile) {
         const int kv0 = tile * BKV;
-        int key = kv0 + krow;
+        int key = kv0 + (IS_BF16 ? k_row_key(krow) : krow);  // bf16: permuted key order (k_row_key, common.cuh)
         key = key < p.Lk ? key : p.Lk - 1;
         const char* kp = kbase + (int64_t)key * p.ldkb;
 #pragma unroll
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kv0 + 16 * t + 4 * g + r;
+                    const int key = kv0 + (IS_BF16 ? k_row_key(16 * t + 4 * g + r) : 16 * t + 4 * g + r);
 #pragma unroll
                     for (int jq = 0; jq < 2; ++jq) {
                         const int qi = q0 + 16 * jq + c16;
@@ -208,12 +208,7 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
                 }
 #pragma unroll
                 for (int i = 0; i < ND; ++i) {
-                    const int row = 16 * i + c16;
-                    const int chunk = 4 * s2 + (g >> 1);
-                    const int sw = swz<VROWB>(row);
-                    const half_frag_t va = lds_read_half(vs, row * VROWB + ((chunk ^ sw) << 4) + (g & 1) * 8);
-                    const half_frag_t vb = lds_read_half(vs, row * VROWB + (((chunk + 2) ^ sw) << 4) + (g & 1) * 8);
-                    const frag_t vf = frag_t{va[0], va[1], vb[0], vb[1]};
+                    const frag_t vf = lds_read_frag(vs, tile_off<VROWB>(16 * i + c16, 4 * s2 + g));  // one chunk = the lane's 8 consecutive keys
                     mma_step<T>(o[i][0], vf, pb[0]);
                     mma_step<T>(o[i][1], vf, pb[1]);
                 }

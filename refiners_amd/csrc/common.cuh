@@ -25,7 +25,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) int frag_t;   // one 16-byte operand chunk
-typedef __attribute__((ext_vector_type(2))) int half_frag_t;  // 8 bytes
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -72,11 +71,17 @@ template <int ROWB> MI_DEV int tile_off(int row, int chunk) {  // byte offset of
     return row * ROWB + ((chunk ^ swz<ROWB>(row)) << 4);
 }
 
+// Key held by LDS row `row` of a 64-key K tile (bf16): LDS row 16 t + r16 holds key 32 (t >> 1) + 8 (r16 >> 2) + 4 (t & 1) + (r16 & 3).
+// S^T block t then gives lane group g the keys 8 g + 4 (t & 1) + {0..3} of its 32-key half, so the P^T fragment a lane assembles from
+// blocks 2 s, 2 s + 1 covers EIGHT CONSECUTIVE keys 32 s + 8 g .. + 7 and the matching V^T fragment is ONE 16-byte chunk (4 s + g) of the
+// row -- read with the GEMM's conflict-free ds_read_b128 pattern.  With keys in natural order the fragment was two 8-byte halves two chunks
+// apart: ds_read_b64 pairs that ran at a 2-way bank conflict (a third of the kernel's LDS cycles, profiles/r03_q_pmc_sq_by_kernel.json).
+// The permutation lives in the loader's SOURCE row (and in the tail / causal masks); LDS addressing of the K reads is unchanged.
+// Used by attn_kernel, attn_short_kernel (attention.hip) and attn_general_kernel (attention_general.hip).
+MI_DEV constexpr int k_row_key(int row) { return (row & 32) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3); }
+
 MI_DEV frag_t lds_read_frag(const char* lds, int byte_off) {
     return *reinterpret_cast<const frag_t*>(lds + byte_off);
-}
-MI_DEV half_frag_t lds_read_half(const char* lds, int byte_off) {
-    return *reinterpret_cast<const half_frag_t*>(lds + byte_off);
 }
 
 // Asynchronous 16-byte-per-lane global -> LDS copy.  `lds_wave_base` must be wave-uniform: lane i lands at
