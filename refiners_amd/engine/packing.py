@@ -241,8 +241,8 @@ class PackCache:
                 out.append(("recv", _describe(v)))
         return out
 
-    def adopt(self, manifest: list) -> None:
-        """Receiver side, BEFORE lowering: answer misses from the source's manifest."""
+    def adopt(self, manifest: Optional[list]) -> None:
+        """Receiver side, BEFORE lowering: answer misses from the source's manifest (None: leave adopt mode)."""
         self._adopt, self._cursor = manifest, 0
 
     def leaves(self, manifest: list) -> list[Tensor]:

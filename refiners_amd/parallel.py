@@ -171,6 +171,7 @@ def broadcast_packs(lower: Any, cache: Any, src: int = 0, bucket_bytes: int = 51
             lower()
     except BaseException as e:  # noqa: BLE001
         err = e
+        cache.adopt(None)  # back to normal: a later lowering on this rank packs for itself
     propagate_failure(err, "broadcast_packs: lowering on a receiving rank")
     return broadcast_tensors(cache.leaves(manifest), src=src, bucket_bytes=bucket_bytes, repoint=False)
 
