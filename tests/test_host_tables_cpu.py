@@ -1,0 +1,43 @@
+"""Host-side tables that decide what runs / what is reported: the measured tile table's fallback rules (refiners_amd/engine/tuning.py) and
+which committed counter pass bench.py quotes beside its live roofline (bench.pmc_mfma_file)."""
+import json
+
+import bench
+from refiners_amd.engine import tuning
+
+
+def test_tile_table_fallbacks(monkeypatch):
+    monkeypatch.setattr(tuning, "_table", {"gemm:bf16:8x8x8:s1:": (6, 2), "gemm:bf16:8x8x8:s1:ln": (3, 4), "gemm:bf16:9x9x9:s1:lora": (2, 2)})
+    monkeypatch.setattr(tuning, "enabled", True)
+    assert tuning.lookup("gemm:bf16:8x8x8:s1:") == (6, 2)
+    assert tuning.lookup("gemm:bf16:1x1x1:s1:", stages=3) == (0, 3)  # unknown shape: the library heuristic, the caller's stage hint kept
+    # a LoRA launch without its own entry takes the un-adapted launch's tile, restricted to what the LoRA kernels exist for
+    assert tuning.lookup("gemm:bf16:8x8x8:s1:lora") == (1, 2)    # 8-wave tile -> 128x128, two stages
+    assert tuning.lookup("gemm:bf16:8x8x8:s1:lnlora") == (3, 2)  # deeper ring -> two stages
+    assert tuning.lookup("gemm:bf16:9x9x9:s1:lora") == (2, 2)    # its own measured entry wins
+    monkeypatch.setattr(tuning, "enabled", False)
+    assert tuning.lookup("gemm:bf16:8x8x8:s1:") == (0, 0)
+
+
+def test_the_shipped_table_only_names_tiles_the_library_has():
+    doc = json.loads(tuning.TABLE_PATH.read_text())
+    for sig, (tile, stages) in doc["choices"].items():
+        assert tile in (0, 1, 2, 3, 4, 6) and stages in (0, 2, 3, 4), (sig, tile, stages)
+        if sig.endswith("lora"):
+            assert tile in (1, 2, 3, 4) and stages == 2, sig
+
+
+def test_bench_quotes_the_least_perturbed_counter_pass(tmp_path, monkeypatch):
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    fam = lambda ns, util: {"families": {"mi355x_gemm": {"mfma_util": util, "mfma_util_by_duration": util + 0.05, "SQ_VALU_MFMA_BUSY_CYCLES": 1.0, "DURATION_NS": ns}},  # noqa: E731
+                            "scope": "step program only: 3 full replay(s) of the 686 recorded launches", "classes": {}}
+    (prof / "r02_s_pmc_mfma.json").write_text(json.dumps(fam(1.0e6, 0.9)))   # an older round never wins
+    (prof / "r03_q_pmc_mfma.json").write_text(json.dumps(fam(5.0e7, 0.15)))
+    (prof / "r03_r2_pmc_mfma.json").write_text(json.dumps(fam(7.0e7, 0.11)))  # later by name, but a slower box
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    assert bench.pmc_mfma_file("mi355x_gemm").name == "r03_q_pmc_mfma.json"
+    got = bench.pmc_mfma_util("mi355x_gemm", family_tflop_per_step=8.0)
+    assert got["source"].endswith("r03_q_pmc_mfma.json") and got["mfma_util"] == 0.2 and got["mfma_util_over_gui_active"] == 0.15
+    assert abs(got["flop_frac_of_that_run"] - 8.0 * 3 / 5.0e-2 / bench.PEAK_BF16_TFLOPS) < 1e-4
+    assert bench.pmc_mfma_util("no_such_family") is None
