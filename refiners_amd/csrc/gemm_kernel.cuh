@@ -287,8 +287,17 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
     if (tid == 0) __hip_atomic_store(p.lora_flags + pgi * npb + tm, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Waves per SIMD the register allocation must leave room for.  Left to itself (launch bounds only) the compiler spreads the LoRA instantiations
+// over VGPRs AND AGPRs (128 x 128: 181 + 128, 128 x 64: 141 + 64, 64 x 64: 117 + 32) and they end up ONE wave per SIMD below the un-adapted
+// tile of the same size -- a producer workgroup then owns a whole CU while it waits on its loads.  With the un-adapted tile's occupancy as the
+// floor the same code fits into 237 / 168 / 117 VGPRs, no AGPR copies, no scratch (hipcc -Rpass-analysis=kernel-resource-usage).
+template <typename T, int BM, int BN, bool LORA> constexpr int gemm_min_waves() {
+    if (!LORA || sizeof(T) != 2) return 1;
+    return BM * BN == 128 * 128 ? 2 : BM * BN == 64 * 64 ? 4 : BM == 128 ? 3 : 2;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
-__global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_eu(1))) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_eu(gemm_min_waves<T, BM, BN, LORA>()))) void gemm_kernel(const GemmP p) {
     constexpr int NW = WM * WN;           // waves per K group
     constexpr int NTHR = NW * 64;         // threads per K group: the loader geometry
     constexpr int NTHR_ALL = NTHR * KG;   // threads per workgroup

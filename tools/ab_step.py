@@ -32,10 +32,11 @@ def main() -> None:
     ap.add_argument("--lora-mode", default="merged")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--lib", default=None, help="another build of libmi355x_refiners.so to run instead of the in-tree one (compile-time A/B across two processes)")
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    native.load()
+    native.load(args.lib)
     unet, specs, bare_sd, pipe0, _ = bench.build_pipeline(args.workload, args.images, 0, dev, torch.bfloat16, args.lora_mode, use_graph=True, broadcast=False)
     inputs, x0 = pipe0.inputs, pipe0.x.clone()
     del pipe0
