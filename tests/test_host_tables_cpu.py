@@ -41,3 +41,22 @@ def test_bench_quotes_the_least_perturbed_counter_pass(tmp_path, monkeypatch):
     assert got["source"].endswith("r03_q_pmc_mfma.json") and got["mfma_util"] == 0.2 and got["mfma_util_over_gui_active"] == 0.15
     assert abs(got["flop_frac_of_that_run"] - 8.0 * 3 / 5.0e-2 / bench.PEAK_BF16_TFLOPS) < 1e-4
     assert bench.pmc_mfma_util("no_such_family") is None
+
+
+def test_attention_key_order_puts_a_lanes_eight_keys_in_one_chunk():
+    """csrc/common.cuh: k_row_key -- the property the attention kernels rely on, checked on the expression itself (read from the source):
+    the S^T blocks 2s and 2s+1 hand lane group g the rows 4g..4g+3 of each; with the K tile's rows loaded in k_row_key order those eight
+    P^T values belong to the keys 32s + 8g .. + 7 IN ORDER, i.e. to the 16-byte chunk 4s + g of a bf16 V^T row, and the map is a bijection
+    of the tile's 64 keys (nothing is dropped or doubled, so the softmax sums do not change)."""
+    import re
+    from pathlib import Path
+
+    src = (Path(__file__).resolve().parent.parent / "refiners_amd" / "csrc" / "common.cuh").read_text()
+    expr = re.search(r"constexpr int k_row_key\(int row\) \{ return (.+?); \}", src).group(1)
+    key = lambda row: eval(expr, {"row": row})  # noqa: E731,S307 -- integer shifts / masks only: the C expression is valid Python
+    assert sorted(key(r) for r in range(64)) == list(range(64))
+    for s in range(2):
+        for g in range(4):
+            got = [key(16 * (2 * s) + 4 * g + r) for r in range(4)] + [key(16 * (2 * s + 1) + 4 * g + r) for r in range(4)]
+            assert got == list(range(32 * s + 8 * g, 32 * s + 8 * g + 8)), (s, g, got)
+            assert (got[0] * 2) // 16 == 4 * s + g  # byte offset of the first key in a bf16 row / 16 = the chunk the kernel reads
