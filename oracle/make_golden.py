@@ -3,6 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python oracle/make_golden.py            # ~10 min, needs ~25 GB RAM
+    python oracle/make_golden.py --only sdxl_control2     # (re)generate the named cases only; the manifest keeps the others' entries
 Outputs (all small, committed):
     tests/golden/sdxl_unet_keys.json, sd1_unet_keys.json   state-dict key -> shape of the reference's bare models
     tests/golden/<case>.safetensors                         reference outputs for the cases in CASES
@@ -49,7 +50,10 @@ def reference_model(cls, shapes, seed):
 
 def main() -> None:
     torch.manual_seed(0)
+    only = sys.argv[sys.argv.index("--only") + 1 :] if "--only" in sys.argv else None
     manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "cases": {}}
+    if only and (GOLD / "manifest.json").exists():
+        manifest["cases"] = json.loads((GOLD / "manifest.json").read_text())["cases"]
     shapes = {}
     for name, cls in (("sdxl", SDXLUNet), ("sd1", SD1UNet)):
         shapes[name] = synth.model_shapes(cls(4, device="meta"))
@@ -57,6 +61,8 @@ def main() -> None:
     models = {}
     with torch.no_grad():
         for case, cfg in CASES.items():
+            if only and case not in only:
+                continue
             t0 = time.time()
             fam = cfg["family"]
             unet = reference_model(SDXLUNet if fam == "sdxl" else SD1UNet, shapes[fam], cfg["weight_seed"])

@@ -20,6 +20,10 @@ CASES: dict[str, dict[str, Any]] = {
     # config 4's adapter: ControlLora (with its own rank-8 LoRA on the copied encoder) at scale 0.9, non-square latent
     "sdxl_control": dict(family="sdxl", weight_seed=0, input_seed=3, images=1, latent_hw=(32, 24), num_steps=30, step=29, condition_scale=7.5,
                          adapters=["control:canny:0.9"]),
+    # two STACKED ControlLoras at 0.55 each, as the reference's own end-to-end test does (tests/e2e/test_diffusion.py:299-310,
+    # xl/control_lora.py:251-411): distinct names / contexts / scales / control pictures, the first with its own LoRAs, the second without
+    "sdxl_control2": dict(family="sdxl", weight_seed=0, input_seed=6, images=1, latent_hw=(24, 16), num_steps=30, step=7, condition_scale=6.0,
+                          adapters=["control:canny:0.55", "control:depth:0.45:nolora"]),
     # Conv2d LoRAs on ResidualBlock / Downsample / Upsample convolutions (reference tests/e2e/test_diffusion.py:1655-1663)
     "sdxl_conv_lora": dict(family="sdxl", weight_seed=0, input_seed=4, images=1, latent_hw=(16, 16), num_steps=50, step=0, condition_scale=5.0,
                            adapters=["convlora:c1:0.7"]),
@@ -64,8 +68,8 @@ def build_specs(cfg: Mapping[str, Any], shapes: Mapping[str, Sequence[int]]) -> 
         elif kind == "ip":
             ip = synth.ip_spec(shapes, scale=0.6, batch=batch, seed=seed)
         elif kind == "control":
-            own = synth.lora_spec(shapes, f"ctl_{rest[0]}", 1.0, rank=8, seed=seed + 1, targets=control_lora_targets(shapes))
-            control.append(synth.control_spec(rest[0], float(rest[1]), batch, cfg["latent_hw"], seed=seed, loras=[own]))
+            own = [] if "nolora" in rest[2:] else [synth.lora_spec(shapes, f"ctl_{rest[0]}", 1.0, rank=8, seed=seed + 1, targets=control_lora_targets(shapes))]
+            control.append(synth.control_spec(rest[0], float(rest[1]), batch, cfg["latent_hw"], seed=seed, loras=own))
     return {"loras": loras, "ip": ip, "control": control}
 
 

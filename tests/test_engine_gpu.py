@@ -170,7 +170,7 @@ def test_full_size_step_matches_oracle():
     assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
 
 
-@pytest.mark.parametrize("case", ["sdxl_lora_ip", "sdxl_conv_lora", "sdxl_control"])
+@pytest.mark.parametrize("case", ["sdxl_lora_ip", "sdxl_conv_lora", "sdxl_control", "sdxl_control2"])
 def test_merged_lora_mode_matches_reference(case):
     """lora_mode="merged": W' = W + sum s B A formed at lowering time; an adapted layer costs one launch.  Same parity bar,
     and scale changes after compilation still take effect (the merge is redone for the touched sites)."""

@@ -59,7 +59,7 @@ def _build(case):
     return cfg, unet, specs, inp
 
 
-@pytest.mark.parametrize("case", ["sdxl_bare", "sdxl_lora_ip", "sdxl_control", "sdxl_conv_lora"])
+@pytest.mark.parametrize("case", ["sdxl_bare", "sdxl_lora_ip", "sdxl_control", "sdxl_control2", "sdxl_conv_lora"])
 def test_compiled_unet_on_the_real_refiners_tree(gpu_device, case):
     _api()
     from refiners.foundationals.latent_diffusion.solvers import DDIM
