@@ -189,6 +189,7 @@ class PackCache:
         self.order: list[tuple] = []          # keys in creation order (what the manifest walks)
         self._adopt: Optional[list] = None    # receiver side: the source's manifest
         self._cursor = 0
+        self._mark = 0                        # len(order) when the current hand-over window opened (see mark())
         self.made = 0                         # make() calls that really ran here (receivers: aliases only)
         self.build_device: Optional[torch.device] = None  # where a receiver allocates (the Lowering that owns the cache sets it)
 
@@ -205,6 +206,9 @@ class PackCache:
             assert self._cursor < len(self._adopt), "the source rank lowered fewer packed weights than this rank asks for (different trees?)"
             spec = self._adopt[self._cursor]
             self._cursor += 1
+            assert spec[-1] == _key_desc(key), (
+                f"packed-weight hand-over out of step at entry {self._cursor - 1}: the source made {spec[-1]}, this rank asks for {_key_desc(key)} "
+                "(the two ranks did not lower the same tree from the same cache state)")
             if spec[0] == "alias":
                 v = make()
                 self.made += 1
@@ -221,14 +225,23 @@ class PackCache:
         for k in list(self.store):
             if k not in self.used:
                 del self.store[k]
+        self._mark = sum(1 for k in self.order[: self._mark] if k in self.store)  # the window keeps starting at the same surviving entry
         self.order = [k for k in self.order if k in self.store]
         self.used = set()
 
     # -- multi-GPU hand-over ----------------------------------------------------------------------------------------------------
+    # A hand-over covers a WINDOW of the cache: the entries created by one lowering.  Both sides call mark() right before that lowering
+    # (the receivers through adopt()), so entries left by earlier lowerings -- a first broadcast, a LoRA scale change, sweep() survivors -- are
+    # neither published nor consumed, and each manifest entry carries a rank-independent description of its key (tag, scalars, source shapes)
+    # that the receiver compares before it builds anything: a sequence that is out of step asserts instead of mis-assigning storage.
+    def mark(self) -> int:
+        self._mark = len(self.order)
+        return self._mark
+
     def manifest(self) -> list:
-        """Source side: one picklable description per entry, in creation order."""
+        """Source side: one picklable description per entry created since mark(), in creation order."""
         out = []
-        for key in self.order:
+        for key in self.order[self._mark :]:
             v = self.store[key]
             src = {s.t.data_ptr() for s in key if isinstance(s, _Src)}
             leaves = _leaves(v)
@@ -236,24 +249,41 @@ class PackCache:
                 # nothing to move: no tensors inside, a pure function of the key (index tables: no source tensor in the key), or the source
                 # tensors' own storage -- every rank makes these itself.  (A value that mixes views and fresh tensors travels whole: its fresh
                 # part may have been computed from other packs, which a receiver does not hold yet while it lowers.)
-                out.append(("alias",))
+                out.append(("alias", _key_desc(key)))
             else:
-                out.append(("recv", _describe(v)))
+                out.append(("recv", _describe(v), _key_desc(key)))
         return out
 
     def adopt(self, manifest: Optional[list]) -> None:
-        """Receiver side, BEFORE lowering: answer misses from the source's manifest (None: leave adopt mode)."""
+        """Receiver side, BEFORE lowering: answer misses from the source's manifest (None: leave adopt mode).  Opens the window."""
         self._adopt, self._cursor = manifest, 0
+        if manifest is not None:
+            self.mark()
 
     def leaves(self, manifest: list) -> list[Tensor]:
-        """The tensors of every "recv" entry, in manifest order: what the broadcast writes (source) / fills (receivers)."""
-        assert len(manifest) == len(self.order), (len(manifest), len(self.order))
+        """The tensors of every "recv" entry of the window, in manifest order: what the broadcast writes (source) / fills (receivers)."""
+        window = self.order[self._mark :]
+        assert len(manifest) == len(window), f"the source published {len(manifest)} packed-weight entries, this rank made {len(window)} in the same lowering"
         out: list[Tensor] = []
-        for key, spec in zip(self.order, manifest):
+        for key, spec in zip(window, manifest):
+            assert spec[-1] == _key_desc(key), (spec[-1], _key_desc(key))
             if spec[0] == "recv":
                 out.extend(_leaves(self.store[key]))
         self._adopt = None
         return out
+
+
+def _key_desc(key: tuple) -> tuple:
+    """What two ranks can compare about a cache key: its scalars as they are, its source tensors as (shape, dtype)."""
+    out = []
+    for s in key:
+        if isinstance(s, _Src):
+            out.append(("src", tuple(s.t.shape), str(s.t.dtype).replace("torch.", "")))
+        elif s is None or isinstance(s, (int, float, str, bool)):
+            out.append(s)
+        else:
+            out.append(repr(type(s).__name__))
+    return tuple(out)
 
 
 def _key_device(key: tuple) -> torch.device:

@@ -158,6 +158,7 @@ def broadcast_packs(lower: Any, cache: Any, src: int = 0, bucket_bytes: int = 51
     box: list[Any] = [None]
     try:
         if rank == src:
+            cache.mark()  # the hand-over covers what THIS lowering creates (a warm cache keeps its earlier entries to itself)
             lower()
             box[0] = cache.manifest()
     except BaseException as e:  # noqa: BLE001
@@ -208,7 +209,10 @@ def load_and_broadcast(module: torch.nn.Module, tensors_path: Any, device: torch
 
 
 def _materialise(module: torch.nn.Module, device: torch.device) -> None:
-    """Every parameter / buffer still on meta gets (uninitialised) storage on `device`; anything on another device moves there."""
+    """Every parameter / buffer still on meta gets (uninitialised) storage on `device`; anything on another device moves there.
+    Tensors already there keep their identity (id-keyed caches and outside references stay valid): "cuda" and "cuda:0" are the same place."""
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     for mod in module.modules():
         for store in (mod._parameters, mod._buffers):
             for name, t in list(store.items()):

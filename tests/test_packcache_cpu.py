@@ -66,3 +66,50 @@ def test_a_longer_request_sequence_than_the_manifest_is_refused():
     else:
         raise AssertionError("an unexpected extra entry must not be answered silently")
     assert _leaves(3) == []
+
+
+def test_a_warm_cache_hands_over_only_what_the_current_lowering_created():
+    """Round-3 advisor finding: manifest() used to walk every entry ever created while a receiver consumed from position 0.  After an earlier
+    lowering on both ranks (a first hand-over, a LoRA scale change) the second hand-over must publish / consume the NEW entries only."""
+    torch.manual_seed(1)
+    w, b = torch.randn(32, 64), torch.randn(32)
+    w2, b2 = w.clone(), b.clone()
+    src, dst = PackCache(), PackCache()
+    dst.build_device = torch.device("cpu")
+    # first hand-over
+    src.mark()
+    _fill(src, w, b, [])
+    man = src.manifest()
+    dst.adopt(man)
+    _fill(dst, w2, b2, [])
+    for t, s in zip(dst.leaves(man), src.leaves(man)):
+        t.copy_(s)
+    # a scale change re-lowers: every old entry hits, one new merged weight is made
+    calls = []
+    src.mark()
+    _fill(src, w, b, calls)
+    src.get(("merged", 0.5) + PackCache.ident(w), lambda: w * 0.5)
+    man2 = src.manifest()
+    assert calls == [] and len(man2) == 1 and man2[0][0] == "recv"
+    dst.adopt(man2)
+    _fill(dst, w2, b2, calls)
+    got = dst.get(("merged", 0.5) + PackCache.ident(w2), lambda: calls.append("merged") or w2 * 0.5)
+    assert calls == [] and tuple(got.shape) == (32, 64)
+    (leaf,), (want,) = dst.leaves(man2), src.leaves(man2)
+    leaf.copy_(want)
+    assert torch.equal(dst.store[dst.order[-1]], w * 0.5)
+
+
+def test_a_receiver_that_is_out_of_step_is_refused_before_it_builds_anything():
+    w, b = torch.randn(32, 64), torch.randn(32)
+    src = PackCache()
+    src.get(("kblocked",) + PackCache.ident(w), lambda: native.KBlocked(w))
+    dst = PackCache()
+    dst.build_device = torch.device("cpu")
+    dst.adopt(src.manifest())
+    try:
+        dst.get(("fold",) + PackCache.ident(w, b), lambda: (w * 2, b))  # same position, another entry: used to get the K-blocked description
+    except AssertionError as exc:
+        assert "out of step" in str(exc)
+    else:
+        raise AssertionError("a mismatching key must not be answered from the manifest")
