@@ -86,22 +86,9 @@ def respawn_under_torchrun(n: int) -> None:
 
 
 def pmc_mfma_file(family: str) -> Path:
-    """The committed MFMA counter pass to quote: of the latest round's step-scoped passes, the one whose profiled dispatches of `family` were
-    the shortest -- boxes of the pool differ by up to 10 % on memory-latency-bound launches and the least
-    perturbed run is the one comparable to a normal bench run; falls back to the latest file by name."""
-    files = sorted((ROOT / "profiles").glob("r*_pmc_mfma.json"))
-    latest_round = files[-1].name.split("_")[0]
-    best, best_ns = files[-1], None
-    for f in files:
-        if not f.name.startswith(latest_round + "_"):
-            continue
-        try:
-            ns = json.loads(f.read_text())["families"][family].get("DURATION_NS")
-        except Exception:  # noqa: BLE001
-            continue
-        if ns and (best_ns is None or ns < best_ns):
-            best, best_ns = f, ns
-    return best
+    """The committed MFMA counter pass to quote: the LATEST one by name (deterministic; round 3 picked the least-perturbed of several passes,
+    which the advisor rightly called best-of-N selection)."""
+    return sorted((ROOT / "profiles").glob("r*_pmc_mfma.json"))[-1]
 
 
 def pmc_mfma_util(family: str, family_tflop_per_step: float = 0.0):
@@ -213,7 +200,7 @@ def replica_check(pipe, specs: dict, n_img: int, dev: torch.device) -> dict:
     return {"ok": ok, "max_rel_checksum_deviation": dev_max, "ranks": world, **({} if ok else {"checksums": [g.tolist() for g in got]})}
 
 
-def build_pipeline(workload: str, n_img: int, rank: int, dev: torch.device, dtype: torch.dtype, lora_mode: str, use_graph: bool, broadcast: bool = True):
+def build_pipeline(workload: str, n_img: int, rank: int, dev: torch.device, dtype: torch.dtype, lora_mode: str, use_graph: bool, broadcast: bool = True, packs: str = "broadcast"):
     """UNet (random init in HBM) + adapters injected through the Chain API + one CompiledSDXL with its inputs staged."""
     import refiners_amd
     from refiners_amd import parallel, synth
@@ -232,22 +219,38 @@ def build_pipeline(workload: str, n_img: int, rank: int, dev: torch.device, dtyp
         specs = {"loras": [], "ip": None, "control": [synth.control_spec("canny", 1.0, 2 * n_img, LATENT, seed=5)]}
     if workload != "bare":
         synth.apply_adapters(unet, refiners_amd.namespace(), device=dev, dtype=dtype, **specs)
+    multi = broadcast and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
     torch.cuda.synchronize()
+    if multi:
+        torch.distributed.barrier()  # the clock below times the collective, not the other ranks' weight drawing
+    b0 = parallel.moved["bytes"]
     tb = time.time()
     n_bcast = parallel.broadcast_module(unet, src=0) if broadcast else 0
     torch.cuda.synchronize()
     bcast_s = time.time() - tb
+    wbytes = parallel.moved["bytes"] - b0
     pipe = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=use_graph, lora_mode=lora_mode)
     stage_inputs(pipe, specs, n_img, 100 + rank, dev)
-    info = {"weights_broadcast_s": round(bcast_s, 3), "broadcast_launches": n_bcast}
-    if broadcast and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        # every rank lowers its own program (it holds local addresses); only rank 0 K-blocks / merges / LayerNorm-folds the weights, the packed
-        # copies then travel over xGMI like the weights did (refiners_amd.parallel.broadcast_packs)
+    info = {"weights_broadcast_s": round(bcast_s, 3), "broadcast_launches": n_bcast, "weights_broadcast_bytes": wbytes,
+            "weights_broadcast_gbps": round(wbytes / bcast_s / 1e9, 2) if wbytes and bcast_s > 0 else None}
+    if multi:
+        # every rank lowers its own program (it holds local addresses).  --packs broadcast (default): only rank 0 K-blocks / merges /
+        # LayerNorm-folds the weights, the packed copies then travel over xGMI like the weights did (refiners_amd.parallel.broadcast_packs);
+        # --packs local: every rank packs for itself (the A/B for the driver's 8-GPU run: ~11 GB over the links against seconds of torch work per rank)
         torch.cuda.synchronize()
+        torch.distributed.barrier()
+        b1 = parallel.moved["bytes"]
         tp = time.time()
-        n_pk = parallel.broadcast_packs(pipe.lower_now, pipe.engine.cache, src=0)
+        if packs == "broadcast":
+            n_pk = parallel.broadcast_packs(pipe.lower_now, pipe.engine.cache, src=0)
+        else:
+            pipe.lower_now()
+            n_pk = 0
         torch.cuda.synchronize()
-        info.update(packs_broadcast_s=round(time.time() - tp, 3), packs_broadcast_launches=n_pk)
+        pk_s = time.time() - tp
+        pbytes = parallel.moved["bytes"] - b1
+        info.update(packs=packs, packs_broadcast_s=round(pk_s, 3), packs_broadcast_launches=n_pk, packs_broadcast_bytes=pbytes,
+                    packs_broadcast_gbps=round(pbytes / pk_s / 1e9, 2) if pbytes and pk_s > 0 else None)
     return unet, specs, bare_sd, pipe, info
 
 
@@ -268,7 +271,9 @@ def timed_steps(pipe, steps: int, warmup: int, world: int, dev: torch.device) ->
     sync()
     if world > 1:
         torch.distributed.barrier()
-    return parallel.max_over_ranks(time.perf_counter() - t1, device=dev)
+    mine = time.perf_counter() - t1
+    timed_steps.last_local_s = mine  # this rank's own clock (bench.py gathers them into extra.per_rank_ms_per_step)
+    return parallel.max_over_ranks(mine, device=dev)
 
 
 def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict:
@@ -325,34 +330,99 @@ def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict
     }
 
 
-def cpu_baseline_step(bare_sd: dict, specs: dict, workload: str, threads: int) -> dict:
-    """The reference's own path for ONE denoising step on this host's cores: the mirror's UNFUSED Chain forward issues the
-    same ATen calls, module by module, as refiners' `LatentDiffusionModel.forward` (CFG cat, SDXLUNet Chain with the same
-    adapters injected through the same API, CFG combine, DDIM) -- float32, CPU, `threads` intra-op threads."""
-    import refiners_amd
-    from refiners_amd import synth
-    from refiners_amd.latent_diffusion.sampling import DDIM, SDXLDenoiser
-    from refiners_amd.latent_diffusion.sdxl import SDXLUNet
+def reference_checkout():
+    """refiners' own package for the CPU baseline leg: REFINERS_SRC, else the copy __graft_entry__.build() staged under oracle/_ref (it travels to
+    the GPU box with the snapshot).  Test / baseline infrastructure only: the timed GPU region never imports it."""
+    for cand in (os.environ.get("REFINERS_SRC"), ROOT / "oracle" / "_ref" / "src"):
+        if cand and (Path(cand) / "refiners").exists():
+            return Path(cand)
+    return None
 
-    torch.set_num_threads(threads)
+
+def _cpu_step_fn(api_kind: str, bare_sd: dict, specs: dict, workload: str, ref_src=None):
+    """(step(x, text, pooled, time_ids) -> x_next, description) on CPU float32: one denoising step the way `LatentDiffusionModel.forward` does it
+    (foundationals/latent_diffusion/model.py:128-159): contexts set on the UNet, Chain forward on the CFG pair, CFG combine, DDIM.
+    api_kind "reference": refiners' OWN SDXLUNet / adapters / DDIM; "mirror": refiners_amd.fluxion's unfused Chain forward (the same ATen calls)."""
+    from types import SimpleNamespace
+
+    from refiners_amd import synth
+
     cpu = torch.device("cpu")
-    unet = SDXLUNet(4, device="meta")
+    if api_kind == "reference":
+        sys.path[:0] = [p for p in (str(ROOT / "oracle" / "shim"), str(ref_src)) if p not in sys.path]
+        import refiners.fluxion.layers as rfl
+        from refiners.fluxion.adapters.lora import Conv2dLora, LinearLora, LoraAdapter
+        from refiners.foundationals.latent_diffusion.solvers import DDIM as RefDDIM
+        from refiners.foundationals.latent_diffusion.stable_diffusion_xl.control_lora import ConditionEncoder, ControlLoraAdapter, ZeroConvolution
+        from refiners.foundationals.latent_diffusion.stable_diffusion_xl.image_prompt import SDXLIPAdapter
+        from refiners.foundationals.latent_diffusion.stable_diffusion_xl.unet import SDXLUNet as RefUNet
+
+        assert Path(rfl.__file__).resolve().is_relative_to(Path(ref_src).resolve())
+        api = SimpleNamespace(fl=rfl, LinearLora=LinearLora, Conv2dLora=Conv2dLora, LoraAdapter=LoraAdapter, SDXLIPAdapter=SDXLIPAdapter,
+                              ControlLoraAdapter=ControlLoraAdapter, ConditionEncoder=ConditionEncoder, ZeroConvolution=ZeroConvolution)
+        unet, solver = RefUNet(4, device="meta"), RefDDIM(num_inference_steps=50)
+        desc = "finegrain-ai/refiners itself (oracle/_ref): refiners.foundationals SDXLUNet Chain forward, adapters injected through its own API, its own DDIM"
+    else:
+        import refiners_amd
+        from refiners_amd.latent_diffusion.sampling import DDIM
+        from refiners_amd.latent_diffusion.sdxl import SDXLUNet
+
+        api, unet, solver = refiners_amd.namespace(), SDXLUNet(4, device="meta"), DDIM(50, device=cpu, dtype=torch.float32)
+        desc = "mirror-of-reference ATen path: refiners_amd.fluxion Chain forward, unfused, the same adapters injected (no oracle, no native kernels)"
     unet.load_state_dict({k: v.detach().to(device=cpu, dtype=torch.float32) for k, v in bare_sd.items()}, assign=True)
     if workload != "bare":
-        synth.apply_adapters(unet, refiners_amd.namespace(), device=cpu, dtype=torch.float32, **specs)
-    sd = SDXLDenoiser(unet, DDIM(50, device=cpu, dtype=torch.float32))
+        synth.apply_adapters(unet, api, device=cpu, dtype=torch.float32, **specs)
+
+    def step(x, text, pooled, time_ids):
+        unet.set_timestep(solver.timesteps[0].unsqueeze(0))
+        unet.set_clip_text_embedding(text)
+        unet.set_pooled_text_embedding(pooled)
+        unet.set_time_ids(time_ids)
+        u, c = unet(torch.cat((x, x))).chunk(2)
+        return solver(x, predicted_noise=u + 5.0 * (c - u), step=0)
+
+    return step, desc
+
+
+def cpu_baseline_step(bare_sd: dict, specs: dict, workload: str, threads: int) -> dict:
+    """ONE denoising step of the benchmarked workload on this host's cores, float32, `threads` intra-op threads.  With refiners' own package at
+    hand (reference_checkout) the timed step runs refiners ITSELF (`kind: "reference"`); the mirror's unfused Chain forward -- the stand-in of
+    earlier rounds, and the fallback when no checkout is present (`kind: "port"`) -- is timed beside it on a 32x32-latent sample of the same
+    step, where both are also compared value for value."""
+    from refiners_amd import synth
+
+    torch.set_num_threads(threads)
+    ref_src = reference_checkout() if workload in ("bare", "lora_ip", "control") else None
+    if workload == "control" and specs["control"] and specs["control"][0]["condition"].shape[0] != 2:
+        ref_src = None  # the bounded sample below is one image
+    kind = "reference" if ref_src is not None else "port"
+    step, desc = _cpu_step_fn("reference" if ref_src is not None else "mirror", bare_sd, specs, workload, ref_src)
     cin = synth.sdxl_inputs(1, LATENT, seed=100)
-    kw = dict(clip_text_embedding=cin["text"], pooled_text_embedding=cin["pooled"], time_ids=cin["time_ids"], condition_scale=5.0)
+    small = [cin["x"][:, :, :32, :32], cin["text"], cin["pooled"], cin["time_ids"]]
     with torch.no_grad():
-        sd(cin["x"][:, :, :16, :16], 0, **kw)  # page-in / thread-pool warm-up on a 16x16 latent
+        step(cin["x"][:, :, :16, :16], *small[1:])  # page-in / thread-pool warm-up on a 16x16 latent
         tc = time.perf_counter()
-        out = sd(cin["x"], 0, **kw)
+        out = step(cin["x"], *small[1:])
         cpu_s = time.perf_counter() - tc
-    assert bool(torch.isfinite(out).all())
-    return {"value": round(1.0 / (cpu_s * 50), 6), "unit": "images/s", "cores": threads, "kind": "port",
-            "path": "mirror-of-reference ATen path: refiners_amd.fluxion Chain forward, unfused, the same adapters injected (no oracle, no native kernels)",
-            "dtype": "f32", "ms_per_step": round(cpu_s * 1e3, 1), "host_cpus": os.cpu_count(),
-            "sample": "1 of the 50 DDIM steps of one 1024x1024 image (CFG pair) of this workload; images/s extrapolated x50"}
+        assert bool(torch.isfinite(out).all())
+        res = {"value": round(1.0 / (cpu_s * 50), 6), "unit": "images/s", "cores": threads, "kind": kind, "path": desc, "dtype": "f32",
+               "ms_per_step": round(cpu_s * 1e3, 1), "host_cpus": os.cpu_count(),
+               "sample": "1 of the 50 DDIM steps of one 1024x1024 image (CFG pair) of this workload; images/s extrapolated x50"}
+        if kind == "reference":
+            try:  # the mirror beside it, on a bounded sample (32x32 latents): same step, same weights, same adapters
+                t1 = time.perf_counter()
+                y_ref = step(*small)
+                ref_small = time.perf_counter() - t1
+                mstep, mdesc = _cpu_step_fn("mirror", bare_sd, specs, workload)
+                mstep(cin["x"][:, :, :16, :16], *small[1:])
+                t2 = time.perf_counter()
+                y_mir = mstep(*small)
+                mir_small = time.perf_counter() - t2
+                res["mirror"] = {"path": mdesc, "sample": "the same step on 32x32 latents", "reference_ms": round(ref_small * 1e3, 1), "mirror_ms": round(mir_small * 1e3, 1),
+                                 "mirror_over_reference": round(mir_small / ref_small, 3), "rel_l2_mirror_vs_reference": float((y_mir - y_ref).norm() / y_ref.norm())}
+            except Exception as exc:  # noqa: BLE001
+                res["mirror"] = f"failed: {type(exc).__name__}: {exc}"
+    return res
 
 
 def sam_point(dev: torch.device, dtype: torch.dtype) -> dict:
@@ -392,6 +462,8 @@ def main() -> None:
     ap.add_argument("--no-extra", action="store_true", help="skip the informational extras (configs[1] line, fused-LoRA line, VAE decode, 4-images-per-GPU point)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-family replay (profiler passes: the kernel table then holds the timed steps only)")
     ap.add_argument("--dump-program", default=None, help="write the recorded step program (one entry per launch: entry point + shape class) as JSON: tools/profile_round.py")
+    ap.add_argument("--packs", choices=["broadcast", "local"], default="broadcast",
+                    help="N > 1: packed weights (K-blocked / merged / LayerNorm-folded copies) computed on rank 0 and broadcast (default), or computed by every rank for itself")
     ap.add_argument("--lora-mode", choices=["fused", "merged"], default="fused",
                     help="fused (default, the engine's default and the north star's kernel): run-time LoRA inside the parent launch, adapters stay live; "
                          "merged: W' = W + sum s B A formed at lowering time (reported under extra.lora_mode_merged)")
@@ -417,9 +489,12 @@ def main() -> None:
     use_graph = not args.no_graph
 
     t0 = time.time()
-    unet, specs, bare_sd, pipe, bc = build_pipeline(args.workload, n_img, rank, dev, dtype, args.lora_mode, use_graph)
+    unet, specs, bare_sd, pipe, bc = build_pipeline(args.workload, n_img, rank, dev, dtype, args.lora_mode, use_graph, packs=args.packs)
     n_params = sum(p.numel() for p in unet.parameters())
     elapsed = timed_steps(pipe, args.steps, args.warmup, world, dev)
+    if world > 1:  # every rank's own clock around the same K steps (value uses the max): a slow GPU / link shows up here
+        mine = torch.tensor([timed_steps.last_local_s / args.steps * 1e3], dtype=torch.float64, device=dev)
+        bc["per_rank_ms_per_step"] = [round(float(t), 3) for t in parallel.all_gather(mine)]
     setup_s = time.time() - t0 - elapsed
     finite = bool(torch.isfinite(pipe.x.float()).all())
     if world > 1:
@@ -441,7 +516,7 @@ def main() -> None:
                    "arena_bytes": stats["pool_bytes"], "weight_prefetch": stats.get("weight_prefetch"), **bc, "setup_s": round(setup_s, 1),
                    "output_finite": finite, "device": native.device_info(), "gemm_tuning": stats.get("gemm_tuning")}
 
-    # ---- CPU baseline: the reference's path (mirror Chain forward, same adapters) on this host's cores, one step -----------
+    # ---- CPU baseline: refiners itself where its package is at hand (oracle/_ref), else the mirror's Chain forward; same adapters, one step ----
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(64, os.cpu_count() or 1)

@@ -13,13 +13,18 @@ after `set_unet_context`): inputs come from the UNet's context store, the contex
 redone when `tree_epoch()` moved).  `CompiledSDXL` adds the classifier-free-guidance + DDIM update as one more kernel and
 replays a whole denoising step as ONE HIP graph launch.
 
-There is no silent fallback: if the native library is missing this module raises; if a (sub-)tree cannot be lowered the
-reason is recorded in `.stats["fallback_nodes"]` (node-level torch fallback) or raised as `Unsupported` (whole UNet).
+There is no silent fallback: if the native library is missing this module raises.  A tree shape the lowering does not know follows the
+reference's own convention for unknown children -- the stock child loop runs (fluxion/layers/chain.py:226-257; SURVEY.md section 8(b):
+"unsupported => fall back, never error") -- at two levels, both reported: a context-free sub-tree inside a UNet stage runs through its own
+torch forward inside the recorded program (`.stats["fallback_nodes"]`); anything else (a node that needs the Chain's context store at run
+time, an unknown top-level layout) makes the WHOLE call run `unet(x)`, with a `RuntimeWarning` naming the reason and
+`.stats["whole_fallback"]` set.  Adapters outside SURVEY.md section 8 (FreeU, reference-only, StyleAligned ...) therefore keep working, unfused.
 """
 from __future__ import annotations
 
 import os
 
+import warnings
 from typing import Any, Optional
 
 import torch
@@ -86,6 +91,7 @@ class CompiledUNet:
         self.low: Optional[UNetLowering] = None
         self.io: Optional[UNetIO] = None
         self.key: Any = None
+        self.bad_key: Any = None  # the (tree state, geometry) key whose lowering raised Unsupported: those calls run the stock forward
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.prologue_key: Any = None
         self.prologue_refs: Any = None  # the staged source tensors themselves (see _ident)
@@ -221,8 +227,17 @@ class CompiledUNet:
                tuple((k, tuple(v.shape)) for k, v in got["conditions"].items()), got["pooled"] is not None,
                tuple((k, tuple(tuple(f.shape) for f in feats)) for k, feats in got.get("t2i", {}).items()))
         if key != self.key:
-            self._build(x_shape, device, got)
-            self.key = key
+            if key == self.bad_key:
+                raise Unsupported(self.stats.get("whole_fallback", "this tree could not be lowered"))
+            try:
+                self._build(x_shape, device, got)
+            except Unsupported as exc:
+                # remembered per (tree state, geometry): the next call does not walk the tree again; any inject / eject / scale change retries
+                self.bad_key, self.key, self.low, self.io, self.graph = key, None, None, None, None
+                self.stats = {"whole_fallback": str(exc), "fallback_nodes": ["<whole UNet>"], "step_ops": 0, "prologue_ops": 0}
+                warnings.warn(f"refiners_amd: this UNet tree is not lowered to the MI355X kernels ({exc}); running the stock Chain forward instead", RuntimeWarning, stacklevel=3)
+                raise
+            self.key, self.bad_key = key, None
         return self._stage_inputs(got)
 
     def run_prologue(self) -> None:
@@ -247,7 +262,11 @@ class CompiledUNet:
 
     @torch.no_grad()
     def __call__(self, x: Tensor) -> Tensor:
-        if self.prepare(x):
+        try:
+            changed = self.prepare(x)
+        except Unsupported:
+            return self.unet(x)  # the stock child loop: reads the same context store, resets it itself (chain.py:245-257)
+        if changed:
             self.run_prologue()
         self.run_step()
         assert self.io is not None
@@ -318,10 +337,14 @@ class CompiledSDXL:
         self.ts_table = self.solver.timesteps.to(device=device, dtype=torch.float32)
         # Self-Attention Guidance degrades the latents through Solver.remove_noise / add_noise: (-, scale_t, std_t) per step, for mi355x_sag_degrade.
         # A solver whose add_noise / remove_noise the reference itself cannot evaluate (Euler: float timesteps) has no table; SAG then raises.
-        try:
-            self.sag_table = torch.tensor([[0.0, *self.solver.sag_coefficients(s)] for s in range(self.solver.num_inference_steps)], dtype=torch.float32, device=device)
-        except (IndexError, AttributeError):
+        # The one refusal that is the reference's own: a solver whose timesteps are floats (Euler) cannot index the integer train-time tables
+        # in add_noise / remove_noise -- torch raises IndexError there too.  Anything else (a solver without the method, a bug in its tables)
+        # propagates instead of being turned into "no SAG" (round-3 advisor finding).
+        ts = self.solver.timesteps
+        if not hasattr(self.solver, "sag_coefficients") or (torch.is_tensor(ts) and ts.is_floating_point()):
             self.sag_table = None
+        else:
+            self.sag_table = torch.tensor([[0.0, *self.solver.sag_coefficients(s)] for s in range(self.solver.num_inference_steps)], dtype=torch.float32, device=device)
         self.sag_coef = torch.zeros(3, dtype=torch.float32, device=device)
 
     def set_inputs(self, x: Tensor, *, clip_text_embedding: Tensor, pooled_text_embedding: Optional[Tensor] = None, time_ids: Optional[Tensor] = None,
@@ -376,7 +399,11 @@ class CompiledSDXL:
         got = dict(self.inputs, timestep=self.ts_table[step : step + 1])
         n = self.x.shape[0]
         shape2 = (2 * n,) + tuple(self.x.shape[1:])
-        if eng.prepare_explicit(shape2, self.x.device, got):
+        try:
+            changed = eng.prepare_explicit(shape2, self.x.device, got)
+        except Unsupported:
+            return self._stock_step(step, got)
+        if changed:
             eng.run_prologue()
         io, low = eng.io, eng.low
         assert io is not None and low is not None
@@ -412,6 +439,39 @@ class CompiledSDXL:
             self.graph, self.graph_key = g, gkey
         self.graph.replay()
         return self.x
+
+    # -- whole-tree fallback ------------------------------------------------------------------------------------------------------
+    def _stock_step(self, step: int, got: dict[str, Any]) -> Tensor:
+        """A tree the lowering refused (CompiledUNet.prepare_explicit warned and recorded why): the step runs like the reference's
+        `LatentDiffusionModel.forward` (latent_diffusion/model.py:128-159) -- contexts set on the tree, `unet(cat(x, x))` through the stock
+        child loop -- and only the guidance + solver update stays on the native kernel."""
+        assert self._sag_adapter() is None, "Self-Attention Guidance on a tree that is not lowered: use refiners' own pipeline"
+        unet, x = self.unet, self.x
+        assert x is not None
+        unet.set_timestep(got["timestep"])
+        for (ctx, key), v in got["tokens"].items():
+            unet.set_context(ctx, {key: v.to(x.dtype)})
+        if got.get("pooled") is not None:
+            unet.set_pooled_text_embedding(got["pooled"].to(x.dtype))
+            unet.set_time_ids(got["time_ids"])
+        for name, v in got.get("conditions", {}).items():
+            ctx, _, key = name.partition(".")
+            unet.set_context(ctx, {key or "condition": v.to(x.dtype)})
+        for name, feats in got.get("t2i", {}).items():
+            unet.set_context("t2iadapter", {f"condition_features_{name}": tuple(f.to(x.dtype) for f in feats)})
+        self.coef.copy_(self.coef_table[step])
+        xin = torch.cat((x, x))
+        if not self.linear:
+            native.cfg_ddim_step(x, unet(xin).contiguous(), self.coef)
+            return x
+        assert self.hist is not None
+        if getattr(self.solver, "needs_noise", None) is not None and self.solver.needs_noise(step):
+            noise = torch.randn(tuple(x.shape), generator=getattr(self, "generator", None), device=getattr(self.solver, "device", x.device), dtype=getattr(self.solver, "dtype", x.dtype))
+            self.hist.copy_(noise)
+        s0 = float(self.solver.input_scale(step))
+        y = unet(xin * s0 if s0 != 1.0 else xin).contiguous()
+        native.cfg_linear_step(x, y, self.hist, None, self.coef)  # (no model-input buffer: the next step scales cat(x, x) itself)
+        return x
 
     # -- self-attention guidance (xl/model.py:164-250) ---------------------------------------------------------------------------
     def _sag_adapter(self) -> Any:

@@ -386,10 +386,24 @@ class BlockLowering(Lowering):
 
     # -- generic fallback -------------------------------------------------------------------------------------------
     def torch_node(self, node: Any, a: Act, out_channels: Optional[int] = None, out_hw: Optional[tuple[int, int]] = None, what: str = "") -> Act:
-        """Run an unrecognised sub-tree through its own torch forward on an NCHW copy (shape-preserving unless told)."""
-        C2 = out_channels or a.C
-        H2, W2 = out_hw or (a.H, a.W)
+        """Run an unrecognised sub-tree through its own torch forward on an NCHW copy: the node-level half of the section 8(b) error convention
+        ("unsupported => fall back to the stock child loop, never error", fluxion/layers/chain.py:226-243).  Only for sub-trees that do not touch
+        the context store: at run time the Chain's contexts do not hold this program's tensors (residual slots, embeddings live in the lowered
+        program), so a node that reads or writes them -- FreeU's concatenator, reference-only / StyleAligned attention injections -- makes the WHOLE
+        tree fall back to the stock forward instead (Unsupported -> CompiledUNet.__call__).  The output geometry is whatever the node
+        produces on a zero image of the input's shape (one trial call at lowering time)."""
+        ctx_nodes = sorted({cname(s) for s in node.modules() if isa(s, "UseContext", "SetContext")})
+        if ctx_nodes:
+            raise Unsupported(f"{cname(node)} is not a lowered pattern and contains {', '.join(ctx_nodes)}: it needs the stock Chain forward's context store")
+        C2, (H2, W2) = out_channels or a.C, out_hw or (a.H, a.W)
         nchw = torch.empty(a.B, a.C, a.H, a.W, device=self.device, dtype=self.dtype)
+        if out_channels is None and out_hw is None and self.device.type != "meta":
+            with torch.no_grad():
+                trial = node(torch.zeros_like(nchw))
+            if not (isinstance(trial, Tensor) and trial.dim() == 4 and trial.shape[0] == a.B):
+                raise Unsupported(f"{cname(node)} is not a lowered pattern and does not map an image to an image")
+            C2, H2, W2 = trial.shape[1], trial.shape[2], trial.shape[3]
+            del trial
         res = torch.empty(a.B, C2, H2, W2, device=self.device, dtype=self.dtype)
         out = self.pool.get(a.B * H2 * W2, C2)
         native.nhwc_to_nchw(a.tokens(), nchw, a.C)

@@ -35,6 +35,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local
 
 
+moved = {"bytes": 0, "collectives": 0}  # running totals of broadcast_tensors on this rank (bench.py reads the deltas: GB/s over xGMI = bytes / seconds)
+
+
 def _staged(t: Tensor) -> bool:
     """gloo moves host memory: device tensors are staged through the host (the one-GPU rehearsal of bench.py; RCCL takes them as they are)."""
     return t.device.type != "cpu" and dist.get_backend() == "gloo"
@@ -97,6 +100,8 @@ def broadcast_tensors(tensors: Iterable[Tensor], src: int = 0, bucket_bytes: int
         for lo in range(0, total, per):
             _broadcast(arena[lo : min(lo + per, total)], src)
             launches += 1
+        moved["bytes"] += total * es
+        moved["collectives"] += launches
         if not repoint and rank != src:
             for t, off in zip(items, offs):
                 t.copy_(arena[off : off + t.numel()].view(t.shape))

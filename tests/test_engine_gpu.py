@@ -1026,3 +1026,110 @@ def test_self_attention_guidance_on_the_engine(tag):
             assert l2 < F32_TOL and mx < F32_TOL, ("scale 0", l2, mx)
             sag.scale = CFG["sag_scale"]
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- section 8(b): "unsupported => fall back to the stock child loop, never error" (fluxion/layers/chain.py:226-243) --------------------------------
+def test_unknown_context_free_layer_runs_as_a_torch_node_inside_the_program():
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd.latent_diffusion.blocks import ResidualBlock
+
+    class Scale(fl.Module):
+        def __init__(self, s):
+            super().__init__()
+            self.s = s
+
+        def forward(self, x):
+            return x * self.s
+
+    cfg, unet, specs, handles, inp = build("sdxl_bare", torch.float32)
+    unet.layer(("DownBlocks", 1), fl.Chain).insert_after_type(ResidualBlock, Scale(0.9))
+    unet.layer(("UpBlocks", 7), fl.Chain).insert_after_type(ResidualBlock, Scale(1.1))
+    fast = CompiledUNet(unet)
+    xx = torch.cat((inp["x"], inp["x"]))
+    set_context(unet, cfg, inp, torch.float32)
+    y = fast(xx)
+    assert fast.stats["fallback_nodes"] == ["Scale", "Scale"] and "whole_fallback" not in fast.stats
+    set_context(unet, cfg, inp, torch.float32)
+    ref = unet(xx)
+    l2, mx = S.rel_err(y, ref)
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    l2g, _ = S.rel_err(y, S.golden("sdxl_bare")["unet_out"])
+    assert l2g > 1e-2  # the inserted layers do change the result: the torch nodes really ran
+    set_context(unet, cfg, inp, torch.float32)
+    assert torch.equal(y, fast(xx))  # graph replay with the captured torch node
+
+
+def test_layer_that_needs_the_context_store_runs_the_stock_forward_with_a_warning():
+    import refiners_amd.fluxion.layers as fl
+    from refiners_amd.latent_diffusion.blocks import ResidualConcatenator
+
+    class SkipFilter(fl.Concatenate):  # the shape of FreeU's concatenator (latent_diffusion/freeu.py:57-72)
+        def __init__(self, n):
+            super().__init__(fl.Identity(), fl.Chain(fl.UseContext(context="unet", key="residuals").compose(lambda r: r[n]), fl.Lambda(lambda t: t * 0.5)), dim=1)
+
+    cfg, unet, specs, handles, inp = build("sdxl_bare", torch.float32)
+    block = unet.layer(("UpBlocks", 0), fl.Chain)
+    old = block.ensure_find(ResidualConcatenator)
+    block.replace(old, SkipFilter(-2))
+    fast = CompiledUNet(unet)
+    xx = torch.cat((inp["x"], inp["x"]))
+    set_context(unet, cfg, inp, torch.float32)
+    with pytest.warns(RuntimeWarning, match="stock Chain forward"):
+        y = fast(xx)
+    assert "SkipFilter" in fast.stats["whole_fallback"] and fast.stats["fallback_nodes"] == ["<whole UNet>"]
+    set_context(unet, cfg, inp, torch.float32)
+    assert torch.equal(y, unet(xx))
+    set_context(unet, cfg, inp, torch.float32)
+    assert torch.equal(y, fast(xx))  # remembered: no second lowering attempt, no second warning needed
+    # the CFG + DDIM step keeps working on such a tree as well (stock UNet forward + the native guidance / solver kernel)
+    sd = CompiledSDXL(unet, num_inference_steps=cfg["num_steps"], condition_scale=cfg["condition_scale"])
+    sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"])
+    with pytest.warns(RuntimeWarning):
+        x1 = sd.step(cfg["step"]).clone()
+    u, c = y.chunk(2)
+    from refiners_amd.latent_diffusion.sampling import DDIM as MirrorDDIM
+
+    want = MirrorDDIM(cfg["num_steps"], device="cuda")(inp["x"], predicted_noise=u + cfg["condition_scale"] * (c - u), step=cfg["step"])
+    l2, mx = S.rel_err(x1, want)
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    # ejecting the layer brings the lowered path back
+    block.replace(block.ensure_find(SkipFilter), old)
+    set_context(unet, cfg, inp, torch.float32)
+    y2 = fast(xx)
+    assert "whole_fallback" not in fast.stats and fast.stats["fallback_nodes"] == []
+    l2, mx = S.rel_err(y2, S.golden("sdxl_bare")["unet_out"])
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+
+
+def test_lora_hand_off_with_two_programs_replaying_concurrently():
+    """The in-launch LoRA hand-off (producer workgroups -> flags -> output tiles, csrc/gemm_kernel.cuh) assumes nothing about what else runs on
+    the GPU: two lowered programs (own flags, epoch words and arenas) replayed at the same time on two streams, next to a third stream that
+    keeps the CUs busy, must each reproduce their solo result bit for bit on every replay (a tile that read t before its producer finished,
+    or a flag of the other program, would show up as a different output; a lost producer as the kernel's trap)."""
+    cfg, unet, specs, handles, inp = build("sdxl_lora_ip", torch.bfloat16)
+    xs = [torch.cat((inp["x"], inp["x"])).to(torch.bfloat16), torch.cat((inp["x"].flip(-1), inp["x"].flip(-2))).to(torch.bfloat16) * 0.9]
+    engines, solo = [], []
+    for x in xs:
+        fast = CompiledUNet(unet)
+        for _ in range(2):  # direct replay + capture, then the graph
+            set_context(unet, cfg, inp, torch.bfloat16)
+            y = fast(x)
+        assert fast.graph is not None and fast.stats["lora_sites"] > 0 and fast.stats["fallback_nodes"] == []
+        engines.append(fast)
+        solo.append(y.clone())
+    assert not torch.equal(solo[0], solo[1])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    noise = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    for it in range(12):
+        order = (0, 1) if it % 2 == 0 else (1, 0)
+        with torch.cuda.stream(streams[2]):
+            for _ in range(1 + it % 3):
+                noise @ noise  # uneven background load
+        for i in order:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(1 + (it + i) % 2):  # the two programs drift against each other
+                    engines[i].graph.replay()
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            assert torch.equal(engines[i].io.out, solo[i]), (it, i, float((engines[i].io.out.float() - solo[i].float()).abs().max()))

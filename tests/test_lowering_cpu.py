@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import refiners_amd
+import refiners_amd.fluxion.layers as fl
 from refiners_amd import native, synth
 from refiners_amd.engine.compiled import CompiledUNet
 from refiners_amd.engine.packing import launches
@@ -243,3 +244,52 @@ def test_kblocked_wrapper_round_trips_and_is_what_prefetch_sees():
     a.dtype, a.M, a.N, a.nseg, a.conv = 1, 2048, 1280, 1, 0
     a.seg[0].k, a.seg[0].ksize, a.seg[0].w, a.seg[0].ldw, a.seg[0].kblocked = 5120, 1, 0x1000, 5120, 1
     assert native.weight_spans(a) == [(0x1000, 1280 * 5120 * 2)]
+
+
+# ---- the section 8(b) error convention: unknown sub-trees fall back, they never make the call fail (fluxion/layers/chain.py:226-243) -------------
+class _Scale(fl.Module):
+    """An out-of-scope, context-free layer someone appended to a UNet stage."""
+
+    def __init__(self, s: float) -> None:
+        super().__init__()
+        self.s = s
+
+    def forward(self, x):
+        return x * self.s
+
+
+def _bare_io(dev, dtype=torch.float32):
+    io = UNetIO(x=torch.empty(2, 4, 32, 32, device=dev, dtype=dtype), timestep=torch.empty(2, device=dev), out=torch.empty(2, 4, 32, 32, device=dev, dtype=dtype))
+    io.pooled, io.time_ids = torch.empty(2, 1280, device=dev, dtype=dtype), torch.empty(2, 6, device=dev)
+    io.tokens[("cross_attention_block", "clip_text_embedding")] = (torch.zeros(256, 2048, device=dev, dtype=dtype), 77)
+    return io
+
+
+def test_a_context_free_unknown_layer_becomes_a_torch_node_of_the_program():
+    from refiners_amd.latent_diffusion.blocks import ResidualBlock
+
+    unet = SDXLUNet(4, device="meta")
+    unet.layer(("DownBlocks", 1), fl.Chain).insert_after_type(ResidualBlock, _Scale(0.9))
+    low = UNetLowering(torch.device("meta"), torch.float32)
+    low.lower(unet, _bare_io(torch.device("meta")))
+    assert low.stats["fallback_nodes"] == ["_Scale"]
+    assert sum(1 for e in low.step if e[0] is None and e[2] == "torch:_Scale") == 1
+
+
+def test_an_unknown_layer_that_needs_the_context_store_refuses_the_whole_tree():
+    """FreeU's concatenator shape (latent_diffusion/freeu.py:57-72): Concatenate(backbone features, UseContext(unet.residuals)[n] -> filter).  The
+    recorded program keeps the residual slots to itself, so this node cannot run inside it: lowering raises Unsupported and CompiledUNet
+    runs the stock forward (tests/test_engine_gpu.py, tests/test_reference_tree_gpu.py)."""
+    from refiners_amd.engine.packing import Unsupported
+    from refiners_amd.latent_diffusion.blocks import ResidualConcatenator
+
+    class SkipFilter(fl.Concatenate):
+        def __init__(self, n: int) -> None:
+            super().__init__(fl.Identity(), fl.Chain(fl.UseContext(context="unet", key="residuals").compose(lambda r: r[n]), fl.Lambda(lambda t: t * 0.5)), dim=1)
+
+    unet = SDXLUNet(4, device="meta")
+    block = unet.layer(("UpBlocks", 0), fl.Chain)
+    block.replace(block.ensure_find(ResidualConcatenator), SkipFilter(-2))
+    low = UNetLowering(torch.device("meta"), torch.float32)
+    with pytest.raises(Unsupported, match="SkipFilter.*UseContext"):
+        low.lower(unet, _bare_io(torch.device("meta")))

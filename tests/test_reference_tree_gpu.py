@@ -159,3 +159,50 @@ def test_the_proposed_binding_on_refiners_own_stable_diffusion_xl(gpu_device, ca
                      condition_scale=cfg["condition_scale"])  # the unpatched reference on the same GPU (stock ATen kernels)
     l2, mx = S.rel_err(x1, x_ref)
     assert l2 < 1e-3 and mx < 1e-3
+
+
+def test_out_of_scope_adapters_keep_working_on_the_real_refiners_tree(gpu_device):
+    """adapters outside the lowered set "must keep working unfused".  refiners' own `SDFreeUAdapter`
+    (latent_diffusion/freeu.py:75-104) swaps the ResidualConcatenators of the first UpBlocks for nodes that read `unet.residuals` from the
+    context store: the lowering refuses the tree, CompiledUNet warns and runs refiners' stock Chain forward (bit-identical to calling the
+    UNet); after eject() the lowered path is back.  A context-free foreign layer (refiners' own fl.Multiply appended to a stage) runs as a
+    torch node INSIDE the lowered program."""
+    api = _api()
+    from refiners.foundationals.latent_diffusion.freeu import SDFreeUAdapter
+    from refiners.foundationals.latent_diffusion.solvers import DDIM
+
+    from refiners_amd.engine.compiled import CompiledUNet
+    from tests import support as S
+
+    cfg, unet, specs, inp = _build("sdxl_bare")
+    xx = torch.cat((inp["x"], inp["x"]))
+    fast = CompiledUNet(unet)
+
+    def ctx():
+        unet.set_timestep(DDIM(cfg["num_steps"]).timesteps[cfg["step"]].unsqueeze(0).cuda())
+        unet.set_clip_text_embedding(inp["text"])
+        unet.set_pooled_text_embedding(inp["pooled"])
+        unet.set_time_ids(inp["time_ids"])
+
+    freeu = SDFreeUAdapter(unet, backbone_scales=[1.2, 1.2], skip_scales=[0.9, 0.9]).inject()
+    ctx()
+    with pytest.warns(RuntimeWarning, match="stock Chain forward"):
+        y = fast(xx)
+    assert "FreeUResidualConcatenator" in fast.stats["whole_fallback"] and fast.stats["fallback_nodes"] == ["<whole UNet>"]
+    ctx()
+    assert torch.equal(y, unet(xx))
+    l2, _ = S.rel_err(y, S.golden("sdxl_bare")["unet_out"])
+    assert l2 > 1e-3  # FreeU does change the output
+    freeu.eject()
+    ctx()
+    y0 = fast(xx)
+    l2, mx = S.rel_err(y0, S.golden("sdxl_bare")["unet_out"])
+    assert l2 < 1e-3 and mx < 1e-3 and fast.stats["fallback_nodes"] == [] and "whole_fallback" not in fast.stats
+    # node-level: a context-free layer of refiners' own
+    unet.layer(("DownBlocks", 4), api.fl.Chain).append(api.fl.Multiply(scale=0.8))
+    ctx()
+    y1 = fast(xx)
+    assert fast.stats["fallback_nodes"] == ["Multiply"]
+    ctx()
+    l2, mx = S.rel_err(y1, unet(xx))
+    assert l2 < 1e-3 and mx < 1e-3, (l2, mx)
