@@ -152,7 +152,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     if (a->lora_b) {
         if (a->ksplit > 1 && a->geglu) return MI355X_ESHAPE;
         if ((a->ln_stats && (!a->lora_ls || !a->lora_lc)) || a->out_f32 || a->lora_groups < 1 || a->lora_groups > 3 || a->lora_nb[0] != 0 ||
-            !aligned16(a->lora_b) || (a->lora_r != 32 && a->lora_r != 64 && a->lora_r != 128) || !a->lora_t || !aligned16(a->lora_t) || !a->lora_flags ||
+            !aligned16(a->lora_b) || (a->lora_r != 32 && a->lora_r != 64 && a->lora_r != 128) || !a->lora_t || (reinterpret_cast<uintptr_t>(a->lora_t) & 127) || !a->lora_flags ||
             !a->lora_epoch || (a->conv && a->lora_groups != 1))
             return MI355X_ESHAPE;
         for (int g = 0; g < a->lora_groups; ++g) {
@@ -166,6 +166,9 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         p.lora_ls = static_cast<const float*>(a->lora_ls);
         p.lora_lc = static_cast<const float*>(a->lora_lc);
         p.lora_t = static_cast<char*>(a->lora_t);
+        // group stride of the hand-off scratch: whole 128-byte lines per group, so that no cache line holds rows of two (group, row block) units
+        // (the tiles read t with plain cacheable loads: a line may only be fetched after ITS flag was seen -- round-3 advisor finding)
+        p.lora_gs = ((int64_t)a->M * a->lora_r * (a->dtype == MI355X_F32 ? 4 : 2) + 127) / 128 * 128;
         p.lora_flags = a->lora_flags;
         p.lora_epoch = a->lora_epoch;
     }

@@ -140,6 +140,11 @@ class CompiledUNet:
         if got["pooled"] is not None:
             io.pooled = torch.empty(B, got["pooled"].shape[1], device=dev, dtype=dtype)
             io.time_ids = torch.empty(B, got["time_ids"].shape[1], device=dev, dtype=torch.float32)
+        if got.get("timesteps_all") is not None:  # CompiledSDXL: the solver's whole timestep list -> the timestep-embedding chain becomes a prologue table
+            S = int(got["timesteps_all"].numel())
+            io.timesteps = torch.empty(B * S, device=dev, dtype=torch.float32)
+            io.step_rows = torch.zeros(B, device=dev, dtype=torch.int32)
+            self.rows_table = (torch.arange(B, dtype=torch.int32).unsqueeze(0) * S + torch.arange(S, dtype=torch.int32).unsqueeze(1)).to(dev)  # [S, B]: b*S + s
         for ck, v in got["tokens"].items():
             assert v.shape[0] == B, f"context {ck} has batch {v.shape[0]}, latents have {B}"
             L, width = v.shape[1], v.shape[2]
@@ -172,13 +177,18 @@ class CompiledUNet:
         assert io is not None
         ts = got["timestep"].to(device=io.timestep.device, dtype=torch.float32).reshape(-1)
         io.timestep.copy_(ts.expand(io.timestep.shape[0]) if ts.numel() == 1 else ts)
-        pk = (_ident(got["pooled"]), _ident(got["time_ids"]), tuple(_ident(v) for v in got["tokens"].values()), tuple(_ident(v) for v in got["conditions"].values()),
+        if io.step_rows is not None:
+            io.step_rows.copy_(self.rows_table[int(got["step_index"])])
+        pk = (_ident(got.get("timesteps_all")), _ident(got["pooled"]), _ident(got["time_ids"]), tuple(_ident(v) for v in got["tokens"].values()), tuple(_ident(v) for v in got["conditions"].values()),
               tuple(_ident(f) for feats in got.get("t2i", {}).values() for f in feats))
         if pk == self.prologue_key:
             return False
         if io.pooled is not None:
             io.pooled.copy_(got["pooled"])
             io.time_ids.copy_(got["time_ids"])  # type: ignore[union-attr]
+        if io.timesteps is not None:
+            B = io.timestep.shape[0]
+            io.timesteps.view(B, -1).copy_(got["timesteps_all"].to(device=io.timesteps.device, dtype=torch.float32).reshape(1, -1).expand(B, -1))
         for ck, v in got["tokens"].items():
             buf, L = io.tokens[ck]
             B = v.shape[0]
@@ -189,7 +199,7 @@ class CompiledUNet:
             for buf, f in zip(io.t2i[name], feats):
                 buf.copy_(f)
         self.prologue_key = pk
-        self.prologue_refs = (got["pooled"], got["time_ids"], tuple(got["tokens"].values()), tuple(got["conditions"].values()),
+        self.prologue_refs = (got.get("timesteps_all"), got["pooled"], got["time_ids"], tuple(got["tokens"].values()), tuple(got["conditions"].values()),
                               tuple(f for feats in got.get("t2i", {}).values() for f in feats))
         return True
 
@@ -223,7 +233,8 @@ class CompiledUNet:
     def prepare_explicit(self, x_shape: tuple, device: torch.device, got: dict[str, Any]) -> bool:
         """Same, with the side inputs given explicitly: {"timestep", "pooled", "time_ids", "tokens": {(ctx, key): t},
         "conditions": {ctx_name: t}}.  Does not stage x (the caller fills io.x).  Returns True when the prologue must run."""
-        key = (self._tree_state(), tuple(x_shape), self.unet.dtype, tuple((k, tuple(v.shape)) for k, v in got["tokens"].items()),
+        key = (self._tree_state(), tuple(x_shape), self.unet.dtype, None if got.get("timesteps_all") is None else int(got["timesteps_all"].numel()),
+               tuple((k, tuple(v.shape)) for k, v in got["tokens"].items()),
                tuple((k, tuple(v.shape)) for k, v in got["conditions"].items()), got["pooled"] is not None,
                tuple((k, tuple(tuple(f.shape) for f in feats)) for k, feats in got.get("t2i", {}).items()))
         if key != self.key:
@@ -381,7 +392,7 @@ class CompiledSDXL:
         if self.coef_table is None or self.coef_table.device != self.x.device:
             self._tables(self.x.device)
         n = self.x.shape[0]
-        self.engine.prepare_explicit((2 * n,) + tuple(self.x.shape[1:]), self.x.device, dict(self.inputs, timestep=self.ts_table[0:1]))
+        self.engine.prepare_explicit((2 * n,) + tuple(self.x.shape[1:]), self.x.device, dict(self.inputs, timestep=self.ts_table[0:1], timesteps_all=self.ts_table, step_index=0))
         self.engine.prologue_key = None  # staged, not yet run: the first step() re-stages and runs the prologue
 
     def _fill(self) -> None:
@@ -396,7 +407,7 @@ class CompiledSDXL:
         if self.coef_table is None or self.coef_table.device != self.x.device:
             self._tables(self.x.device)  # condition_scale / solver changed since the last call
         eng = self.engine
-        got = dict(self.inputs, timestep=self.ts_table[step : step + 1])
+        got = dict(self.inputs, timestep=self.ts_table[step : step + 1], timesteps_all=self.ts_table, step_index=step)
         n = self.x.shape[0]
         shape2 = (2 * n,) + tuple(self.x.shape[1:])
         try:
@@ -511,7 +522,8 @@ class CompiledSDXL:
             half = lambda t: None if t is None else t[: t.shape[0] // 2]  # noqa: E731
             halves = (self.inputs, {"pooled": half(got["pooled"]), "time_ids": half(got["time_ids"]), "tokens": {k: half(v) for k, v in got["tokens"].items()}})
             self._sag_halves = halves
-        got2 = {"timestep": got["timestep"], **halves[1], "conditions": got["conditions"], "t2i": got.get("t2i", {})}
+        got2 = {"timestep": got["timestep"], "timesteps_all": got.get("timesteps_all"), "step_index": got.get("step_index", 0), **halves[1],
+                "conditions": got["conditions"], "t2i": got.get("t2i", {})}
         x = self.x
         if e2.prepare_explicit((n,) + tuple(x.shape[1:]), x.device, got2):
             e2.run_prologue()

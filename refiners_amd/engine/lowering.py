@@ -297,7 +297,7 @@ class Lowering:
         if id(self._target) not in self._bumped:
             self._target.insert(0, self._lsync.bump_op())
             self._bumped.add(id(self._target))
-        return self.pool.get(groups * M, R), self._lsync.flags(groups, M), self._lsync
+        return self.pool.get(native.lora_scratch_rows(groups, M, R, self.dtype), R), self._lsync.flags(groups, M), self._lsync
 
     def lora_down(self, x: Tensor, lora: LoraPack) -> Tensor:
         t = self.pool.get(x.shape[0], lora.a_cat.shape[0])

@@ -25,6 +25,7 @@ class UNetContext:
     B: int
     text: dict[tuple[str, str], tuple[Tensor, int]] = field(default_factory=dict)  # padded token buffers + true length
     temb_silu: dict[str, Tensor] = field(default_factory=dict)  # context key -> SiLU(timestep embedding) [B, 1280]
+    temb_table: dict[str, Tensor] = field(default_factory=dict)  # table mode: context key -> the [B*S, 1280] prologue table (rows b*S + s); the [B, 1280] rows are gathered on first use
     residuals: list[Any] = field(default_factory=list)
     shapes: list[tuple[int, int]] = field(default_factory=list)
     time_table: dict[tuple[str, int], Tensor] = field(default_factory=dict)  # (context key, id(packed weight)) -> [B, cout] view of the batched launch
@@ -37,12 +38,17 @@ class UNetContext:
 
     def time_bias(self, spec: ConvSpec) -> Tensor:
         key, lin = spec.time  # type: ignore[misc]
-        src = self.temb_silu.get(key)
-        if src is None:
-            raise Unsupported(f"timestep embedding '{key}' has not been produced yet")
         got = self.time_table.get((key, id(lin.w)))
         if got is not None:  # a column slice of the one launch UNetLowering.batch_time_biases issued for every RangeAdapter2d of this key
             return got
+        src = self.temb_silu.get(key)
+        if src is None and key in self.temb_table:  # table mode, and a site outside the batched launch (its Linear carries LoRAs): this step's rows
+            src = self.low.pool.get(self.B, self.temb_table[key].shape[1])
+            self.low.pool.pin(src)
+            native.gather_rows(self.temb_table[key], self.low.io.step_rows, src)
+            self.temb_silu[key] = src
+        if src is None:
+            raise Unsupported(f"timestep embedding '{key}' has not been produced yet")
         out = self.low.pool.get(self.B, lin.N)
         self.low.pool.pin(out)
         self.low.linear(src, lin, out=out)
@@ -67,6 +73,11 @@ class UNetIO:
     out: Tensor  # [B, Cout, H, W]
     pooled: Optional[Tensor] = None  # [B, 1280]
     time_ids: Optional[Tensor] = None  # [B, 6] float32
+    # table mode (CompiledSDXL knows the solver's S timesteps): the whole timestep-embedding chain -- sinusoid, two Linears, SiLU, the 17
+    # RangeAdapter2d projections -- is a function of (timestep, batch row) alone, so it runs ONCE per prompt in the prologue for all S
+    # timesteps and a step only gathers its rows
+    timesteps: Optional[Tensor] = None  # [B*S] float32, row b*S + s = timestep s
+    step_rows: Optional[Tensor] = None  # [B] int32 on the device: b*S + (current step)
     tokens: dict[tuple[str, str], tuple[Tensor, int]] = field(default_factory=dict)  # (context, key) -> ([B*Lp, width], L)
     conditions: dict[str, Tensor] = field(default_factory=dict)  # control context name -> [B, 3, 8H, 8W]
     t2i: dict[str, list[Tensor]] = field(default_factory=dict)  # T2I-Adapter name -> its feature maps, NCHW, batch 1 or B
@@ -117,18 +128,26 @@ class UNetLowering(BlockLowering):
         return isa(m, "UseContext") and m.context == "unet" and m.key == "residuals"
 
     # -- timestep ----------------------------------------------------------------------------------------------
-    def _range_encoder(self, enc: Any, res: Optional[Tensor]) -> Tensor:
+    def _range_encoder(self, enc: Any, res: Optional[Tensor], table: bool = False) -> Tensor:
+        """RangeEncoder (range_adapter.py:25-44) of the step's timestep rows [B]; `table`: of all S timesteps x B rows (row b*S + s), `res`
+        ([B, C], one row per batch row) then enters as a per-group row bias."""
         ch = kids(enc)
         _expect(len(ch) == 5 and isa(ch[0], "Lambda") and isa(ch[1], "Converter") and isa(ch[3], "SiLU"), "unexpected RangeEncoder layout")
         l1, l2 = self.linear_spec(ch[2]), self.linear_spec(ch[4])
-        B = self.io.timestep.shape[0]
-        sin = self.pool.get(B, enc.sinusoidal_embedding_dim)
-        native.sinusoidal(self.io.timestep, enc.sinusoidal_embedding_dim, sin)
+        ts = self.io.timesteps if table else self.io.timestep
+        R = ts.shape[0]
+        sin = self.pool.get(R, enc.sinusoidal_embedding_dim)
+        native.sinusoidal(ts, enc.sinusoidal_embedding_dim, sin)
         e1 = self.linear(sin, l1)
         self.pool.put(sin)
-        e1s = self.pool.get(B, l1.N)
+        e1s = self.pool.get(R, l1.N)
         native.silu(e1, e1s)
-        te = self.linear(e1s, l2, res=res)
+        if table and res is not None:
+            _expect(l2.lora is None, "RangeEncoder Linear with LoRAs in table mode")
+            te = self.pool.get(R, l2.N)
+            native.gemm([(e1s, self.kblocked(l2.w))], te, bias=l2.b, rowbias=res, rows_per_group=R // res.shape[0])
+        else:
+            te = self.linear(e1s, l2, res=res)
         self.pool.put(e1)
         self.pool.put(e1s)
         return te
@@ -161,13 +180,24 @@ class UNetLowering(BlockLowering):
                 self.linear(t1s, l2, out=tte)
                 self.pool.put(t1)
                 self.pool.put(t1s)
-            temb = self._range_encoder(kids(sc[0])[1], res=tte)
-            writer = ch[1]
+            enc, res, writer = kids(sc[0])[1], tte, ch[1]
         else:  # SD1.5: Passthrough(UseContext timestep, RangeEncoder, SetContext)
             _expect(len(ch) == 3 and isa(ch[1], "RangeEncoder"), "unexpected TimestepEncoder layout")
-            temb = self._range_encoder(ch[1], res=None)
-            writer = ch[2]
+            enc, res, writer = ch[1], None, ch[2]
         _expect(isa(writer, "SetContext") and writer.context == "range_adapter", "TimestepEncoder must write context range_adapter")
+        if self.io.timesteps is not None and self.io.step_rows is not None and self.device.type != "meta" and os.environ.get("REFINERS_AMD_TIME_TABLE", "1") != "0":
+            with self.in_prologue():
+                temb = self._range_encoder(enc, res, table=True)
+                tab = self.pool.get(temb.shape[0], temb.shape[1])
+                self.pool.pin(tab)
+                native.silu(temb, tab)
+                self.pool.put(temb)
+            ctx.temb_table[writer.key] = tab
+            self.stats["time_table_rows"] = tab.shape[0]
+            if scope is not None:
+                self.batch_time_biases(scope, writer.key, tab, ctx, table=True)
+            return
+        temb = self._range_encoder(enc, res)
         ts = self.pool.get(B, temb.shape[1])
         self.pool.pin(ts)
         native.silu(temb, ts)
@@ -176,7 +206,7 @@ class UNetLowering(BlockLowering):
         if scope is not None:
             self.batch_time_biases(scope, writer.key, ts, ctx)
 
-    def batch_time_biases(self, scope: Any, key: str, src: Tensor, ctx: UNetContext) -> None:
+    def batch_time_biases(self, scope: Any, key: str, src: Tensor, ctx: UNetContext, table: bool = False) -> None:
         """Every RangeAdapter2d below `scope` computes Linear_i(SiLU(timestep embedding)) from the same [B, 1280] row pair
         (range_adapter.py:47-86): one GEMM against the row-concatenated weights instead of one 12-14 us, 2-row launch per ResidualBlock
         (19 per SDXL step); each block's conv then reads its [B, cout] column slice as `rowbias` (ld_rowbias = total width).
@@ -211,7 +241,14 @@ class UNetLowering(BlockLowering):
         total = w.shape[0]
         out = self.pool.get(ctx.B, total)
         self.pool.pin(out)
-        self.linear(src, LinSpec(w, b), out=out)
+        if table:  # `src` = the [B*S, 1280] table of the prologue: the projections of every (timestep, batch row) once per prompt, a step gathers its B rows
+            with self.in_prologue():
+                tb = self.pool.get(src.shape[0], total)
+                self.pool.pin(tb)
+                self.linear(src, LinSpec(w, b), out=tb)
+            native.gather_rows(tb, self.io.step_rows, out)
+        else:
+            self.linear(src, LinSpec(w, b), out=out)
         off = 0
         for sp in specs:
             ctx.time_table[(key, id(sp.w))] = out[:, off:off + sp.N]

@@ -514,7 +514,7 @@ class LoraSync:
         return f
 
     def scratch(self, groups: int, M: int, r: int, dtype: torch.dtype) -> Tensor:
-        return torch.empty(groups * M * r, dtype=dtype, device=self.device)
+        return torch.empty(lora_scratch_rows(groups, M, r, dtype) * r, dtype=dtype, device=self.device)
 
     def bump_op(self) -> tuple:
         return (getattr(load(), "mi355x_epoch_bump"), (self.epoch.data_ptr(),), "mi355x_epoch_bump", (self,))
@@ -524,6 +524,12 @@ class LoraSync:
 
 
 _eager_sync: dict[int, "LoraSync"] = {}
+
+
+def lora_scratch_rows(groups: int, M: int, R: int, dtype: torch.dtype) -> int:
+    """Rows of R elements the in-launch LoRA hand-off scratch needs: every group's block starts on a 128-byte line (mi355x_gemm_args.lora_t)."""
+    rb = R * (4 if dtype == torch.float32 else 2)
+    return groups * (((M * rb + 127) // 128 * 128) // rb)
 
 
 def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: int, keep: list, sync: Optional[tuple]) -> None:
@@ -550,7 +556,8 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
         ls.bump()
         sync = (ls.scratch(len(groups), a.M, R, dtype), ls.flags(len(groups), a.M), ls)
     t, flags, ls = sync
-    assert t.numel() >= len(groups) * a.M * R and t.dtype == dtype and flags.numel() >= len(groups) * ((a.M + 31) // 32) and flags.dtype == torch.int32
+    assert t.numel() >= lora_scratch_rows(len(groups), a.M, R, dtype) * R and t.dtype == dtype and t.data_ptr() % 128 == 0
+    assert flags.numel() >= len(groups) * ((a.M + 31) // 32) and flags.dtype == torch.int32
     a.lora_t, a.lora_flags, a.lora_epoch = t.data_ptr(), flags.data_ptr(), ls.epoch.data_ptr()
     keep.append((lora, t, flags, ls))
 

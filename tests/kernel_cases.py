@@ -922,6 +922,12 @@ def all_cases():
             (f"gemm_{tag}_lora1_transposed", lambda dt=dt: gemm_lora_inlaunch_case(154, 2048, 640, dt, transposed=True)),
             (f"gemm_{tag}_qkv_lora_1024x1280", lambda dt=dt: gemm_qkv_lora_case(1024, 1280, 1280, dt)),
             (f"gemm_{tag}_qkv_lora_tile4", lambda dt=dt: gemm_qkv_lora_case(512, 640, 384, dt, tile=4)),
+            # round 4: one producer per row block serves all three column groups (64-row producers under the 128 x 128 tile, 32-row ones elsewhere);
+            # odd M: the groups' t blocks start on 128-byte lines (padded group stride), rows beyond M are clamped / suppressed
+            (f"gemm_{tag}_qkv_lora_tile1_shared64", lambda dt=dt: gemm_qkv_lora_case(1024, 1280, 1280, dt, tile=1)),
+            (f"gemm_{tag}_qkv_lora_tile1_oddM", lambda dt=dt: gemm_qkv_lora_case(301, 640, 384, dt, tile=1)),
+            (f"gemm_{tag}_qkv_lora_tile2_oddM", lambda dt=dt: gemm_qkv_lora_case(77, 640, 256, dt, tile=2)),
+            (f"gemm_{tag}_lora1_oddM_tile4", lambda dt=dt: gemm_lora_inlaunch_case(333, 1280, 320, dt, tile=4)),
             (f"gemm_{tag}_ln_lora_1024x1280", lambda dt=dt: gemm_ln_lora_case(1024, 1280, 1280, dt)),
             (f"gemm_{tag}_ln_lora_tile4", lambda dt=dt: gemm_ln_lora_case(300, 640, 384, dt, tile=4)),
             (f"gemm_{tag}_ln_lora_transposed_tile3", lambda dt=dt: gemm_ln_lora_case(512, 640, 256, dt, tile=3, transposed=True)),

@@ -1078,9 +1078,12 @@ def test_layer_that_needs_the_context_store_runs_the_stock_forward_with_a_warnin
         y = fast(xx)
     assert "SkipFilter" in fast.stats["whole_fallback"] and fast.stats["fallback_nodes"] == ["<whole UNet>"]
     set_context(unet, cfg, inp, torch.float32)
-    assert torch.equal(y, unet(xx))
+    with torch.no_grad():
+        l2, mx = S.rel_err(y, unet(xx))  # the same stock forward (torch's own kernels are not bit-reproducible between calls)
+    assert l2 < 1e-5 and mx < 1e-4, (l2, mx)
     set_context(unet, cfg, inp, torch.float32)
-    assert torch.equal(y, fast(xx))  # remembered: no second lowering attempt, no second warning needed
+    l2, mx = S.rel_err(y, fast(xx))  # remembered: no second lowering attempt, no second warning needed
+    assert l2 < 1e-5 and mx < 1e-4, (l2, mx)
     # the CFG + DDIM step keeps working on such a tree as well (stock UNet forward + the native guidance / solver kernel)
     sd = CompiledSDXL(unet, num_inference_steps=cfg["num_steps"], condition_scale=cfg["condition_scale"])
     sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"])
@@ -1133,3 +1136,25 @@ def test_lora_hand_off_with_two_programs_replaying_concurrently():
         torch.cuda.synchronize()
         for i in (0, 1):
             assert torch.equal(engines[i].io.out, solo[i]), (it, i, float((engines[i].io.out.float() - solo[i].float()).abs().max()))
+
+
+def test_timestep_embedding_chain_is_a_prologue_table_in_the_sampling_loop(monkeypatch):
+    """CompiledSDXL knows the solver's timesteps: sinusoid -> Linear -> SiLU -> Linear (+ TextTimeEmbedding) -> SiLU -> the 17 RangeAdapter2d
+    projections run once per prompt for all of them (prologue), a step gathers its rows -- one launch instead of six, same numbers."""
+    cfg, unet, specs, handles, inp = build("sdxl_bare", torch.float32)
+    outs, ops = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("REFINERS_AMD_TIME_TABLE", flag)
+        sd = CompiledSDXL(unet, num_inference_steps=cfg["num_steps"], condition_scale=cfg["condition_scale"])
+        sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"])
+        a = sd.step(cfg["step"]).clone()
+        b = sd.step(cfg["step"] + 1).clone()  # another row of the table, through the captured graph
+        outs.append((a, b))
+        ops.append(sd.engine.stats["step_ops"])
+        assert (sd.engine.stats.get("time_table_rows") == 2 * cfg["num_steps"]) == (flag == "1")
+    assert ops[0] == ops[1] - 5, ops
+    for x, y in zip(outs[0], outs[1]):
+        l2, mx = S.rel_err(x, y)
+        assert l2 < 1e-6 and mx < 1e-5, (l2, mx)
+    l2, mx = S.rel_err(outs[0][0], S.golden("sdxl_bare")["x_next"])
+    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)

@@ -190,7 +190,9 @@ def test_out_of_scope_adapters_keep_working_on_the_real_refiners_tree(gpu_device
         y = fast(xx)
     assert "FreeUResidualConcatenator" in fast.stats["whole_fallback"] and fast.stats["fallback_nodes"] == ["<whole UNet>"]
     ctx()
-    assert torch.equal(y, unet(xx))
+    with torch.no_grad():
+        l2, mx = S.rel_err(y, unet(xx))  # the same stock forward (torch's own kernels are not bit-reproducible between calls)
+    assert l2 < 1e-5 and mx < 1e-4, (l2, mx)
     l2, _ = S.rel_err(y, S.golden("sdxl_bare")["unet_out"])
     assert l2 > 1e-3  # FreeU does change the output
     freeu.eject()
