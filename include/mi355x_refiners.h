@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 5
+#define MI355X_ABI_VERSION 6
 
 enum { MI355X_F32 = 0, MI355X_BF16 = 1 };
 
@@ -182,6 +182,12 @@ typedef struct {
     void* lora_t;
     int32_t* lora_flags;
     const int32_t* lora_epoch;
+    /* GroupNorm statistics of the output, for the mi355x_groupnorm call that consumes it (ResidualBlock = Conv2d -> GroupNorm -> SiLU -> Conv2d,
+       src/refiners/foundationals/latent_diffusion/unet.py:6-51: the statistics pass over the convolution's output disappears):
+       colstats_out[(m / 32) * N + n] = (sum, sum of squares) of out[32 (m / 32) .. + 31][n] AS STORED (rounded to `dtype`), float32 pairs,
+       >= ceil(M / 32) * N * 2 floats, 8-byte aligned.  Written by the epilogue (by the reduction pass when ksplit > 1), fixed summation order.
+       Needs the vectorisable epilogue, N a multiple of 16; not combinable with geglu / out_t / out_f32 / the 8-wave tile.  NULL: off. */
+    float* colstats_out;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);
@@ -286,7 +292,8 @@ typedef struct {
 int mi355x_layernorm(const mi355x_layernorm_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * mi355x_groupnorm -- NHWC GroupNorm (+ optional SiLU), three launches (partial sums, finalize, apply).
+ * mi355x_groupnorm -- NHWC GroupNorm (+ optional SiLU), three launches (partial sums, finalize, apply); TWO when the launch that
+ * produced x also wrote its column statistics (`colstats` = that launch's mi355x_gemm_args.colstats_out; HW must be a multiple of 32).
  * Replaces fl.GroupNorm (src/refiners/fluxion/layers/norm.py:49-93 -> F.group_norm) and the fl.SiLU that follows it
  * in ResidualBlock (src/refiners/foundationals/latent_diffusion/unet.py:29-44) / OutputBlock.
  * x, out: [B][HW][C] with pixel stride ldx / ldo.  `ws` is float scratch of at least mi355x_groupnorm_ws_floats()
@@ -304,6 +311,7 @@ typedef struct {
     void* out;
     int64_t ldo;
     float* ws;
+    const float* colstats; /* [B * HW / 32][C][2] (sum, sum of squares) per 32-pixel block, or NULL (statistics are then computed from x) */
 } mi355x_groupnorm_args;
 
 int64_t mi355x_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C);

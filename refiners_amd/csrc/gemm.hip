@@ -180,6 +180,10 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         if (a->conv || a->ksplit > 1 || a->geglu == 1 || has_t || !vec || a->N % 64 || (reinterpret_cast<uintptr_t>(a->stats_out) & 7)) return MI355X_ESHAPE;
         p.stats_out = static_cast<float*>(a->stats_out);
     }
+    if (a->colstats_out) {
+        if (a->geglu == 1 || has_t || a->out_f32 || !vec || a->N % 16 || a->tile == 6 || (reinterpret_cast<uintptr_t>(a->colstats_out) & 7)) return MI355X_ESHAPE;
+        p.colstats = a->colstats_out;
+    }
     for (int i = 0; i < MI355X_MAX_PREFETCH; ++i) {
         p.pf_ptr[i] = static_cast<const char*>(a->prefetch[i]);
         p.pf_bytes[i] = a->prefetch[i] ? a->prefetch_bytes[i] : 0;

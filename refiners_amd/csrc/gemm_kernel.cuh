@@ -90,6 +90,8 @@ struct GemmP {
     const float* ln_s;  // [N]: sum_k W'[n][k]
     const float* ln_c;  // [N]: sum_k beta[k] W[n][k] (+ bias[n])
     float* stats_out;   // [N / 32][M][2], or NULL
+    float* colstats;    // GroupNorm statistics of the output (producer side): [ceil(M / 32)][N][2] = per (32-row block, column) (sum, sum of squares)
+                        // of the values AS STORED, rows beyond M excluded; or NULL
     int out_f32;        // store `out` as float32 (scores for mi355x_softmax_rows)
     // LoRA inside the launch: per column group g (columns >= lora_nb[g]) the K-blocked stacked down rows, [K blocks][lora_r][128 B];
     // lora_b: [N][lora_r] pre-scaled up-projections (row n = output column n), row-major
@@ -103,8 +105,7 @@ struct GemmP {
     char* lora_t;          // [groups][M][lora_r] of T: the producers' t = x A^T (already divided by rstd when LayerNorm is folded in)
     int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
     const int* lora_epoch;
-    int lp_blocks;         // producer workgroups at the head of the grid (rounded up to a multiple of 8)
-    int lp_nrb, lp_shared; // producer geometry (lora_plan): 16-row blocks per producer; one producer per row block serves every column group
+    int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
     int64_t lora_gs;       // bytes from one group's t to the next: M * lora_r * sizeof(T) rounded up to 128 (a 128-byte line never holds two groups' rows)
     int lora_dbg;          // probing only (mi355x_set_option "lora_dbg", tools/probe_lora.py; timing, not results): 1 = producers exit at once (valid only
                            // while the flags still hold the epoch), 4 = tiles skip the LoRA term entirely, 8 = in-loop hand-off but no product, 16 = product but no hand-off
@@ -128,6 +129,32 @@ MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, flo
     }
 }
 
+// Column sums over the 16 lanes of a lane group (lane c16 = one row): a[e], b[e] hold this lane's contribution to column e of RUN; on return
+// lane c16 holds the 16-lane totals of column `c16 % RUN` in a[0], b[0].  Recursive halving: each exchange adds the partner's half and keeps
+// half of the columns (RUN = 8: one full exchange first, the two 8-lane halves then end with the same totals), 15 / 14 shuffles per
+// quantity instead of 64 for an all-reduce, a fixed tree (deterministic).
+template <int RUN> MI_DEV void colsum16(float (&a)[RUN], float (&b)[RUN], int c16) {
+    static_assert(RUN == 8 || RUN == 16, "8 or 16 columns per lane");
+    if constexpr (RUN == 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] += __shfl_xor(a[e], 8);
+            b[e] += __shfl_xor(b[e], 8);
+        }
+    }
+#pragma unroll
+    for (int w = (RUN == 16 ? 8 : 4); w >= 1; w >>= 1) {  // w = lane-bit mask of this exchange = number of columns kept
+        const bool up = (c16 & w) != 0;
+#pragma unroll
+        for (int e = 0; e < w; ++e) {
+            const float sa = up ? a[e] : a[e + w], sb = up ? b[e] : b[e + w];
+            const float ka = up ? a[e + w] : a[e], kb = up ? b[e + w] : b[e];
+            a[e] = ka + __shfl_xor(sa, w);
+            b[e] = kb + __shfl_xor(sb, w);
+        }
+    }
+}
+
 constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
 constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)
 constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch (control-lora-*-rank128)
@@ -137,41 +164,37 @@ constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch 
 MI_DEV void st_agent8(void* p, uint64_t v) { __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- LoRA producer ---------------------------------------------------------------------------------------------------------------
-// t[g][m0 .. m0 + 16 NRB)[0 .. R) = x A_g^T for one block of 16 NRB rows (NRB = 2 or 4), called at the very top of gemm_kernel by the workgroups
-// at the head of a LoRA launch's grid.  Round 4: the operands stream through REGISTERS, not through the tile's LDS ring.  The loop is
-// latency-bound (R / BN of a tile's MFMAs on a fraction of its rows), so what sets a producer's duration is the number of K blocks it keeps
-// in flight; an LDS ring cut out of the tile's allocation gave 3 (64 x 64 tiles: 32 KB) to 7, and serving the three column groups of a
-// Q|K|V launch from one x stage halved that again (round 3: 192 short producers in front of 480 tiles that filled the resident slots
-// exactly, +8.6 us per launch).  Here every wave owns one (row block, NKB rank blocks) product and loads ITS OWN fragments straight into MFMA
-// operand layout -- a 16-row x 64-byte piece per load instruction, lane (g, c16) = (chunk, row) -- U K blocks ahead, register sets rotated by
-// full unrolling: no LDS, no barrier, no cross-wave coupling inside the loop, the compiler's in-order vmcnt bookkeeping is exact (straight-line
-// body, loads never conditional: blocks past the end re-read the last one and their MFMAs are skipped).  Fragment-shaped loads cost
-// the texture path twice a full-line load (microarchitecture guide) -- irrelevant at 1 / 40 of a tile's bytes.
-// Column groups that share x (every group of a launch reads segment 0) are served by ONE producer per row block (`shared`): the rank blocks
-// of all groups are spread over the waves, x is read once per producer: 64 rows x 3 groups = 32 producers for a CFG pair's Q|K|V^T.
+// t[m0 .. m0 + 32)[0 .. R) = x A_g^T for one (column group, 32-row block), R = 32 RI.  A SEPARATE, non-inlined function called at the very
+// top of gemm_kernel by the workgroups at the head of a LoRA launch's grid: compiled on its own, it does not touch the register allocation
+// or the instruction stream of the tiles' path (inlined, its mere presence cost every tile ~0.8 us: profiles/r03_g_bisect.log).
+// The loop is latency-bound (R / BN of a tile's MFMAs on a quarter of its rows), so the workgroup's LDS ring is re-cut into PST <= 8 stages of
+// (32 x rows + R weight rows) x 128 B, PST - 1 K blocks in flight.  Own loader: one 16-byte piece of x per thread and K block (plain rows,
+// K-blocked rows, or the taps of a convolution gathered from the NHWC image) + RI pieces of the stacked down rows (always K-blocked:
+// [K blocks][R][128 B]; LDS row r = rank r).  Wave w multiplies row block w & 1 against the RI rank blocks (w >> 1) RI ...
 // LayerNorm folded in -> what is published is t / rstd = (x A'^T - mean sA) + cA / rstd (the tile epilogue's rstd * (acc - mean s) + c then
 // scales the up-projected product back: one rounding of t, as in the reference); (mean, M2) of a row = the producer launch's 32-column
-// partials Chan-merged in index order.  t is rounded to T, written through to L2 (8-byte agent-scope stores), then the flags of the block's
-// 32-row halves, one per group.
-template <typename T, bool CONV, int NRB, int NKB, int U>
+// partials Chan-merged in index order.  t is rounded to T, written through to L2 (8-byte agent-scope stores), then the block's flag.
+// (Round 4 tried the opposite design -- operands streamed straight into MFMA fragment layout through registers, 2-6 K blocks in flight per
+//  wave, no LDS, no barrier, one producer per row block serving all column groups: correct, and 1.3-2x SLOWER per launch (N = K = 1280:
+//  27.0 vs 17.5 us; Q|K|V^T 62.6 vs 40.2; step 31.05 vs 25.9 ms, profiles/r04_b_*): beside tiles that keep the CU's vector-memory queue full a
+//  producer pays 2-3 us per dependent round trip whatever it asks for, and fragment-shaped loads put 4x the lines through that queue.)
+template <typename T, bool CONV, int RI, int PST>
 __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
-    static_assert((NRB == 2 || NRB == 4) && NKB >= 1 && U >= 2, "LoRA producer geometry");
-    constexpr int PM = 16 * NRB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTHR = 256, PXB = LORA_PM * 128, PSTAGE = PXB + 32 * RI * 128, PD = PST - 1, PL = 1 + RI;
+    static_assert(PST >= 2 && PST <= 8, "LoRA producer: 2..8 stages");
     const int tid = threadIdx.x, lane = tid & 63, wid = wave_id(), g = lane >> 4, c16 = lane & 15;
-    const int rbg = p.lora_r >> 4;                                   // rank blocks per group
-    const int ngr = p.lp_shared ? p.lora_groups : 1;                 // groups served by this workgroup
-    const int npb = (p.M + PM - 1) / PM;
-    const int pg0 = p.lp_shared ? 0 : q / npb, tm = p.lp_shared ? q : q - pg0 * npb, m0 = tm * PM;
+    const int npb = (p.M + LORA_PM - 1) / LORA_PM;
+    const int pgi = q / npb, tm = q - pgi * npb, m0 = tm * LORA_PM;
     const int tag = *p.lora_epoch;
+    if (p.lora_dbg & 32) __builtin_amdgcn_s_setprio(3);  // (probing: producers' instructions win the CU's issue arbitration against co-resident tiles)
     const SegP& sp = p.seg[0];  // the LoRAs adapt segment 0 (the conv / Linear itself, not a fused shortcut)
     const int nkb = sp.nkb;
-    // this wave's product: row block rb x rank blocks [k0, k0 + NKB) of the ngr * rbg this workgroup owes (host: ngr * rbg * NRB == 4 * NKB)
-    const int rb = wid % NRB, k0 = (wid / NRB) * NKB;
-    const int m = m0 + 16 * rb + c16;
-    const bool xvalid = m < p.M;
-    const int xm = xvalid ? m : p.M - 1;
-    // ---- x fragments: row xm, chunks 4 kk + g of K block kb ----
-    const char* xrow = nullptr;
+    // ---- this thread's piece of the x tile: row tid >> 3, logical chunk tid & 7 (swizzled source chunk, lane-linear LDS image) ----
+    const int row = tid >> 3, pch = tid & 7;
+    const int xcoff = (pch ^ swz<128>(row)) << 4;
+    const bool xvalid = m0 + row < p.M;
+    const int xm = xvalid ? m0 + row : p.M - 1;
     int xb = 0, xoy = 0, xox = 0;
     if constexpr (CONV) {
         const int ohw = p.OH * p.OW;
@@ -179,13 +202,13 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
         const int rem = xm - xb * ohw;
         xoy = rem / p.OW;
         xox = rem - xoy * p.OW;
-    } else {
-        xrow = sp.x + (sp.xkb ? (int64_t)xm * 128 : (int64_t)xm * sp.ldxb) + g * 16;
     }
-    const int64_t xstep = sp.xkb ? (int64_t)p.M * 128 : 128;
-    int ltap = 0, lcb = 0;  // conv: tap / block-in-tap of the NEXT block to load
-    auto conv_ptr = [&]() __attribute__((always_inline)) -> const char* {
-        int dy = ltap / sp.ksize, dx = ltap - dy * sp.ksize;
+    const char* xbase = nullptr;
+    int64_t xoff = 0, woff = 0;
+    const int64_t xstep = CONV ? 128 : (sp.xkb ? (int64_t)p.M * 128 : 128), wstep = (int64_t)p.lora_r * 128;
+    int tap = 0, cb = 0;
+    auto set_tap = [&]() __attribute__((always_inline)) {
+        int dy = tap / sp.ksize, dx = tap - dy * sp.ksize;
         dy -= sp.pad;
         dx -= sp.pad;
         const int iy = xoy * sp.stride + dy, ix = xox * sp.stride + dx;
@@ -193,106 +216,97 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
         const bool ok = xvalid && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
         const int sy = iy >> sp.ups_shift, sx = ix >> sp.ups_shift;
         const int64_t pix = ((int64_t)xb * sp.H + sy) * sp.W + sx;
-        return ok ? sp.x + pix * sp.ldxb + (int64_t)lcb * 128 + g * 16 : p.zeros + g * 16;
+        xbase = ok ? sp.x + pix * sp.ldxb + xcoff : nullptr;
     };
-    // ---- A fragments: rank row 16 (k0 + j) + c16 of its group, K-blocked [K block][R][128 B] ----
-    const char* arow[NKB];
+    if constexpr (CONV) set_tap();
+    else xbase = sp.x + (sp.xkb ? (int64_t)xm * 128 : (int64_t)xm * sp.ldxb) + xcoff;
+    const char* pw[RI];
 #pragma unroll
-    for (int j = 0; j < NKB; ++j) {
-        const int k = k0 + j, gi = pg0 + k / rbg, r = (k - (k / rbg) * rbg) * 16 + c16;
-        arow[j] = p.lora_a[gi < p.lora_groups ? gi : 0] + (int64_t)r * 128 + g * 16;
+    for (int j = 0; j < RI; ++j) {
+        const int qq = j * NTHR + tid, r = qq >> 3, c = qq & 7;
+        pw[j] = p.lora_a[pgi] + (int64_t)r * 128 + ((c ^ swz<128>(r)) << 4);
     }
-    const int64_t astep = (int64_t)p.lora_r * 128;
-    frag_t xq[U][2], aq[U][NKB][2];
-    int lkb = 0;  // next K block to load (clamped: blocks past the end re-read the last one, nothing is conditional in the load stream)
-    auto load_block = [&](frag_t(&xf)[2], frag_t(&af)[NKB][2]) __attribute__((always_inline)) {
-        const int kb = lkb < nkb ? lkb : nkb - 1;
-        const char* xs;
-        if constexpr (CONV) xs = conv_ptr();
-        else xs = xrow + (int64_t)kb * xstep;
-        xf[0] = *reinterpret_cast<const frag_t*>(xs);
-        xf[1] = *reinterpret_cast<const frag_t*>(xs + 64);
+    int kb = 0;
+    auto issue_p = [&](int buf) __attribute__((always_inline)) {
+        char* st = smem + buf * PSTAGE;
+        const char* src;
+        if constexpr (CONV) src = xbase ? xbase + (int64_t)cb * 128 : p.zeros + xcoff;
+        else src = xbase + xoff;
+        glds16(src, st + wid * 64 * 16);
 #pragma unroll
-        for (int j = 0; j < NKB; ++j) {
-            const char* as = arow[j] + (int64_t)kb * astep;
-            af[j][0] = *reinterpret_cast<const frag_t*>(as);
-            af[j][1] = *reinterpret_cast<const frag_t*>(as + 64);
-        }
-        if (lkb < nkb - 1) {
-            ++lkb;
-            if constexpr (CONV) {
-                if (++lcb == sp.cpb) {
-                    lcb = 0;
-                    ++ltap;
-                }
+        for (int j = 0; j < RI; ++j) glds16(pw[j] + woff, st + PXB + (j * NTHR + wid * 64) * 16);
+        ++kb;
+        woff += wstep;
+        if constexpr (CONV) {
+            if (++cb == sp.cpb) {
+                cb = 0;
+                ++tap;
+                if (kb < nkb) set_tap();
             }
+        } else {
+            xoff += xstep;
         }
     };
-    // ---- LayerNorm folded in: (mean, 1 / rstd) of this lane's row.  The partials are requested BEFORE the first blocks (one round trip, overlapped
-    // with theirs; a serial load-merge chain would be ln_parts dependent L2 round trips at the head of every producer) ----
+    // ---- LayerNorm folded in: (mean, 1 / rstd) of this lane's row 16 rb + c16.  The producer launch's 32-column partials are requested
+    // BEFORE the first stages and merged after their issue: one round trip, overlapped with the stages' (a serial load-merge chain
+    // would be ln_parts dependent L2 round trips at the head of every producer).
+    const int rb = wid & 1, rg = wid >> 1;
+    const int mrow = 16 * rb + c16, m = m0 + mrow;
     float mean = 0.f, inv = 1.f;
-    // the four lane groups of a wave hold the same 16 rows: group g takes the partials g, g + 4, ... (a quarter of the registers a full copy
-    // per lane would hold next to the U blocks in flight), the groups are Chan-merged with two exchanges, lower group first on both sides
-    constexpr int MAXQ = 12;  // partials per lane held in registers at once (K <= 1536 in one batch)
-    f32x2 lst[MAXQ];
-    const float* sp2 = p.ln_stats ? p.ln_stats + (int64_t)xm * 2 : nullptr;
+    constexpr int MAXP = 48;  // partials held in registers at once (K <= 1536 in one batch)
+    f32x2 lst[MAXP];
+    const float* sp2 = p.ln_stats ? p.ln_stats + (int64_t)min(m, p.M - 1) * 2 : nullptr;
     const int64_t pstride = (int64_t)p.M * 2;
     if (sp2) {
 #pragma unroll
-        for (int i = 0; i < MAXQ; ++i) lst[i] = g + 4 * i < p.ln_parts ? *reinterpret_cast<const f32x2*>(sp2 + (g + 4 * i) * pstride) : f32x2{0.f, 0.f};
+        for (int i = 0; i < MAXP; ++i) lst[i] = i < p.ln_parts ? *reinterpret_cast<const f32x2*>(sp2 + i * pstride) : f32x2{0.f, 0.f};
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) load_block(xq[u], aq[u]);
+    for (int s0 = 0; s0 < PD; ++s0)
+        if (s0 < nkb) issue_p(s0);
     if (sp2) {
         float m2 = 0.f, cn = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXQ; ++i)
-            if (g + 4 * i < p.ln_parts) stat_merge(cn, mean, m2, 32.f, lst[i][0], lst[i][1]);
-        for (int part = g + 4 * MAXQ; part < p.ln_parts; part += 4) {  // wider rows: the slow way
+        for (int i = 0; i < MAXP; ++i)
+            if (i < p.ln_parts) stat_merge(cn, mean, m2, 32.f, lst[i][0], lst[i][1]);
+        for (int part = MAXP; part < p.ln_parts; ++part) {  // wider rows: the slow way
             const f32x2 s2 = *reinterpret_cast<const f32x2*>(sp2 + part * pstride);
             stat_merge(cn, mean, m2, 32.f, s2[0], s2[1]);
         }
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const float nb = __shfl_xor(cn, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
-            if (lane & o) {
-                float n2 = nb, me2 = mb, q2 = qb;
-                stat_merge(n2, me2, q2, cn, mean, m2);
-                cn = n2, mean = me2, m2 = q2;
-            } else {
-                stat_merge(cn, mean, m2, nb, mb, qb);
-            }
-        }
         inv = sqrtf(m2 / cn + p.ln_eps);  // 1 / rstd
     }
-    f32x4 ta[NKB];
+    f32x4 ta[RI];
 #pragma unroll
-    for (int j = 0; j < NKB; ++j) ta[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int t0 = 0; t0 < nkb; t0 += U) {
+    for (int j = 0; j < RI; ++j) ta[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nkb; ++t) {
+        if (t + PD <= nkb) wait_vm<(PD - 1) * PL>();  // block t has landed, the PD - 1 younger ones stay in flight
+        else wait_vm0();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + PD < nkb) issue_p((t + PD) % PST);  // into the buffer block t - 1 was read from (every wave retired those reads above)
+        const char* st = smem + (t % PST) * PSTAGE;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (t0 + u < nkb) {  // wave-uniform
+        for (int kk = 0; kk < 2; ++kk) {
+            const frag_t xf = lds_read_frag(st, tile_off<128>(16 * rb + c16, 4 * kk + g));
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int j = 0; j < NKB; ++j) mma_step<T>(ta[j], aq[u][j][kk], xq[u][kk]);  // D[rank 16 (k0 + j) + 4 g + r][row 16 rb + c16]
+            for (int j = 0; j < RI; ++j) {
+                const frag_t af = lds_read_frag(st + PXB, tile_off<128>((rg * RI + j) * 16 + c16, 4 * kk + g));
+                mma_step<T>(ta[j], af, xf);  // D[rank 16 (rg RI + j) + 4 g + r][row 16 rb + c16]
             }
-            load_block(xq[u], aq[u]);  // block t0 + u + U into the set just consumed
         }
     }
-    const int64_t gs = p.lora_gs;
+    char* tg = p.lora_t + pgi * p.lora_gs;
 #pragma unroll
-    for (int j = 0; j < NKB; ++j) {
-        const int k = k0 + j, gl = k / rbg, gi = pg0 + gl, r0 = (k - gl * rbg) * 16 + 4 * g;
+    for (int j = 0; j < RI; ++j) {
+        const int r0 = (rg * RI + j) * 16 + 4 * g;
         f32x4 v = ta[j];
         if (p.ln_stats) {
-            const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + gi * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + gi * p.lora_r + r0);
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + pgi * p.lora_r + r0), ca = *reinterpret_cast<const f32x4*>(p.lora_lc + pgi * p.lora_r + r0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean * sa[e]) + ca[e] * inv;
         }
-        if (xvalid && gi < p.lora_groups) {
-            char* dst = p.lora_t + gi * gs + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
+        if (m < p.M) {
+            char* dst = tg + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
             if constexpr (sizeof(T) == 4) {
                 st_agent8(dst, __builtin_bit_cast(uint64_t, f32x2{v[0], v[1]}));
                 st_agent8(dst + 8, __builtin_bit_cast(uint64_t, f32x2{v[2], v[3]}));
@@ -304,23 +318,7 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
     __syncthreads();
-    // one flag per (group, 32 rows): lanes 0 .. ngr * NRB / 2 - 1 of wave 0
-    if (tid < ngr * (NRB / 2)) {
-        const int gl = tid / (NRB / 2), h = tid - gl * (NRB / 2), fb = m0 / LORA_PM + h, nfl = (p.M + LORA_PM - 1) / LORA_PM;
-        if (fb < nfl) __hip_atomic_store(p.lora_flags + (pg0 + gl) * nfl + fb, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Producer geometry of a launch (host and device agree through GemmP::lp_nrb / lp_shared): `big` = the 128 x 128 tile's register budget.
-// shared (one producer per row block serves every column group): groups x R / 16 = 4 or 6 rank blocks in all; else one producer per (group, row block).
-struct LoraPlan {
-    int nrb, shared, nkb;
-};
-inline LoraPlan lora_plan(int groups, int R, bool big) {
-    const int rbk = groups * (R / 16);
-    if (groups > 1 && rbk == 6) return big ? LoraPlan{4, 1, 6} : LoraPlan{2, 1, 3};
-    if (groups > 1 && rbk == 4) return LoraPlan{2, 1, 2};
-    return LoraPlan{2, 0, R / 32};
+    if (tid == 0) __hip_atomic_store(p.lora_flags + pgi * npb + tm, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Waves per SIMD the register allocation must leave room for.  Left to itself (launch bounds only) the compiler spreads the LoRA instantiations
@@ -384,26 +382,13 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     int bid = (int)blockIdx.x - p.pf_blocks;
     if constexpr (LORA) {
         if (bid < p.lp_blocks) {  // LoRA producer role: see lora_producer (a separate function; nothing of it lives in the tiles' path)
-            constexpr int PM_ = 16;
-            const int nprod = (p.M + PM_ * p.lp_nrb - 1) / (PM_ * p.lp_nrb) * (p.lp_shared ? 1 : p.lora_groups);
-            if ((p.lora_dbg & 1) || bid >= nprod) return;  // (probing) / padding up to a multiple of 8
-            // K blocks in flight per wave, by the register budget of this tile's instantiation (gemm_min_waves): 16 + 8 NKB registers per block
-            constexpr bool BIG = BM * BN == 128 * 128, SMALL = BM * BN == 64 * 64;
-            const int nkb_w = (p.lp_shared ? p.lora_groups : 1) * (p.lora_r >> 4) * p.lp_nrb / 4;
-            // (a convolution's producers carry the tap arithmetic as well and never serve more than one group: shallower sets, no shared variants)
-            if constexpr (!CONV) {
-                if (p.lp_nrb == 4) {
-                    if constexpr (BIG) lora_producer<T, false, 4, 6, 3>(p, bid);
-                    return;
-                }
-                if (nkb_w == 3) {
-                    lora_producer<T, false, 2, 3, (SMALL ? 2 : BIG ? 5 : 3)>(p, bid);
-                    return;
-                }
-            }
-            if (nkb_w == 1) lora_producer<T, CONV, 2, 1, (SMALL || CONV ? 4 : 6)>(p, bid);
-            else if (nkb_w == 2) lora_producer<T, CONV, 2, 2, (SMALL || (CONV && !BIG) ? 3 : BIG && !CONV ? 6 : 4)>(p, bid);
-            else if constexpr (BN == 128) lora_producer<T, CONV, 2, 4, (BIG ? (CONV ? 3 : 4) : 2)>(p, bid);  // (the host routes rank-128 launches to the 128-column tiles)
+            if ((p.lora_dbg & 1) || bid >= (p.M + LORA_PM - 1) / LORA_PM * p.lora_groups) return;  // (probing) / padding up to a multiple of 8
+            constexpr int RING = KG * NSTAGE * (BM + BN) * 128;
+            constexpr int PB1 = (LORA_PM + 32) * 128, PB2 = (LORA_PM + 64) * 128, PB4 = (LORA_PM + 128) * 128;  // bytes per producer stage
+            constexpr int P1 = RING / PB1 < 8 ? RING / PB1 : 8, P2 = RING / PB2 < 8 ? RING / PB2 : 8, P4 = RING / PB4;
+            if (p.lora_r == 32) lora_producer<T, CONV, 1, P1>(p, bid);
+            else if (p.lora_r == 64) lora_producer<T, CONV, 2, P2>(p, bid);
+            else if constexpr (P4 >= 2) lora_producer<T, CONV, 4, (P4 < 8 ? P4 : 8)>(p, bid);  // (the host routes rank-128 launches to the 128-column tiles)
             return;
         }
         bid -= p.lp_blocks;
@@ -960,6 +945,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         }
         return;
     }
+    float cs_a[RUN], cs_b[RUN];  // GemmP::colstats: the even row of the current 32-row block
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int mrow = wm * WME + 16 * i + c16;
@@ -967,7 +953,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         // rows beyond M keep going through the arithmetic when statistics are produced (the shuffles below need all lanes);
         // their stores are suppressed
         const bool mok = m < p.M;
-        if (!mok && !p.stats_out) continue;
+        if (!mok && !p.stats_out && !p.colstats) continue;
         float v[RUN];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -1055,11 +1041,34 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
                     if (mok) store16<T>(op + c * EPC, ov);
-                    if (p.stats_out) {
+                    if (p.stats_out || p.colstats) {
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) {
                             v[c * EPC + e] = ov.get(e);
                             rs += ov.get(e);
+                        }
+                    }
+                }
+                if (p.colstats) {
+                    // GroupNorm statistics for the consumer of this tensor: (sum, sum of squares) per column over each 32-row block = the two
+                    // 16-row MMA blocks 2h, 2h + 1 of this wave (i even: remember the row, i odd: add, reduce over the 16 lanes, store)
+                    if ((i & 1) == 0) {
+#pragma unroll
+                        for (int e = 0; e < RUN; ++e) {
+                            cs_a[e] = mok ? v[e] : 0.f;
+                            cs_b[e] = mok ? v[e] * v[e] : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < RUN; ++e) {
+                            cs_a[e] += mok ? v[e] : 0.f;
+                            cs_b[e] += mok ? v[e] * v[e] : 0.f;
+                        }
+                        colsum16<RUN>(cs_a, cs_b, c16);
+                        const int blk = (m0 + wm * WME + 16 * (i - 1)) >> 5;  // (tiles start on multiples of 64 rows)
+                        if ((RUN == 16 || c16 < 8) && (blk << 5) < p.M) {
+                            f32x2 st = {cs_a[0], cs_b[0]};
+                            *reinterpret_cast<f32x2*>(p.colstats + ((int64_t)blk * p.N + n + (c16 & (RUN - 1))) * 2) = st;
                         }
                     }
                 }
@@ -1107,39 +1116,73 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     }
 }
 
-// out[m][n] = dtype( sum_s partial[s][m][n] (fixed order) + bias[n] + rowbias[m / rpg][n] + res[m][n] ): 4 columns per thread
+// out[m][n] = dtype( sum_s partial[s][m][n] (fixed order) + bias[n] + rowbias[m / rpg][n] + res[m][n] ).  One workgroup = 32 rows x 256 columns:
+// thread (ty, tx) = (t >> 6, t & 63) walks rows 8 ty .. 8 ty + 7 of the block at columns 4 tx .. 4 tx + 3, so the per-column sums GemmP::colstats asks
+// for are 8 local adds + one fixed-order exchange of the four row groups through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
-    const int nq = (p.N + 3) / 4;
-    const int64_t total = (int64_t)p.M * nq;
+    __shared__ float red[3][64][8];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int nbx = (p.N + 255) / 256;
+    const int bm = blockIdx.x / nbx, bn = blockIdx.x - bm * nbx;
+    const int n = bn * 256 + tx * 4;
     T* out = reinterpret_cast<T*>(p.out);
     const T* bias = reinterpret_cast<const T*>(p.bias);
     const T* rowbias = reinterpret_cast<const T*>(p.rowbias);
     const T* res = reinterpret_cast<const T*>(p.res);
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
-        const int m = (int)(q / nq);
-        const int n = (int)(q - (int64_t)m * nq) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool full4 = n + 4 <= p.N;
-        for (int s = 0; s < p.ksplit; ++s) {
-            const float* pp = p.partial + ((int64_t)s * p.M + m) * p.N + n;
-            if (full4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(pp);
-                v[0] += t[0], v[1] += t[1], v[2] += t[2], v[3] += t[3];
-            } else {
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) v[r] += pp[r];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full4 = n + 4 <= p.N;
+    if (n < p.N) {
+#pragma unroll 2
+        for (int r = 0; r < 8; ++r) {
+            const int m = bm * 32 + ty * 8 + r;
+            if (m >= p.M) break;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.ksplit; ++s) {
+                const float* pp = p.partial + ((int64_t)s * p.M + m) * p.N + n;
+                if (full4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(pp);
+                    v[0] += t[0], v[1] += t[1], v[2] += t[2], v[3] += t[3];
+                } else {
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < p.N) v[q] += pp[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nn = n + q;
+                if (nn >= p.N) break;
+                float val = v[q];
+                if (bias) val += to_f32(bias[nn]);
+                if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
+                if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
+                if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
+                const T o = from_f32<T>(val);
+                out[(int64_t)m * p.ldo + nn] = o;
+                const float f = to_f32(o);
+                s1[q] += f;
+                s2[q] += f * f;
             }
         }
-        for (int r = 0; r < 4; ++r) {
-            const int nn = n + r;
-            if (nn >= p.N) break;
-            float val = v[r];
-            if (bias) val += to_f32(bias[nn]);
-            if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
-            if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
-            if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
-            out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
+    }
+    if (p.colstats) {  // (workgroup-uniform)
+        if (ty > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                red[ty - 1][tx][q] = s1[q];
+                red[ty - 1][tx][4 + q] = s2[q];
+            }
+        }
+        __syncthreads();
+        if (ty == 0 && n < p.N) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (n + q >= p.N) break;
+                const float a = ((s1[q] + red[0][tx][q]) + red[1][tx][q]) + red[2][tx][q];
+                const float b = ((s2[q] + red[0][tx][4 + q]) + red[1][tx][4 + q]) + red[2][tx][4 + q];
+                f32x2 st = {a, b};
+                *reinterpret_cast<f32x2*>(p.colstats + ((int64_t)bm * p.N + n + q) * 2) = st;
+            }
         }
     }
 }
@@ -1205,22 +1248,13 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
     q.pf_mode = g_pf_mode;
     q.lora_dbg = g_lora_dbg;
-    if constexpr (LORA) {  // LoRA producers, ahead of every tile in dispatch order
-        const LoraPlan lp = lora_plan(q.lora_groups, q.lora_r, BM * BN == 128 * 128);
-        q.lp_nrb = lp.nrb;
-        q.lp_shared = lp.shared;
-        q.lp_blocks = ((q.M + 16 * lp.nrb - 1) / (16 * lp.nrb) * (lp.shared ? 1 : q.lora_groups) + 7) / 8 * 8;
-    } else {
-        q.lp_blocks = 0;
-    }
+    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
     const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), q.ln_stats ? LDS : LDS - BM * 8, stream, q);
     if (q.ksplit > 1) {
-        const int64_t work = (int64_t)q.M * ((q.N + 3) / 4);
-        int64_t rb = (work + 255) / 256;
-        if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((int)rb), dim3(256), 0, stream, q);
+        const int rb = ((q.M + 31) / 32) * ((q.N + 255) / 256);
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb), dim3(256), 0, stream, q);
     }
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
@@ -1229,13 +1263,15 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
 //                       6: 128x128 with two K groups (8 waves, intra-workgroup split-K)
 // (5: 256x128 with 8 lockstep waves and 7 / 8: the same tile with its two 4-wave groups one barrier slot apart were measured level with
 //  or behind two co-resident 128x128 workgroups on every shape of the step -- profiles/r02_i_probe_tiles.log, r02_g_autotune_merged.log --
-//  and removed in round 3.)
+//  and removed in round 3.  Round 4 re-tried the one-workgroup-per-CU idea with 128 x 64 WAVE tiles (fewer LDS reads per MFMA): 256x128 and
+//  128x256 with 4 waves and a 3-deep ring, 256x256 with 8 waves -- behind the 128x128 tile on every shape of the step, level on a hot 4096^3
+//  (profiles/r04_a_probe_tiles.log, which is also the hipBLASLt yardstick of this core); not kept.)
 // The UNet's GEMMs are small for a 256-CU chip (2048x1280 outputs = 160 tiles of 128x128), so the choice is driven by
 // how many workgroups a configuration yields: big tiles reuse operands better, small tiles fill the machine.  The engine
 // passes measured choices per shape (refiners_amd/engine/tuning.py); this heuristic is the fallback.
 inline int pick_tile(const GemmP& p, bool conv) {
-    if (g_tile >= 1 && g_tile <= 8) return g_tile;
-    if (p.tile_hint >= 1 && p.tile_hint <= 8) return p.tile_hint;
+    if ((g_tile >= 1 && g_tile <= 4) || g_tile == 6) return g_tile;
+    if ((p.tile_hint >= 1 && p.tile_hint <= 4) || p.tile_hint == 6) return p.tile_hint;
     const int64_t b128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (conv) return 3;  // 64 x 128 wins for every conv shape of the UNet (r01_b probe: 339 / 540 / 570 TF at 32^2 / 64^2 / 128^2)
     if (p.geglu) return 1;
@@ -1275,12 +1311,6 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
                 default: return launch_cfg<T, 128, 128, 2, 2, false, 2, 1, true>(p, stream);
             }
         }
-    }
-    if constexpr (!CONV && sizeof(T) == 2) {
-        // one-workgroup-per-CU tiles (round 4): more FLOP per byte staged into LDS AND per byte read back from it (128 x 64 wave tiles)
-        if (tile == 5) return launch_cfg<T, 256, 128, 2, 2, false, 3>(p, stream);  // 4 waves, 144 KB ring
-        if (tile == 7) return launch_cfg<T, 256, 256, 2, 4, false, 2>(p, stream);  // 8 waves, 128 KB ring
-        if (tile == 8) return launch_cfg<T, 128, 256, 2, 2, false, 3>(p, stream);  // 4 waves, 64 x 128 wave tiles
     }
     switch (tile) {
         case 1: return launch_stages<T, 128, 128, CONV>(p, st, stream);

@@ -222,6 +222,75 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
     }
 }
 
+// The same table from the PRODUCER's column statistics (mi355x_gemm_args.colstats_out: (sum, sum of squares) per 32-pixel block and channel,
+// written by the epilogue of the convolution / GEMM that produced x): no pass over x at all.  One workgroup per (group, sample); thread t
+// takes channel t % cg and the blocks t / cg, t / cg + L, ... (eight independent loads in flight), fixed-order tree; the raw moments are
+// turned into (mean, M2) per channel in double (the subtraction S2 - S1^2 / n is where float32 would lose digits), groups merged like above.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __restrict__ cs, int HW, int C, int G, const T* __restrict__ gamma, float eps,
+                                                              float* __restrict__ tab) {
+    __shared__ float red[256 * 2];
+    __shared__ double mean_c[256], m2_c[256];
+    __shared__ float stat[2];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cg = C / G, nblk = HW / 32;
+    const int L = 256 / cg;
+    const int t = threadIdx.x;
+    const int j = t / cg, cl = t - j * cg;
+    const bool on = j < L;
+    const int c = g * cg + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (on) {
+        const f32x2* pp = reinterpret_cast<const f32x2*>(cs) + ((int64_t)b * nblk * C + c);
+        int k = j;
+        for (; k + 7 * L < nblk; k += 8 * L) {
+            f32x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(k + u * L) * C];
+            s1 += ((v[0][0] + v[1][0]) + (v[2][0] + v[3][0])) + ((v[4][0] + v[5][0]) + (v[6][0] + v[7][0]));
+            s2 += ((v[0][1] + v[1][1]) + (v[2][1] + v[3][1])) + ((v[4][1] + v[5][1]) + (v[6][1] + v[7][1]));
+        }
+        for (; k < nblk; k += L) {
+            const f32x2 v = pp[(int64_t)k * C];
+            s1 += v[0];
+            s2 += v[1];
+        }
+    }
+    red[t * 2 + 0] = s1;
+    red[t * 2 + 1] = s2;
+    __syncthreads();
+    const double n = (double)HW;
+    if (on && j == 0) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int q = 0; q < L; ++q) {
+            a1 += (double)red[(cl + cg * q) * 2 + 0];
+            a2 += (double)red[(cl + cg * q) * 2 + 1];
+        }
+        mean_c[cl] = a1 / n;
+        const double m2 = a2 - a1 * a1 / n;
+        m2_c[cl] = m2 > 0.0 ? m2 : 0.0;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double mg = 0.0;
+        for (int q = 0; q < cg; ++q) mg += mean_c[q];
+        mg /= (double)cg;
+        double m2 = 0.0;
+        for (int q = 0; q < cg; ++q) {
+            const double d = mean_c[q] - mg;
+            m2 += m2_c[q] + n * d * d;
+        }
+        stat[0] = (float)mg;
+        stat[1] = rsqrtf((float)(m2 / (n * (double)cg)) + eps);
+    }
+    __syncthreads();
+    if (t < cg) {
+        float* tb = tab + ((int64_t)b * C + g * cg + t) * 2;
+        tb[0] = stat[0];
+        tb[1] = stat[1] * to_f32(gamma[g * cg + t]);
+    }
+}
+
 // One workgroup per pixel chunk of one sample (the chunks of gn_partial): a thread keeps the (scale, shift) of its 8 / 4 channels in registers
 // and streams its pixels with four loads in flight -- per element one FMA (+ SiLU), no per-element table reads.
 template <typename T>
@@ -314,9 +383,13 @@ int run_groupnorm(const mi355x_groupnorm_args* a, hipStream_t st) {
     float* part = a->ws;
     float* tab = a->ws + (int64_t)a->B * nchunk * a->C * 2;
     const T* x = static_cast<const T*>(a->x);
-    hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, ppc, nchunk, part);
-    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, a->G,
-                       nchunk, part, static_cast<const T*>(a->gamma), a->eps, tab);
+    if (a->colstats) {  // the launch that produced x left its column statistics: no statistics pass over x
+        hipLaunchKernelGGL((gn_finalize_cs_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, a->colstats, a->HW, a->C, a->G, static_cast<const T*>(a->gamma), a->eps, tab);
+    } else {
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, ppc, nchunk, part);
+        hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, a->G,
+                           nchunk, part, static_cast<const T*>(a->gamma), a->eps, tab);
+    }
     hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, static_cast<T*>(a->out), a->ldo, a->HW,
                        a->C, ppc, tab, static_cast<const T*>(a->beta), a->silu);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
@@ -354,6 +427,7 @@ extern "C" int mi355x_groupnorm(const mi355x_groupnorm_args* a, void* stream) {
     if ((a->C * es) % 16 || (a->ldx * es) % 16 || (a->ldo * es) % 16) return MI355X_ESHAPE;
     if ((a->C * es) / 16 > 256 * GN_MAXVPT || a->C / a->G > 256) return MI355X_ESHAPE;
     if (!al16(a->x) || !al16(a->out) || !al16(a->beta)) return MI355X_ESHAPE;
+    if (a->colstats && (a->HW % 32 || (reinterpret_cast<uintptr_t>(a->colstats) & 7))) return MI355X_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return a->dtype == MI355X_F32 ? run_groupnorm<float>(a, st) : run_groupnorm<bf16_t>(a, st);
 }

@@ -58,6 +58,11 @@ class Lowering:
         # lora_mode="fused": the LoRA down / up projections run INSIDE the parent GEMM's / conv's launch (stacked rank <= 128: producer
         # workgroups at the head of the grid, see gemm_kernel.cuh); 0 = the older skinny-GEMM + extra-K-segment pair of launches
         self.lora_inlaunch = os.environ.get("REFINERS_AMD_LORA_INLAUNCH", "1") != "0"
+        # GroupNorm statistics from the epilogue of the convolution / GEMM that produces the normalised tensor (mi355x_gemm_args.colstats_out):
+        # the statistics pass over that tensor disappears (2 launches per GroupNorm instead of 3); 0 = always the three-kernel GroupNorm
+        self.gn_stats = os.environ.get("REFINERS_AMD_GN_STATS", "1") != "0"
+        self._cs_buf: dict[tuple[int, int], Tensor] = {}
+        self._cs_serial: dict[tuple[int, int], int] = {}
         self._lsync: Any = None          # native.LoraSync: the epoch word every program of this lowering bumps once per replay
         self._bumped: set[int] = set()   # id() of the op lists that already start with the bump
         self.device, self.dtype = device, dtype
@@ -299,6 +304,18 @@ class Lowering:
             self._bumped.add(id(self._target))
         return self.pool.get(native.lora_scratch_rows(groups, M, R, self.dtype), R), self._lsync.flags(groups, M), self._lsync
 
+    def colstats_for(self, M: int, N: int, HW: int) -> Any:
+        """(buffer, serial) for the column statistics of an [M, N] image tensor about to be produced, or None when its consumer could not use
+        them (32-pixel blocks must not straddle samples).  One buffer per (M, N): the program is sequential and a GroupNorm follows its producer
+        before the next tensor of that shape is written; the serial lets groupnorm() verify exactly that instead of trusting it."""
+        if not self.gn_stats or HW % 32 or N % 16 or self.device.type == "meta":
+            return None
+        key = (M, N)
+        if key not in self._cs_buf:
+            self._cs_buf[key] = torch.empty(native.colstats_shape(M, N), device=self.device, dtype=torch.float32)
+        self._cs_serial[key] = self._cs_serial.get(key, 0) + 1
+        return self._cs_buf[key], self._cs_serial[key]
+
     def lora_down(self, x: Tensor, lora: LoraPack) -> Tensor:
         t = self.pool.get(x.shape[0], lora.a_cat.shape[0])
         native.gemm([(x, lora.a_cat)], t)
@@ -315,14 +332,15 @@ class Lowering:
 
     def linear(self, x: Any, spec: LinSpec, *, res: Optional[Tensor] = None, out: Optional[Tensor] = None,
                rows: Optional[int] = None, lora_t: Optional[Tensor] = None, gelu: bool = False, out_kblocked: bool = False,
-               ln: Optional[tuple] = None, stats_out: Optional[Tensor] = None) -> Tensor:
-        """out[M, N(/2 if geglu)] = epi(x W^T + b (+ LoRA) (+ res)).  `lora_t` lets callers share one down-projection
+               ln: Optional[tuple] = None, stats_out: Optional[Tensor] = None, colstats: Any = None) -> Tensor:
+        """out[M, N(/2 if geglu)] = epi(x W^T + b (+ LoRA) (+ res)).  `colstats` = colstats_for(...): also write the output's GroupNorm statistics.  `lora_t` lets callers share one down-projection
         launch between Linears that read the same x.  `ln` = (stats, LayerNorm node): x is the UN-normalised tensor and the
         LayerNorm is applied inside this launch (ln_fold); `stats_out`: also write the output rows' statistics."""
         M = x.shape[0]
         n_cols = spec.N // 2 if spec.geglu else spec.N
         if out is None:
             out = self.pool.get(M, n_cols)
+        cso = None if colstats is None else colstats[0]
         if ln is not None:
             stats, node = ln
             wl, ls, lc = self.ln_fold(spec, node)
@@ -332,7 +350,7 @@ class Lowering:
                 lo = ([(0, al)], spec.lora.bs_r, als, alc)
                 sy = self.lora_sync(1, M, spec.lora.R)
             native.gemm([(x, self.kblocked(wl))], out, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, ln=(stats, ls, lc, float(node.eps)),
-                        stats_out=stats_out, lora=lo, lora_sync=sy)
+                        stats_out=stats_out, lora=lo, lora_sync=sy, colstats_out=cso)
             if sy is not None:
                 self.pool.put(sy[0])
             return out
@@ -340,7 +358,7 @@ class Lowering:
             # LoraAdapter = Sum(target, loras) as ONE launch: producer workgroups compute x A_cat^T once per row block, the up-projections are the tiles' last K steps
             sy = self.lora_sync(1, M, spec.lora.R)
             native.gemm([(x, self.kblocked(spec.w))], out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, stats_out=stats_out,
-                        lora=([(0, spec.lora.a_kb)], spec.lora.bs_r), lora_sync=sy)
+                        lora=([(0, spec.lora.a_kb)], spec.lora.bs_r), lora_sync=sy, colstats_out=cso)
             self.pool.put(sy[0])
             return out
         segs = [(x, self.kblocked(spec.w))]
@@ -348,7 +366,7 @@ class Lowering:
         if spec.lora is not None:
             t = lora_t if lora_t is not None else self.lora_down(x, spec.lora)
             segs.append((t, spec.lora.bs_cat))
-        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, stats_out=stats_out)
+        native.gemm(segs, out, bias=spec.b, res=res, geglu=spec.geglu, gelu=gelu, out_kblocked=out_kblocked, stats_out=stats_out, colstats_out=cso)
         if t is not None and lora_t is None:
             self.pool.put(t)
         return out
@@ -458,11 +476,13 @@ class Lowering:
             ws = self.splitk_workspace(ksplit * M_out * spec.cout)
         if lo is not None:
             sy = self.lora_sync(1, M_out, spec.lora.R)
-        native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res, tile=tile, ksplit=ksplit, ws=ws, lora=lo, lora_sync=sy)
+        cs = self.colstats_for(M_out, spec.cout, OH * OW)  # most convolution outputs of a UNet are normalised next (ResidualBlock, unet.py:6-51)
+        native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res, tile=tile, ksplit=ksplit, ws=ws, lora=lo, lora_sync=sy,
+                         colstats_out=None if cs is None else cs[0])
         if sy is not None:
             self.pool.put(sy[0])
         self.pool.put(t)
-        return Act(out, a.B, OH, OW)
+        return Act(out, a.B, OH, OW, cs)
 
     def splitk_workspace(self, floats: int) -> Tensor:
         """One float32 scratch per size class, shared by every split-K launch of the (sequential) program."""
@@ -475,7 +495,11 @@ class Lowering:
     def groupnorm(self, a: Act, gn: Any, silu: bool) -> Act:
         _expect(isa(gn, "GroupNorm") and gn.num_channels == a.C, "GroupNorm channel mismatch")
         out = self.pool.get(a.M, a.C)
-        native.groupnorm_nhwc(a.tokens(), self._w(gn.weight), self._w(gn.bias), gn.num_groups, gn.eps, silu, Act(out, a.B, a.H, a.W).tokens())
+        cs = None
+        if a.cs is not None and self._cs_serial.get((a.M, a.C)) == a.cs[1] and a.HW % 32 == 0:  # the producer's statistics are still the last ones written there
+            cs = a.cs[0]
+            self.stats["gn_from_producer"] = self.stats.get("gn_from_producer", 0) + 1
+        native.groupnorm_nhwc(a.tokens(), self._w(gn.weight), self._w(gn.bias), gn.num_groups, gn.eps, silu, Act(out, a.B, a.H, a.W).tokens(), colstats=cs)
         return Act(out, a.B, a.H, a.W)
 
     def layernorm(self, x: Tensor, ln: Any) -> Tensor:

@@ -349,9 +349,11 @@ class BlockLowering(Lowering):
         for i, blk in enumerate(blocks):
             _expect(isa(blk, "CrossAttentionBlock"), f"unexpected {cname(blk)} among transformer layers")
             h = self.cross_attention_block(blk, h, a.B, ctx, stats, last=i == len(blocks) - 1)
-        out = self.linear(h, self.linear_spec(proj_out), res=a.t)
+        po = self.linear_spec(proj_out)
+        cs = self.colstats_for(h.shape[0], po.N, a.H * a.W)  # the next ResidualBlock normalises this tensor
+        out = self.linear(h, po, res=a.t, colstats=cs)
         self.pool.put(h)
-        return Act(out, a.B, a.H, a.W)
+        return Act(out, a.B, a.H, a.W, cs)
 
     # -- ResidualBlock -------------------------------------------------------------------------------------------
     def residual_block(self, node: Any, a: Act, ctx: "UNetContext") -> Act:

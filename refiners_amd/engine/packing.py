@@ -51,6 +51,7 @@ class Act:
     B: int
     H: int
     W: int
+    cs: Any = None  # (column statistics [M / 32, C, 2] float32 written by the launch that produced `t`, serial) -- see Lowering.colstats_for
 
     @property
     def C(self) -> int:

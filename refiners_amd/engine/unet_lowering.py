@@ -272,9 +272,10 @@ class UNetLowering(BlockLowering):
         cols = self.pool.get(B * H * W, kp)
         native.im2col3x3_nchw(self.io.x, cols)
         out = self.pool.get(B * H * W, conv.out_channels)
-        native.gemm([(cols, wp)], out, bias=self._w(conv.bias))
+        cs = self.colstats_for(B * H * W, conv.out_channels, H * W)
+        native.gemm([(cols, wp)], out, bias=self._w(conv.bias), colstats_out=None if cs is None else cs[0])
         self.pool.put(cols)
-        return Act(out, B, H, W)
+        return Act(out, B, H, W, cs)
 
     def _release(self, a: Optional[Act]) -> None:
         if a is not None:

@@ -149,6 +149,7 @@ class GemmArgs(C.Structure):
         ("lora_t", C.c_void_p),
         ("lora_flags", C.c_void_p),
         ("lora_epoch", C.c_void_p),
+        ("colstats_out", C.c_void_p),
     ]
 
 
@@ -242,6 +243,7 @@ class GroupNormArgs(C.Structure):
         ("out", C.c_void_p),
         ("ldo", C.c_int64),
         ("ws", C.c_void_p),
+        ("colstats", C.c_void_p),
     ]
 
 
@@ -322,7 +324,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
-    if lib.mi355x_abi_version() != 5:
+    if lib.mi355x_abi_version() != 6:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
     import os
@@ -600,6 +602,7 @@ def gemm(
     out_f32: bool = False,
     lora: Optional[tuple[Sequence[tuple[int, "KBlocked"]], Tensor]] = None,
     lora_sync: Optional[tuple] = None,
+    colstats_out: Optional[Tensor] = None,
 ) -> Optional[Tensor]:
     """out[M,N] = epi(sum_s x_s @ w_s^T) for plain row-major 2-D segments (x_s: [M,K_s], w_s: [N,K_s]).
     weight_operand="x" marks launches whose PARAMETERS sit in the x slot (transposed projections) for link_weight_prefetch.
@@ -650,6 +653,7 @@ def gemm(
         assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= (a.N // 32) * a.M * 2 and a.N % 64 == 0
         a.stats_out = stats_out.data_ptr()
         keep.append(stats_out)
+    _fill_colstats(a, colstats_out, keep)
     _fill_split(a, tile, ksplit, ws, stages)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm", keep=tuple(keep))
     return out
@@ -672,6 +676,7 @@ def conv_gemm(
     stages: int = 0,
     lora: Optional[tuple] = None,
     lora_sync: Optional[tuple] = None,
+    colstats_out: Optional[Tensor] = None,
 ) -> Tensor:
     """Implicit-GEMM convolution over NHWC images.
 
@@ -703,6 +708,7 @@ def conv_gemm(
     keep: list = []
     if lora is not None:
         _lora_fill(a, lora, False, img0.dtype, tuple(w0.shape)[1], keep, lora_sync)
+    _fill_colstats(a, colstats_out, keep)
     _fill_split(a, tile, ksplit, ws, stages)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm(conv)", keep=tuple(keep))
     return out
@@ -758,6 +764,19 @@ def gemm_signature(a: GemmArgs) -> str:
     k = sum(int(a.seg[s].k) * (int(a.seg[s].ksize) ** 2 if a.conv else 1) for s in range(a.nseg))
     flags = ("geglu" if a.geglu == 1 else "") + ("T%d" % a.nt_begin if a.out_t else "") + ("ln" if a.ln_stats else "") + ("st" if a.stats_out else "") + ("lora" if a.lora_b else "")
     return f"{'conv' if a.conv else 'gemm'}:{'f32' if a.dtype == 0 else 'bf16'}:{a.M}x{a.N}x{k}:s{a.nseg}:{flags}"
+
+
+def colstats_shape(M: int, N: int) -> tuple[int, int, int]:
+    """Shape of the float32 buffer mi355x_gemm_args.colstats_out fills: (sum, sum of squares) per (32-row block, column)."""
+    return ((M + 31) // 32, N, 2)
+
+
+def _fill_colstats(a: GemmArgs, cs: Optional[Tensor], keep: list) -> None:
+    if cs is None:
+        return
+    assert cs.dtype == torch.float32 and cs.is_contiguous() and cs.numel() >= (a.M + 31) // 32 * a.N * 2 and a.N % 16 == 0
+    a.colstats_out = cs.data_ptr()
+    keep.append(cs)
 
 
 def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor], stages: int = 0) -> None:
@@ -861,8 +880,9 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Tensor) -
 _gn_ws: dict[tuple[int, int], Tensor] = {}
 
 
-def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool, out: Tensor) -> Tensor:
-    """x, out: [B, HW, C] views with contiguous channels."""
+def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool, out: Tensor, colstats: Optional[Tensor] = None) -> Tensor:
+    """x, out: [B, HW, C] views with contiguous channels.  `colstats`: what the launch that produced x wrote through `colstats_out`
+    ([B * HW / 32, C, 2] float32): the statistics pass over x is skipped."""
     a = GroupNormArgs()
     B, HW, Cc = x.shape
     assert x.stride(2) == 1 and out.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and out.stride(0) == HW * out.stride(1)
@@ -880,7 +900,10 @@ def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: flo
     a.B, a.HW, a.C, a.G = B, HW, Cc, groups
     a.x, a.ldx, a.gamma, a.beta, a.eps, a.silu = x.data_ptr(), x.stride(1), gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
     a.out, a.ldo, a.ws = out.data_ptr(), out.stride(1), ws.data_ptr()
-    _launch("mi355x_groupnorm", (C.byref(a),), "mi355x_groupnorm", keep=(ws,))
+    if colstats is not None:
+        assert HW % 32 == 0 and colstats.dtype == torch.float32 and colstats.is_contiguous() and colstats.numel() >= B * HW // 32 * Cc * 2
+        a.colstats = colstats.data_ptr()
+    _launch("mi355x_groupnorm", (C.byref(a),), "mi355x_groupnorm", keep=(ws, colstats))
     return out
 
 

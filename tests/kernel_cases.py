@@ -351,6 +351,57 @@ def groupnorm_case(B, Cc, HW, dtype, silu=True, eps=1e-5, seed=90):
     return _cmp(out.float().permute(0, 2, 1), ref, dtype)
 
 
+def colstats_case(M, K, N, dtype, *, tile=0, ksplit=1, res=True, seed=310):
+    """mi355x_gemm_args.colstats_out: (sum, sum of squares) per (32-row block, column) of the output AS STORED, from the epilogue of every 4-wave
+    tile and from the split-K reduction pass -- checked against the sums of the stored tensor itself, rows beyond M excluded."""
+    x = _rand(M, K, dtype=dtype, seed=seed)
+    w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
+    b = _rand(N, dtype=dtype, seed=seed + 2) + 2.0
+    r = _rand(M, N, dtype=dtype, seed=seed + 3) if res else None
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    cs = torch.full(native.colstats_shape(M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ws = torch.empty(ksplit * M * N, dtype=torch.float32, device=DEV) if ksplit > 1 else None
+    native.gemm([(x, native.KBlocked(w))], out, bias=b, res=r, tile=tile, ksplit=ksplit, ws=ws, colstats_out=cs)
+    ref = x.float() @ w.float().t() + b.float() + (r.float() if res else 0)
+    e_out = _cmp(out, ref, dtype)
+    nb = (M + 31) // 32
+    pad = torch.zeros(nb * 32, N, dtype=torch.float64, device=DEV)
+    pad[:M] = out.double()
+    blocks = pad.view(nb, 32, N)
+    want = torch.stack([blocks.sum(1), blocks.square().sum(1)], dim=-1)
+    assert torch.isfinite(cs).all(), "colstats has unwritten entries"
+    e_cs = ((cs.double() - want).abs() / (want.abs() + 1.0)).max().item()
+    assert e_cs < 2e-6, f"column statistics off by {e_cs:.2e}"
+    cs2 = torch.zeros_like(cs)
+    native.gemm([(x, native.KBlocked(w))], out, bias=b, res=r, tile=tile, ksplit=ksplit, ws=ws, colstats_out=cs2)
+    assert torch.equal(cs, cs2), "column statistics must be bit-reproducible"
+    return e_out
+
+
+def conv_groupnorm_chain_case(B, Cin, Cout, H, W, dtype, *, ksplit=1, tile=0, silu=True, seed=320):
+    """Conv2d -> GroupNorm (-> SiLU) with the statistics taken from the convolution's epilogue (two GroupNorm launches instead of three)
+    against torch's conv2d + group_norm, and against the three-kernel GroupNorm on the same stored tensor."""
+    x = _rand(B, Cin, H, W, dtype=dtype, seed=seed)
+    w = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=(Cin * 9) ** -0.5)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2) + 1.5
+    g = (1 + 0.1 * _rand(Cout, dtype=torch.float32, seed=seed + 3)).to(dtype)
+    be = (0.1 * _rand(Cout, dtype=torch.float32, seed=seed + 4)).to(dtype)
+    M = B * H * W
+    y = torch.empty(M, Cout, dtype=dtype, device=DEV)
+    cs = torch.full(native.colstats_shape(M, Cout), float("nan"), dtype=torch.float32, device=DEV)
+    ws = torch.empty(ksplit * M * Cout, dtype=torch.float32, device=DEV) if ksplit > 1 else None
+    native.conv_gemm([(x.permute(0, 2, 3, 1).contiguous(), native.KBlocked(native.pack_conv_weight(w)), 3, 1, 1)], y, B, H, W, bias=b, tile=tile, ksplit=ksplit, ws=ws, colstats_out=cs)
+    o1, o2 = torch.empty_like(y), torch.empty_like(y)
+    native.groupnorm_nhwc(y.view(B, H * W, Cout), g, be, 32, 1e-5, silu, o1.view(B, H * W, Cout), colstats=cs)
+    native.groupnorm_nhwc(y.view(B, H * W, Cout), g, be, 32, 1e-5, silu, o2.view(B, H * W, Cout))
+    d = (o1.float() - o2.float()).abs().max().item()
+    assert d <= (2e-2 if dtype == torch.bfloat16 else 2e-5), f"producer statistics vs statistics pass: {d:.2e}"
+    ref = F.group_norm(y.float().view(B, H * W, Cout).permute(0, 2, 1), 32, g.float(), be.float(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    return _cmp(o1.float().view(B, H * W, Cout).permute(0, 2, 1), ref, dtype)
+
+
 # ------------------------------------------------------------------------------------------------ glue
 def layout_case(B, Cc, H, W, dtype, seed=100):
     x = _rand(B, Cc, H, W, dtype=dtype, seed=seed)
@@ -914,6 +965,16 @@ def all_cases():
             (f"gemm_{tag}_ln_chain_tiles_6_2", lambda dt=dt: gemm_ln_chain_case(300, 320, 384, dt, tile1=6, tile2=2)),
             (f"gemm_{tag}_ln_chain_tiles_1_3", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=1, tile2=3)),
             (f"gemm_{tag}_ln_chain_tiles_2_1", lambda dt=dt: gemm_ln_chain_case(520, 640, 256, dt, tile1=2, tile2=1)),
+            # round 4: GroupNorm statistics from the producer's epilogue
+            (f"colstats_{tag}_auto_2048x1280", lambda dt=dt: colstats_case(2048, 640, 1280, dt)),
+            (f"colstats_{tag}_tile1_edge_rows", lambda dt=dt: colstats_case(96, 256, 320, dt, tile=1)),
+            (f"colstats_{tag}_tile2", lambda dt=dt: colstats_case(224, 320, 192, dt, tile=2, res=False)),
+            (f"colstats_{tag}_tile3", lambda dt=dt: colstats_case(320, 384, 640, dt, tile=3)),
+            (f"colstats_{tag}_tile4_oddM", lambda dt=dt: colstats_case(77, 128, 64, dt, tile=4)),
+            (f"colstats_{tag}_splitk3", lambda dt=dt: colstats_case(256, 3072, 320, dt, tile=1, ksplit=3)),
+            (f"conv_gn_{tag}_32x32x320", lambda dt=dt: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt)),
+            (f"conv_gn_{tag}_splitk_16x16x640", lambda dt=dt: conv_groupnorm_chain_case(2, 640, 640, 16, 16, dt, ksplit=3, tile=1)),
+            (f"conv_gn_{tag}_24x16x960_nosilu", lambda dt=dt: conv_groupnorm_chain_case(1, 320, 960, 24, 16, dt, silu=False)),
             (f"gemm_{tag}_lora1_2048x1280x1280", lambda dt=dt: gemm_lora_inlaunch_case(2048, 1280, 1280, dt)),
             (f"gemm_{tag}_lora1_rank8_tile4_edges", lambda dt=dt: gemm_lora_inlaunch_case(300, 640, 200, dt, ranks=(8,), tile=4)),
             (f"gemm_{tag}_lora1_tile2", lambda dt=dt: gemm_lora_inlaunch_case(520, 320, 384, dt, ranks=(16, 4), tile=2)),

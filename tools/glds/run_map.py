@@ -5,6 +5,9 @@ import subprocess
 import sys
 from pathlib import Path
 
+if "--build-only" not in sys.argv:
+    import torch  # BEFORE the probe library: its HIP runtime must be the one torch has already initialised (a second copy finds no device)
+
 HERE = Path(__file__).resolve().parent
 SO = HERE / "libprobe_map.so"
 
@@ -19,8 +22,6 @@ def main():
     lib = build()
     if "--build-only" in sys.argv:
         return
-    import torch
-
     lib.glds_map_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     sink = torch.zeros(1, dtype=torch.int32, device="cuda")
     buf = torch.randn(1 << 30, dtype=torch.bfloat16, device="cuda").view(torch.uint8)  # 2 GB
