@@ -33,19 +33,30 @@ def is_stale() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build_native(force: bool = False, verbose: bool = False) -> Path:
+def build_variant(tag: str, defines: list[str]) -> Path:
+    """An experiment build of the same sources with extra -D switches -> csrc/variants/libmi355x_refiners_<tag>.so (git-ignored, travels with
+    the snapshot).  tools/ab_step.py runs it beside the product library IN ONE PROCESS (variant `name%<tag>=...`): a recorded program keeps the
+    entry points of the library it was lowered with."""
+    out = CSRC / "variants" / f"libmi355x_refiners_{tag}.so"
+    return build_native(force=True, defines=defines, lib=out, objdir=CSRC / "variants" / tag)
+
+
+def build_native(force: bool = False, verbose: bool = False, defines: list[str] | None = None, lib: Path = LIB, objdir: Path = CSRC) -> Path:
     """Compile every HIP source for gfx950 and link the shared library. Returns the library path."""
     if not force and not is_stale():
-        return LIB
+        return lib
+    LIB = lib  # noqa: N806 -- (shadows the module constant for an experiment build)
     hipcc = hipcc_path()
+    objdir.mkdir(parents=True, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
-        obj = CSRC / (src.replace(".hip", ".o"))
+        obj = objdir / (src.replace(".hip", ".o"))
         # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified), which removes the
         # v_accvgpr_read/write traffic between the softmax / epilogue VALU code and the matrix cores (attention inner
         # loop: 1062 -> 876 instructions) and lowers the total register count of every kernel.
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", *[f"-D{d}" for d in (defines or [])],
+               "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -64,4 +75,8 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:  # python -m refiners_amd.build_native --variant prio MI355X_GEMM_PRIO=1
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2 :]))
+    else:
+        print(build_native(force="--force" in sys.argv, verbose=True))

@@ -131,30 +131,46 @@ MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, flo
 
 // Column sums over the 16 lanes of a lane group (lane c16 = one row): a[e], b[e] hold this lane's contribution to column e of RUN; on return
 // lane c16 holds the 16-lane totals of column `c16 % RUN` in a[0], b[0].  Recursive halving: each exchange adds the partner's half and keeps
-// half of the columns (RUN = 8: one full exchange first, the two 8-lane halves then end with the same totals), 15 / 14 shuffles per
-// quantity instead of 64 for an all-reduce, a fixed tree (deterministic).
+// half of the columns (RUN = 8: one full exchange first, the two 8-lane halves then end with the same totals), 15 / 14 exchanges per
+// quantity instead of 64 for an all-reduce, a fixed tree (deterministic).  The exchanges are DPP moves inside the 16-lane row (no LDS round
+// trip: __shfl_xor compiles to ds_bpermute): partner = row_mirror (15 - c), row_half_mirror (c ^ 7), quad_perm (c ^ 2), (c ^ 1) -- every
+// partner differs from the lane in exactly the bit that decides which half it keeps, and the four steps together reach all 16 lanes.
+template <int CTRL> MI_DEV float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int RUN> MI_DEV void colsum16(float (&a)[RUN], float (&b)[RUN], int c16) {
     static_assert(RUN == 8 || RUN == 16, "8 or 16 columns per lane");
+    constexpr int ROW_MIRROR = 0x140, ROW_HALF_MIRROR = 0x141, QUAD_XOR2 = 0x4E, QUAD_XOR1 = 0xB1;
+    auto step = [&](auto ctrl, int w) __attribute__((always_inline)) {  // w = the lane bit of this exchange = number of columns kept
+        constexpr int CTRL = decltype(ctrl)::value;
+        const bool up = (c16 & w) != 0;
+#pragma unroll
+        for (int e = 0; e < RUN / 2; ++e) {
+            if (e < w) {
+                const float sa = up ? a[e] : a[e + w], sb = up ? b[e] : b[e + w];
+                const float ka = up ? a[e + w] : a[e], kb = up ? b[e + w] : b[e];
+                a[e] = ka + dpp_f32<CTRL>(sa);
+                b[e] = kb + dpp_f32<CTRL>(sb);
+            }
+        }
+    };
     if constexpr (RUN == 8) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            a[e] += __shfl_xor(a[e], 8);
-            b[e] += __shfl_xor(b[e], 8);
+            a[e] += dpp_f32<ROW_MIRROR>(a[e]);
+            b[e] += dpp_f32<ROW_MIRROR>(b[e]);
         }
+    } else {
+        step(std::integral_constant<int, ROW_MIRROR>{}, 8);
     }
-#pragma unroll
-    for (int w = (RUN == 16 ? 8 : 4); w >= 1; w >>= 1) {  // w = lane-bit mask of this exchange = number of columns kept
-        const bool up = (c16 & w) != 0;
-#pragma unroll
-        for (int e = 0; e < w; ++e) {
-            const float sa = up ? a[e] : a[e + w], sb = up ? b[e] : b[e + w];
-            const float ka = up ? a[e + w] : a[e], kb = up ? b[e + w] : b[e];
-            a[e] = ka + __shfl_xor(sa, w);
-            b[e] = kb + __shfl_xor(sb, w);
-        }
-    }
+    step(std::integral_constant<int, ROW_HALF_MIRROR>{}, 4);
+    step(std::integral_constant<int, QUAD_XOR2>{}, 2);
+    step(std::integral_constant<int, QUAD_XOR1>{}, 1);
 }
 
+#ifndef MI355X_GEMM_PRIO
+#define MI355X_GEMM_PRIO 0  // experiment builds only (refiners_amd.build_native.build_variant): s_setprio 1 around the K loop's MFMA phases
+#endif
 constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
 constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)
 constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch (control-lora-*-rank128)
@@ -747,11 +763,13 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         for (int t = t_begin; t < t_end; ++t) {
             const bool active = KG == 1 || t < my_kb;  // the odd group of an odd block count idles through the last trip
             if (active) {  // phase A
+                if constexpr (MI355X_GEMM_PRIO != 0) __builtin_amdgcn_s_setprio(1);
                 read_half(xf1, wf1, t, 1);
                 mma_half(xf0, wf0);
                 pin();
             }
             if (t + 1 < max_kb) {
+                if constexpr (MI355X_GEMM_PRIO != 0) __builtin_amdgcn_s_setprio(0);
                 if (t + 1 + D <= my_kb) wait_vm<(D - 1) * LPS>();
                 else wait_vm0();
 
@@ -767,6 +785,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 }
             }
             if (active) {  // phase B
+                if constexpr (MI355X_GEMM_PRIO != 0) __builtin_amdgcn_s_setprio(1);
                 read_half(xf0, wf0, t + 1, 0);  // (past the last block: a harmless read of a stale stage; keeps the phase one basic block)
                 mma_half(xf1, wf1);
                 pin();
@@ -1116,16 +1135,18 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     }
 }
 
-// out[m][n] = dtype( sum_s partial[s][m][n] (fixed order) + bias[n] + rowbias[m / rpg][n] + res[m][n] ).  One workgroup = 32 rows x 256 columns:
-// thread (ty, tx) = (t >> 6, t & 63) walks rows 8 ty .. 8 ty + 7 of the block at columns 4 tx .. 4 tx + 3, so the per-column sums GemmP::colstats asks
-// for are 8 local adds + one fixed-order exchange of the four row groups through LDS.
+// out[m][n] = dtype( sum_s partial[s][m][n] (fixed order) + bias[n] + rowbias[m / rpg][n] + res[m][n] ).  One workgroup = 32 rows x 64 columns:
+// thread (ty, tx) = (t >> 4, t & 15) owns rows 2 ty, 2 ty + 1 of the block at columns 4 tx .. 4 tx + 3 -- every partial it needs is requested up front
+// (2 rows x ksplit independent 16-byte loads), (M / 32) x (N / 64) workgroups keep the memory system as busy as the old grid-stride form -- and the
+// per-column sums GemmP::colstats asks for are 2 local adds + one fixed-order sum of the sixteen row pairs through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
-    __shared__ float red[3][64][8];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int nbx = (p.N + 255) / 256;
+    __shared__ float red[15][16][8];
+    constexpr int MAXS = 4;  // splits whose partials are all in flight at once (more: a serial tail)
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int nbx = (p.N + 63) / 64;
     const int bm = blockIdx.x / nbx, bn = blockIdx.x - bm * nbx;
-    const int n = bn * 256 + tx * 4;
+    const int n = bn * 64 + tx * 4;
     T* out = reinterpret_cast<T*>(p.out);
     const T* bias = reinterpret_cast<const T*>(p.bias);
     const T* rowbias = reinterpret_cast<const T*>(p.rowbias);
@@ -1133,20 +1154,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const bool full4 = n + 4 <= p.N;
     if (n < p.N) {
-#pragma unroll 2
-        for (int r = 0; r < 8; ++r) {
-            const int m = bm * 32 + ty * 8 + r;
+        f32x4 part[2][MAXS];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int m = min(bm * 32 + ty * 2 + r, p.M - 1);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                part[r][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (s < p.ksplit) {
+                    const float* pp = p.partial + ((int64_t)s * p.M + m) * p.N + n;
+                    if (full4) part[r][s] = *reinterpret_cast<const f32x4*>(pp);
+                    else
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < p.N) part[r][s][q] = pp[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int m = bm * 32 + ty * 2 + r;
             if (m >= p.M) break;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < p.ksplit; ++s) {
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (s < p.ksplit) v[0] += part[r][s][0], v[1] += part[r][s][1], v[2] += part[r][s][2], v[3] += part[r][s][3];
+            for (int s = MAXS; s < p.ksplit; ++s) {
                 const float* pp = p.partial + ((int64_t)s * p.M + m) * p.N + n;
-                if (full4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(pp);
-                    v[0] += t[0], v[1] += t[1], v[2] += t[2], v[3] += t[3];
-                } else {
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < p.N) v[q] += pp[q];
-                }
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < p.N) v[q] += pp[q];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1178,8 +1213,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (n + q >= p.N) break;
-                const float a = ((s1[q] + red[0][tx][q]) + red[1][tx][q]) + red[2][tx][q];
-                const float b = ((s2[q] + red[0][tx][4 + q]) + red[1][tx][4 + q]) + red[2][tx][4 + q];
+                float a = s1[q], b = s2[q];
+#pragma unroll
+                for (int j = 0; j < 15; ++j) {
+                    a += red[j][tx][q];
+                    b += red[j][tx][4 + q];
+                }
                 f32x2 st = {a, b};
                 *reinterpret_cast<f32x2*>(p.colstats + ((int64_t)bm * p.N + n + q) * 2) = st;
             }
@@ -1253,7 +1292,7 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), q.ln_stats ? LDS : LDS - BM * 8, stream, q);
     if (q.ksplit > 1) {
-        const int rb = ((q.M + 31) / 32) * ((q.N + 255) / 256);
+        const int rb = ((q.M + 31) / 32) * ((q.N + 63) / 64);
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb), dim3(256), 0, stream, q);
     }
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;

@@ -350,6 +350,14 @@ def available() -> bool:
         return False
 
 
+def switch_library(path: Optional[Path]) -> C.CDLL:
+    """Tools only (tools/ab_step.py): make another build of the library the one new launches / recordings bind to (None = the product library).
+    Programs recorded earlier keep the entry points they were recorded with."""
+    global _lib
+    _lib = None
+    return load(path)
+
+
 def loaded_library_path() -> Optional[str]:
     return str(LIB_PATH) if _lib is not None else None
 

@@ -279,10 +279,10 @@ def test_control_lora_rank128_costs_no_extra_launch():
         print(f"control-lora rank 128 on {len(targets)} layers, {mode}: l2 {l2:.2e} max {mx:.2e}, {ops[mode]} launches")
         assert l2 < F32_TOL and mx < F32_TOL, (mode, l2, mx)
     # one launch per adapted layer (a merged Q | K | V^T counts as the one launch it is in both modes): the only difference is that merged
-    # weights let the 2-row time-embedding projections of the copied ResidualBlocks ride in ONE batched launch (UNetLowering.batch_time_biases),
-    # while live LoRAs keep them one launch each
+    # weights let the time-embedding projections of the copied ResidualBlocks come out of the prologue's table with ONE row gather per step
+    # (UNetLowering.batch_time_biases, table mode), while live LoRAs keep them one launch each behind one gather of the embedding rows
     n_time = sum(1 for t in targets if "RangeAdapter2d.Chain.Linear" in t)
-    assert ops["fused"] == ops["merged"] + max(n_time - 1, 0), (ops, n_time)
+    assert ops["fused"] == ops["merged"] + n_time, (ops, n_time)
 
 
 def test_sam_vit_h_float32_matches_reference():

@@ -52,6 +52,10 @@ def main() -> None:
         native.attention_pipeline_from_env()
         tuning.enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
         tuning._table = None
+        libtag = None
+        if "%" in name:  # "name%prio=...": lowered against csrc/variants/libmi355x_refiners_prio.so (refiners_amd.build_native.build_variant)
+            name_, libtag = name.split("%", 1)
+            native.switch_library(ROOT / "refiners_amd" / "csrc" / "variants" / f"libmi355x_refiners_{libtag.split('@')[0]}.so")
         mode = name.split("@", 1)[1] if "@" in name else args.lora_mode  # "name@merged=..." / "name@fused=...": the variant's LoRA mode (same process, same weights)
         p = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=True, lora_mode=mode)
         p.inputs, p.x = inputs, x0.clone()
@@ -61,6 +65,8 @@ def main() -> None:
         torch.cuda.synchronize()
         pipes[name] = p
         print(f"{name}: {p.engine.stats['step_ops']} launches/step, tuning {p.engine.stats.get('gemm_tuning')}", flush=True)
+        if libtag is not None:
+            native.switch_library(None)
     res = {n: [] for n in pipes}
     for _ in range(args.rounds):  # interleaved rounds
         for name, p in pipes.items():
