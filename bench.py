@@ -128,7 +128,7 @@ def program_entry(e) -> dict:
     if what == "mi355x_layernorm":
         return {"what": what, "key": f"layernorm:{a.M}x{a.C}"}
     if what == "mi355x_groupnorm":
-        return {"what": what, "key": f"groupnorm:B{a.B}:HW{a.HW}:C{a.C}"}
+        return {"what": what, "key": f"groupnorm:B{a.B}:HW{a.HW}:C{a.C}" + (":cs" if a.colstats else "")}
     return {"what": what, "key": what}
 
 
@@ -289,12 +289,14 @@ def family_roofline(pipe, workload: str, n_img: int, ms_per_step: float) -> dict
         fl = sum(op_flops(e) for e in ops)
         fam[name] = {"launches": len(ops), "ms": round(sec * 1e3, 4), "avg_us": round(sec / len(ops) * 1e6, 2), "tflop": round(fl / 1e12, 4),
                      "tflops": round(fl / sec / 1e12, 1) if fl else None}
-    # GroupNorm (three HBM-bound kernels per call: partial sums, finalize, apply + SiLU): algorithmic bytes = two reads + one write of the tensor
+    # GroupNorm (HBM-bound: partial sums, finalize, apply + SiLU): algorithmic bytes = two reads + one write of the tensor; one read + one write
+    # where the statistics come from the epilogue of the launch that produced the tensor (mi355x_gemm_args.colstats_out)
     gn_ops = groups.get("mi355x_groupnorm", [])
     if gn_ops:
-        gbytes = sum(3.0 * a.B * a.HW * a.C * (4 if a.dtype == 0 else 2) for a in (e[1][0]._obj for e in gn_ops))
+        gbytes = sum((2.0 if a.colstats else 3.0) * a.B * a.HW * a.C * (4 if a.dtype == 0 else 2) for a in (e[1][0]._obj for e in gn_ops))
         gsec = fam["mi355x_groupnorm"]["ms"] * 1e-3
-        fam["mi355x_groupnorm"].update(algorithmic_gb=round(gbytes / 1e9, 4), hbm_gbps=round(gbytes / gsec / 1e9, 1), frac_of_hbm_peak=round(gbytes / gsec / 1e9 / PEAK_HBM_GBPS, 4))
+        fam["mi355x_groupnorm"].update(algorithmic_gb=round(gbytes / 1e9, 4), hbm_gbps=round(gbytes / gsec / 1e9, 1), frac_of_hbm_peak=round(gbytes / gsec / 1e9 / PEAK_HBM_GBPS, 4),
+                                       stats_from_producer=sum(1 for e in gn_ops if e[1][0]._obj.colstats))
     # the five shape classes that take the most time, each replayed on its own (entry point + shape = the key of profiles/*_inplace_by_shape.md)
     classes: dict[str, list] = {}
     for e in low.step:

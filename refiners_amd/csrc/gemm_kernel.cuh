@@ -169,7 +169,10 @@ template <int RUN> MI_DEV void colsum16(float (&a)[RUN], float (&b)[RUN], int c1
 }
 
 #ifndef MI355X_GEMM_PRIO
-#define MI355X_GEMM_PRIO 0  // experiment builds only (refiners_amd.build_native.build_variant): s_setprio 1 around the K loop's MFMA phases
+#define MI355X_GEMM_PRIO 1  // s_setprio 1 around the K loop's MFMA + LDS-read phases, 0 around its wait / barrier / stage-issue section: the co-resident
+                            // workgroup's matrix instructions win the issue arbitration against this one's address arithmetic.  Same-process A/B of the whole
+                            // step (tools/ab_step.py, profiles/r04_d_ab_gn_prio.log): 25.379 -> 25.314 ms, three interleaved rounds each within 0.01 ms.
+                            // (-DMI355X_GEMM_PRIO=0 through refiners_amd.build_native.build_variant rebuilds the old loop for an A/B.)
 #endif
 constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
 constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)

@@ -293,3 +293,45 @@ def test_an_unknown_layer_that_needs_the_context_store_refuses_the_whole_tree():
     low = UNetLowering(torch.device("meta"), torch.float32)
     with pytest.raises(Unsupported, match="SkipFilter.*UseContext"):
         low.lower(unet, _bare_io(torch.device("meta")))
+
+
+def test_groupnorm_takes_its_statistics_from_the_producing_launch_where_there_is_one(monkeypatch):
+    """ResidualBlock = GroupNorm -> SiLU -> Conv2d -> GroupNorm -> SiLU -> Conv2d (latent_diffusion/unet.py:6-51): the second GroupNorm's input is
+    the first convolution's output, so that launch writes the column statistics (mi355x_gemm_args.colstats_out) and the GroupNorm call carries
+    them (two kernels instead of three); the first GroupNorm's input comes from outside (no producer in this program): statistics pass.
+    The block's output carries its statistics for whoever normalises it next (CrossAttentionBlock2d's GroupNorm here), and a tensor that was
+    overwritten in between (same shape, later producer) is refused by the serial check.  Recorded on the CPU device: nothing is launched."""
+    from refiners_amd.engine.lowering_blocks import BlockLowering
+    from refiners_amd.engine.packing import Act
+    from refiners_amd.engine.unet_lowering import UNetContext
+    from refiners_amd.latent_diffusion.blocks import CrossAttentionBlock2d, ResidualBlock
+
+    torch.manual_seed(0)
+    tree = fl.Chain(ResidualBlock(64, 128), CrossAttentionBlock2d(channels=128, context_embedding_dim=64, context_key="clip_text_embedding", num_attention_heads=2, use_bias=False, use_linear_projection=True))
+    B, H, W = 2, 8, 8
+
+    def lower(flag: str):
+        monkeypatch.setenv("REFINERS_AMD_GN_STATS", flag)
+        low = BlockLowering(torch.device("cpu"), torch.float32)
+        ctx = UNetContext(low, B)
+        ctx.text[("cross_attention_block", "clip_text_embedding")] = (torch.zeros(B * 64, 64), 7)
+        with low.in_step():
+            a = Act(low.pool.get(B * H * W, 64), B, H, W)
+            a1 = low.residual_block(tree[0], a, ctx)
+            assert (a1.cs is not None) == (flag == "1")
+            out = low.cross_attention_2d(tree[1], a1, ctx)
+            stale = low.groupnorm(a1, kids_of(tree[1])[0], silu=False) if flag == "1" else None  # a1's statistics were overwritten by the transformer's proj_out (same shape)
+        return low, out, stale
+
+    def kids_of(m):
+        return list(list(m._modules.values())[0]._modules.values())
+
+    low, out, stale = lower("1")
+    gns = [e[1][0]._obj for e in low.step if e[2] == "mi355x_groupnorm"]
+    assert [bool(g.colstats) for g in gns] == [False, True, True, False]  # GN1 (outside input), GN2 (conv1), transformer GN (conv2 + shortcut), the stale one
+    assert low.stats["gn_from_producer"] == 2 and out.cs is not None
+    producers = [e[1][0]._obj for e in low.step if e[2].startswith("mi355x_gemm") and e[1][0]._obj.colstats_out]
+    assert len(producers) == 3 and {int(p.N) for p in producers} == {128}  # conv1, conv2, proj_out
+    low0, _, _ = lower("0")
+    assert all(not e[1][0]._obj.colstats for e in low0.step if e[2] == "mi355x_groupnorm") and "gn_from_producer" not in low0.stats
+    assert [e[2] for e in low0.step] == [e[2] for e in low.step][:-1]  # same program otherwise

@@ -46,7 +46,7 @@ def family(kernel: str) -> str | None:
         return "mi355x_attention"
     if "layernorm_kernel" in kernel:
         return "mi355x_layernorm"
-    if re.search(r"gn_(partial|finalize|apply|fused)_kernel", kernel):
+    if re.search(r"gn_(partial|finalize|finalize_cs|apply|fused)_kernel", kernel):
         return "mi355x_groupnorm"
     return None
 
@@ -71,7 +71,7 @@ def is_ours(n: str) -> bool:
 def step_map(rows: list[tuple], program: list[dict], max_steps: int = 4) -> list[list[tuple[dict, list]]]:
     """rows: (kernel name, start, payload) of every dispatch of the traced process, in start order.  Returns, for up to `max_steps` of
     the LAST full replays of the step program, the program entries paired with the payloads of the dispatches they issued (a split-K conv
-    = 2 dispatches, a GroupNorm = 3) -- i.e. the prologue, the warm-up and every torch kernel are left out.  Steps are delimited by the
+    = 2 dispatches, a GroupNorm = 3, or 2 when its statistics come from the launch that produced its input) -- i.e. the prologue, the warm-up and every torch kernel are left out.  Steps are delimited by the
     CFG + solver kernel that closes each of them."""
     ours = [(n, s, x) for n, s, x in rows if is_ours(n)]
     ends = [i for i, (n, _, _) in enumerate(ours) if "cfg_ddim_kernel" in n or "cfg_linear_step_kernel" in n]
@@ -98,7 +98,7 @@ def step_map(rows: list[tuple], program: list[dict], max_steps: int = 4) -> list
                 if i + 1 < len(st) and "splitk_reduce_kernel" in st[i + 1][0] and ent.get("ksplit", 1) > 1:
                     take = 2
             elif what == "mi355x_groupnorm":
-                take = 3  # partial sums, finalize, apply
+                take = 2 if "gn_finalize_cs_kernel" in n else 3  # (statistics from the producer's epilogue: finalize, apply) / partial sums, finalize, apply
             mapped.append((ent, [x for _, _, x in st[i : i + take]]))
             i += take
         if ok:
