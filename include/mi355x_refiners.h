@@ -312,6 +312,14 @@ typedef struct {
     int64_t ldo;
     float* ws;
     const float* colstats; /* [B * HW / 32][C][2] (sum, sum of squares) per 32-pixel block, or NULL (statistics are then computed from x) */
+    /* Two-source form: the normalised tensor is Concatenate(x, x2) along the channels WITHOUT existing (ResidualConcatenator -> ResidualBlock,
+       src/refiners/foundationals/latent_diffusion/unet.py:69-85): channels [0, C1) are read from x, [C1, C) from x2 (pixel stride ldx2).  C1 * sizeof(dtype)
+       a multiple of 16.  With colstats: colstats is [B * HW / 32][C1][2] and colstats2 [B * HW / 32][C - C1][2] (each source's producer wrote its own).
+       x2 == NULL: one source. */
+    const void* x2;
+    int64_t ldx2;
+    int32_t C1;
+    const float* colstats2;
 } mi355x_groupnorm_args;
 
 int64_t mi355x_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C);

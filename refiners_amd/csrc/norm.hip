@@ -72,8 +72,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // ws layout (floats): part[B][nchunk][C][2] | tab[B][C][2]
 constexpr int GN_MAXVPT = 4;
 
+// Two-source form (every GroupNorm kernel below): channels [0, C1) come from x (pixel stride ldx), channels [C1, C) from x2 (ldx2) -- the
+// ResidualConcatenator's output never exists as a tensor (unet.py:69-85: Concatenate(x, residuals[n]) feeding a ResidualBlock).  One source: C1 = C.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int64_t ldx, int HW, int C, int ppc,
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int64_t ldx1, const T* __restrict__ x2, int64_t ldx2, int C1, int HW, int C, int ppc,
                                                           int nchunk, float* __restrict__ part) {
     constexpr int EPC = DT<T>::EPC;
     __shared__ float red[256 * EPC * 2];
@@ -85,7 +87,6 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     const int pl = NV >= 256 ? 0 : tid / NV;
     const int v0 = NV >= 256 ? tid : tid % NV;
     const bool active = pl < PL;
-    const T* xb = x + (int64_t)b * HW * ldx;
     const int p0 = chunk * ppc;
     const int p1 = min(p0 + ppc, HW);
     for (int k = 0; k < VPT; ++k) {
@@ -95,10 +96,12 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 #pragma unroll
         for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = piv[e] = 0.f;
         if (on) {
-            Vec16<T> pv = load16<T>(xb + v * EPC);  // pixel 0 of this sample = pivot
+            const bool sec = v * EPC >= C1;
+            const int64_t ldx = sec ? ldx2 : ldx1;
+            const T* xv = sec ? x2 + (int64_t)b * HW * ldx2 + (v * EPC - C1) : x + (int64_t)b * HW * ldx1 + v * EPC;
+            Vec16<T> pv = load16<T>(xv);  // pixel 0 of this sample = pivot
 #pragma unroll
             for (int e = 0; e < EPC; ++e) piv[e] = pv.get(e);
-            const T* xv = xb + v * EPC;
             int px = p0 + pl;
             for (; px + 3 * PL < p1; px += 4 * PL) {  // four independent 16-byte loads in flight (a one-load loop runs at one memory round trip per pixel)
                 Vec16<T> t0 = load16<T>(xv + (int64_t)px * ldx), t1 = load16<T>(xv + (int64_t)(px + PL) * ldx), t2 = load16<T>(xv + (int64_t)(px + 2 * PL) * ldx),
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 // One workgroup per (group, sample): the cg channels of the group x nchunk partials are reduced by 256 threads in a
 // fixed order (L = 256 / cg lanes per channel, then a serial sum of the L lane totals), so the result is deterministic.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ x, int64_t ldx, int HW, int C, int G,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ x2, int64_t ldx2, int C1, int HW, int C, int G,
                                                            int nchunk, const float* __restrict__ part,
                                                            const T* __restrict__ gamma, float eps, float* __restrict__ tab) {
     __shared__ float red[256 * 2];
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
             a1 += red[(cl + cg * q) * 2 + 0];
             a2 += red[(cl + cg * q) * 2 + 1];
         }
-        const float piv = to_f32(x[(int64_t)b * HW * ldx + c]);
+        const float piv = to_f32(c < C1 ? x[(int64_t)b * HW * ldx + c] : x2[(int64_t)b * HW * ldx2 + (c - C1)]);
         mean_c[cl] = piv + a1 / n;
         m2_c[cl] = fmaxf(a2 - a1 * a1 / n, 0.f);
     }
@@ -227,8 +230,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
 // takes channel t % cg and the blocks t / cg, t / cg + L, ... (eight independent loads in flight), fixed-order tree; the raw moments are
 // turned into (mean, M2) per channel in double (the subtraction S2 - S1^2 / n is where float32 would lose digits), groups merged like above.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __restrict__ cs, int HW, int C, int G, const T* __restrict__ gamma, float eps,
-                                                              float* __restrict__ tab) {
+__global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __restrict__ cs, const float* __restrict__ cs2, int C1, int HW, int C, int G,
+                                                              const T* __restrict__ gamma, float eps, float* __restrict__ tab) {
     __shared__ float red[256 * 2];
     __shared__ double mean_c[256], m2_c[256];
     __shared__ float stat[2];
@@ -241,17 +244,19 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
     const int c = g * cg + cl;
     float s1 = 0.f, s2 = 0.f;
     if (on) {
-        const f32x2* pp = reinterpret_cast<const f32x2*>(cs) + ((int64_t)b * nblk * C + c);
+        // the two sources keep their own [block][channel] tables: C1 channels wide for x, C - C1 for x2
+        const int Cs = c < C1 ? C1 : C - C1;
+        const f32x2* pp = c < C1 ? reinterpret_cast<const f32x2*>(cs) + ((int64_t)b * nblk * C1 + c) : reinterpret_cast<const f32x2*>(cs2) + ((int64_t)b * nblk * Cs + (c - C1));
         int k = j;
         for (; k + 7 * L < nblk; k += 8 * L) {
             f32x2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(k + u * L) * C];
+            for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(k + u * L) * Cs];
             s1 += ((v[0][0] + v[1][0]) + (v[2][0] + v[3][0])) + ((v[4][0] + v[5][0]) + (v[6][0] + v[7][0]));
             s2 += ((v[0][1] + v[1][1]) + (v[2][1] + v[3][1])) + ((v[4][1] + v[5][1]) + (v[6][1] + v[7][1]));
         }
         for (; k < nblk; k += L) {
-            const f32x2 v = pp[(int64_t)k * C];
+            const f32x2 v = pp[(int64_t)k * Cs];
             s1 += v[0];
             s2 += v[1];
         }
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
 // One workgroup per pixel chunk of one sample (the chunks of gn_partial): a thread keeps the (scale, shift) of its 8 / 4 channels in registers
 // and streams its pixels with four loads in flight -- per element one FMA (+ SiLU), no per-element table reads.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx1, const T* __restrict__ x2, int64_t ldx2, int C1, T* __restrict__ out, int64_t ldo,
                                                         int HW, int C, int ppc, const float* __restrict__ tab,
                                                         const T* __restrict__ beta, int silu) {
     constexpr int EPC = DT<T>::EPC;
@@ -322,7 +327,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                 sh[e] = bt.get(e) - ma[0] * ma[1];
             }
         }
-        const T* xv = x + (int64_t)b * HW * ldx + v * EPC;
+        const bool sec = v * EPC >= C1;
+        const int64_t ldx = sec ? ldx2 : ldx1;
+        const T* xv = sec ? x2 + (int64_t)b * HW * ldx2 + (v * EPC - C1) : x + (int64_t)b * HW * ldx1 + v * EPC;
         T* ov = out + (int64_t)b * HW * ldo + v * EPC;
         auto emit = [&](const Vec16<T>& t, int px) {
             Vec16<T> o;
@@ -383,14 +390,16 @@ int run_groupnorm(const mi355x_groupnorm_args* a, hipStream_t st) {
     float* part = a->ws;
     float* tab = a->ws + (int64_t)a->B * nchunk * a->C * 2;
     const T* x = static_cast<const T*>(a->x);
-    if (a->colstats) {  // the launch that produced x left its column statistics: no statistics pass over x
-        hipLaunchKernelGGL((gn_finalize_cs_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, a->colstats, a->HW, a->C, a->G, static_cast<const T*>(a->gamma), a->eps, tab);
+    const T* x2 = static_cast<const T*>(a->x2);
+    const int C1 = x2 ? a->C1 : a->C;
+    if (a->colstats) {  // the launch(es) that produced x (and x2) left their column statistics: no statistics pass over the tensor
+        hipLaunchKernelGGL((gn_finalize_cs_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, a->colstats, a->colstats2, C1, a->HW, a->C, a->G, static_cast<const T*>(a->gamma), a->eps, tab);
     } else {
-        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, ppc, nchunk, part);
-        hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, x, a->ldx, a->HW, a->C, a->G,
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, x2, a->ldx2, C1, a->HW, a->C, ppc, nchunk, part);
+        hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, x, a->ldx, x2, a->ldx2, C1, a->HW, a->C, a->G,
                            nchunk, part, static_cast<const T*>(a->gamma), a->eps, tab);
     }
-    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, static_cast<T*>(a->out), a->ldo, a->HW,
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, x2, a->ldx2, C1, static_cast<T*>(a->out), a->ldo, a->HW,
                        a->C, ppc, tab, static_cast<const T*>(a->beta), a->silu);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
@@ -428,6 +437,10 @@ extern "C" int mi355x_groupnorm(const mi355x_groupnorm_args* a, void* stream) {
     if ((a->C * es) / 16 > 256 * GN_MAXVPT || a->C / a->G > 256) return MI355X_ESHAPE;
     if (!al16(a->x) || !al16(a->out) || !al16(a->beta)) return MI355X_ESHAPE;
     if (a->colstats && (a->HW % 32 || (reinterpret_cast<uintptr_t>(a->colstats) & 7))) return MI355X_ESHAPE;
+    if (a->x2) {  // second source: channels [C1, C)
+        if (a->C1 <= 0 || a->C1 >= a->C || (a->C1 * es) % 16 || (a->ldx2 * es) % 16 || !al16(a->x2)) return MI355X_ESHAPE;
+        if (a->colstats && (!a->colstats2 || (reinterpret_cast<uintptr_t>(a->colstats2) & 7))) return MI355X_ESHAPE;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     return a->dtype == MI355X_F32 ? run_groupnorm<float>(a, st) : run_groupnorm<bf16_t>(a, st);
 }

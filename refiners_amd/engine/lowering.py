@@ -37,7 +37,7 @@ from torch import Tensor, nn
 
 from .. import native
 
-from .packing import Act, ConvSpec, LinSpec, LoraPack, PackCache, Pool, Unsupported, _expect, cname, isa, kids, launches  # noqa: F401
+from .packing import Act, CatAct, ConvSpec, LinSpec, LoraPack, PackCache, Pool, Unsupported, _expect, cname, isa, kids, launches  # noqa: F401
 
 
 class Lowering:
@@ -61,8 +61,7 @@ class Lowering:
         # GroupNorm statistics from the epilogue of the convolution / GEMM that produces the normalised tensor (mi355x_gemm_args.colstats_out):
         # the statistics pass over that tensor disappears (2 launches per GroupNorm instead of 3); 0 = always the three-kernel GroupNorm
         self.gn_stats = os.environ.get("REFINERS_AMD_GN_STATS", "1") != "0"
-        self._cs_buf: dict[tuple[int, int], Tensor] = {}
-        self._cs_serial: dict[tuple[int, int], int] = {}
+        self._cs_buf: list[Tensor] = []
         self._lsync: Any = None          # native.LoraSync: the epoch word every program of this lowering bumps once per replay
         self._bumped: set[int] = set()   # id() of the op lists that already start with the bump
         self.device, self.dtype = device, dtype
@@ -305,16 +304,15 @@ class Lowering:
         return self.pool.get(native.lora_scratch_rows(groups, M, R, self.dtype), R), self._lsync.flags(groups, M), self._lsync
 
     def colstats_for(self, M: int, N: int, HW: int) -> Any:
-        """(buffer, serial) for the column statistics of an [M, N] image tensor about to be produced, or None when its consumer could not use
-        them (32-pixel blocks must not straddle samples).  One buffer per (M, N): the program is sequential and a GroupNorm follows its producer
-        before the next tensor of that shape is written; the serial lets groupnorm() verify exactly that instead of trusting it."""
+        """The buffer for the column statistics of an [M, N] image tensor about to be produced, or None when its consumer could not use them
+        (32-pixel blocks must not straddle samples).  One buffer per PRODUCER (they total ~60 MB for the SDXL step, nothing next to 288 GB):
+        the statistics of a tensor stay valid for as long as the tensor does -- a skip tensor is normalised (as one half of a
+        ResidualConcatenator's output) long after the next tensor of its shape has been written."""
         if not self.gn_stats or HW % 32 or N % 16 or self.device.type == "meta":
             return None
-        key = (M, N)
-        if key not in self._cs_buf:
-            self._cs_buf[key] = torch.empty(native.colstats_shape(M, N), device=self.device, dtype=torch.float32)
-        self._cs_serial[key] = self._cs_serial.get(key, 0) + 1
-        return self._cs_buf[key], self._cs_serial[key]
+        cs = torch.empty(native.colstats_shape(M, N), device=self.device, dtype=torch.float32)
+        self._cs_buf.append(cs)
+        return cs
 
     def lora_down(self, x: Tensor, lora: LoraPack) -> Tensor:
         t = self.pool.get(x.shape[0], lora.a_cat.shape[0])
@@ -340,7 +338,7 @@ class Lowering:
         n_cols = spec.N // 2 if spec.geglu else spec.N
         if out is None:
             out = self.pool.get(M, n_cols)
-        cso = None if colstats is None else colstats[0]
+        cso = colstats
         if ln is not None:
             stats, node = ln
             wl, ls, lc = self.ln_fold(spec, node)
@@ -462,7 +460,13 @@ class Lowering:
         if shortcut is not None:
             sa, sspec = shortcut
             _expect(sspec.lora is None and sspec.ksize == 1 and sspec.stride == 1, "unsupported shortcut convolution")
-            segs.append((sa.image(), sspec.w, 1, 1, 1))
+            if isinstance(sa, CatAct):  # 1x1 convolution of a concatenation = two K segments, one per part, against the matching weight columns
+                c1 = sa.a.C
+                w1, w2 = self.cache.get(("sc_split", c1) + PackCache.ident(sspec.w), lambda: (sspec.w[:, :c1].contiguous(), sspec.w[:, c1:].contiguous()))
+                segs.append((sa.a.image(), w1, 1, 1, 1))
+                segs.append((sa.b.image(), w2, 1, 1, 1))
+            else:
+                segs.append((sa.image(), sspec.w, 1, 1, 1))
         _expect(len(segs) <= native.MAX_SEG, "too many K segments for one conv launch")
         # few output tiles but a very long K (the 32 x 32-resolution convolutions of a CFG pair: 160 tiles, K = 11 520):
         # split K three ways over 128 x 128 tiles (measured 169 -> 108 us, profiles/r01_h_probe_splitk.log); the float32
@@ -478,7 +482,7 @@ class Lowering:
             sy = self.lora_sync(1, M_out, spec.lora.R)
         cs = self.colstats_for(M_out, spec.cout, OH * OW)  # most convolution outputs of a UNet are normalised next (ResidualBlock, unet.py:6-51)
         native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res, tile=tile, ksplit=ksplit, ws=ws, lora=lo, lora_sync=sy,
-                         colstats_out=None if cs is None else cs[0])
+                         colstats_out=cs)
         if sy is not None:
             self.pool.put(sy[0])
         self.pool.put(t)
@@ -492,15 +496,32 @@ class Lowering:
         return store[floats]
 
     # -- emitters: norms / glue ------------------------------------------------------------------------------
-    def groupnorm(self, a: Act, gn: Any, silu: bool) -> Act:
+    def groupnorm(self, a: Any, gn: Any, silu: bool) -> Act:
+        """GroupNorm (+ SiLU) of an activation, or of a never-materialised concatenation (CatAct: two sources).  Statistics from the producing
+        launch(es) where every part carries them."""
         _expect(isa(gn, "GroupNorm") and gn.num_channels == a.C, "GroupNorm channel mismatch")
         out = self.pool.get(a.M, a.C)
-        cs = None
-        if a.cs is not None and self._cs_serial.get((a.M, a.C)) == a.cs[1] and a.HW % 32 == 0:  # the producer's statistics are still the last ones written there
-            cs = a.cs[0]
+        oa = Act(out, a.B, a.H, a.W)
+        if isinstance(a, CatAct):
+            both = a.a.cs is not None and a.b.cs is not None and a.HW % 32 == 0
+            if both:
+                self.stats["gn_from_producer"] = self.stats.get("gn_from_producer", 0) + 1
+            native.groupnorm_nhwc(a.a.tokens(), self._w(gn.weight), self._w(gn.bias), gn.num_groups, gn.eps, silu, oa.tokens(), x2=a.b.tokens(),
+                                  colstats=a.a.cs if both else None, colstats2=a.b.cs if both else None)
+            return oa
+        cs = a.cs if a.HW % 32 == 0 else None
+        if cs is not None:
             self.stats["gn_from_producer"] = self.stats.get("gn_from_producer", 0) + 1
-        native.groupnorm_nhwc(a.tokens(), self._w(gn.weight), self._w(gn.bias), gn.num_groups, gn.eps, silu, Act(out, a.B, a.H, a.W).tokens(), colstats=cs)
-        return Act(out, a.B, a.H, a.W)
+        native.groupnorm_nhwc(a.tokens(), self._w(gn.weight), self._w(gn.bias), gn.num_groups, gn.eps, silu, oa.tokens(), colstats=cs)
+        return oa
+
+    def materialise(self, a: Any) -> Act:
+        """The real tensor of a CatAct (one streaming concat launch), for consumers that cannot read two sources."""
+        if not isinstance(a, CatAct):
+            return a
+        cat = self.pool.get(a.M, a.C)
+        native.concat2(a.a.t, a.b.t, cat)
+        return Act(cat, a.B, a.H, a.W)
 
     def layernorm(self, x: Tensor, ln: Any) -> Tensor:
         _expect(isa(ln, "LayerNorm") and tuple(ln.normalized_shape) == (x.shape[1],), "LayerNorm shape mismatch")

@@ -16,7 +16,7 @@ from torch import Tensor, nn
 from .. import native
 
 from .lowering import Lowering
-from .packing import Act, ConvSpec, LinSpec, LoraPack, PackCache, Pool, Unsupported, _expect, cname, isa, kids, launches  # noqa: F401
+from .packing import Act, CatAct, ConvSpec, LinSpec, LoraPack, PackCache, Pool, Unsupported, _expect, cname, isa, kids, launches  # noqa: F401
 
 
 class BlockLowering(Lowering):
@@ -365,6 +365,16 @@ class BlockLowering(Lowering):
         _expect(len(body) == 6 and isa(body[0], "GroupNorm") and isa(body[1], "SiLU") and isa(body[3], "GroupNorm") and isa(body[4], "SiLU"), "unexpected ResidualBlock body")
         c1, c2 = self.conv_spec(body[2]), self.conv_spec(body[5])
         _expect(c1.stride == 1 and c2.stride == 1 and c2.time is None, "unexpected convolutions in ResidualBlock")
+        src = a
+        if isinstance(a, CatAct):
+            # input = a ResidualConcatenator's (x | skip) that was never written: GroupNorm reads both parts, the 1x1 shortcut takes them as two
+            # K segments of conv2.  Anything that needs the tensor itself (identity shortcut cannot happen: channel counts differ; a shortcut
+            # with LoRAs; a third segment that does not fit) gets it materialised.
+            sc0 = None if isa(ch[1], "Identity") else self.conv_spec(ch[1])
+            seg_ok = sc0 is not None and sc0.ksize == 1 and sc0.lora is None and (c2.lora is None or (c2.lora.a_kb is not None and self.lora_inlaunch))
+            if not seg_ok or os.environ.get("REFINERS_AMD_CAT_FUSE", "1") == "0":
+                a = self.materialise(a)
+                self.stats["concat_materialised"] = self.stats.get("concat_materialised", 0) + 1
         g1 = self.groupnorm(a, body[0], silu=True)
         rb = ctx.time_bias(c1) if c1.time is not None else None
         h1 = self.conv(g1, c1, rowbias=rb)
@@ -384,6 +394,10 @@ class BlockLowering(Lowering):
                 out = self.conv(g2, c2, res=s.t)
                 self.pool.put(s.t)
         self.pool.put(g2.t)
+        if isinstance(src, CatAct):  # the block consumed the concatenation: its first part goes back to the pool (the skip stays pinned) ...
+            self.pool.put(src.a.t)
+            if a is not src:         # ... and so does the materialised copy, where one had to be made
+                self.pool.put(a.t)
         return out
 
     # -- generic fallback -------------------------------------------------------------------------------------------

@@ -51,7 +51,7 @@ class Act:
     B: int
     H: int
     W: int
-    cs: Any = None  # (column statistics [M / 32, C, 2] float32 written by the launch that produced `t`, serial) -- see Lowering.colstats_for
+    cs: Any = None  # column statistics [M / 32, C, 2] float32 written by the launch that produced `t` (Lowering.colstats_for), or None
 
     @property
     def C(self) -> int:
@@ -72,6 +72,29 @@ class Act:
     def tokens(self) -> Tensor:
         ld = self.t.stride(0)
         return self.t.as_strided((self.B, self.HW, self.C), (self.HW * ld, ld, 1))
+
+
+class CatAct:
+    """Concatenate(a, b) along the channels that is never materialised (ResidualConcatenator, unet.py:69-85): its only consumers inside a
+    ResidualBlock -- the first GroupNorm and the 1x1 shortcut convolution -- read the two parts where they are (two-source GroupNorm, two K
+    segments).  Anything else asks Lowering.materialise() for the real tensor."""
+
+    def __init__(self, a: Act, b: Act) -> None:
+        assert (a.B, a.H, a.W) == (b.B, b.H, b.W)
+        self.a, self.b = a, b
+        self.B, self.H, self.W = a.B, a.H, a.W
+
+    @property
+    def C(self) -> int:
+        return self.a.C + self.b.C
+
+    @property
+    def M(self) -> int:
+        return self.a.M
+
+    @property
+    def HW(self) -> int:
+        return self.H * self.W
 
 
 @dataclass

@@ -14,7 +14,7 @@ from torch import Tensor, nn
 from .. import native
 
 from .lowering_blocks import BlockLowering
-from .packing import Act, ConvSpec, LinSpec, LoraPack, PackCache, Pool, Unsupported, _expect, cname, isa, kids, launches  # noqa: F401
+from .packing import Act, CatAct, ConvSpec, LinSpec, LoraPack, PackCache, Pool, Unsupported, _expect, cname, isa, kids, launches  # noqa: F401
 
 
 @dataclass
@@ -273,17 +273,22 @@ class UNetLowering(BlockLowering):
         native.im2col3x3_nchw(self.io.x, cols)
         out = self.pool.get(B * H * W, conv.out_channels)
         cs = self.colstats_for(B * H * W, conv.out_channels, H * W)
-        native.gemm([(cols, wp)], out, bias=self._w(conv.bias), colstats_out=None if cs is None else cs[0])
+        native.gemm([(cols, wp)], out, bias=self._w(conv.bias), colstats_out=cs)
         self.pool.put(cols)
         return Act(out, B, H, W, cs)
 
-    def _release(self, a: Optional[Act]) -> None:
-        if a is not None:
+    def _release(self, a: Any) -> None:
+        if a is not None and not isinstance(a, CatAct):  # (the ResidualBlock that consumes a CatAct releases its first part itself)
             self.pool.put(a.t)
 
     def piece(self, m: Any, cur: Optional[Act], ctx: UNetContext, H: int, W: int) -> Optional[Act]:
         if cur is None:
             return self.stem(m)
+        if isinstance(cur, CatAct) and not isa(m, "ResidualBlock"):  # only a ResidualBlock reads a concatenation in place
+            cat = cur
+            cur = self.materialise(cat)
+            self.pool.put(cat.a.t)
+            self.stats["concat_materialised"] = self.stats.get("concat_materialised", 0) + 1
         if isa(m, "ResidualBlock"):
             out = self.residual_block(m, cur, ctx)
         elif isa(m, "CrossAttentionBlock2d"):
@@ -312,9 +317,7 @@ class UNetLowering(BlockLowering):
         elif isa(m, "ResidualConcatenator"):
             skip = self.slot(ctx, m.n)
             _expect(skip is not None and (skip.B, skip.H, skip.W) == (cur.B, cur.H, cur.W), "skip tensor missing or of another size")
-            cat = self.pool.get(cur.M, cur.C + skip.C)
-            native.concat2(cur.t, skip.t, cat)
-            out = Act(cat, cur.B, cur.H, cur.W)
+            return CatAct(cur, skip)  # (cur is released by the ResidualBlock that consumes the pair)
         elif isa(m, "ZeroConvolution"):
             self.zero_convolution(m, cur, ctx)
             return cur

@@ -244,6 +244,10 @@ class GroupNormArgs(C.Structure):
         ("ldo", C.c_int64),
         ("ws", C.c_void_p),
         ("colstats", C.c_void_p),
+        ("x2", C.c_void_p),
+        ("ldx2", C.c_int64),
+        ("C1", C.c_int32),
+        ("colstats2", C.c_void_p),
     ]
 
 
@@ -888,12 +892,18 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Tensor) -
 _gn_ws: dict[tuple[int, int], Tensor] = {}
 
 
-def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool, out: Tensor, colstats: Optional[Tensor] = None) -> Tensor:
+def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool, out: Tensor, colstats: Optional[Tensor] = None,
+                   x2: Optional[Tensor] = None, colstats2: Optional[Tensor] = None) -> Tensor:
     """x, out: [B, HW, C] views with contiguous channels.  `colstats`: what the launch that produced x wrote through `colstats_out`
-    ([B * HW / 32, C, 2] float32): the statistics pass over x is skipped."""
+    ([B * HW / 32, C, 2] float32): the statistics pass over x is skipped.  `x2` [B, HW, C2]: the normalised tensor is the channel concatenation
+    (x | x2), which never exists (out has C + C2 channels; `colstats2` then belongs to x2)."""
     a = GroupNormArgs()
-    B, HW, Cc = x.shape
-    assert x.stride(2) == 1 and out.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and out.stride(0) == HW * out.stride(1)
+    B, HW, C1 = x.shape
+    Cc = C1 + (x2.shape[2] if x2 is not None else 0)
+    assert x.stride(2) == 1 and out.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and out.stride(0) == HW * out.stride(1) and out.shape[2] == Cc
+    if x2 is not None:
+        assert x2.shape[:2] == x.shape[:2] and x2.stride(2) == 1 and x2.stride(0) == HW * x2.stride(1) and x2.dtype == x.dtype and (colstats is None) == (colstats2 is None)
+        a.x2, a.ldx2, a.C1 = x2.data_ptr(), x2.stride(1), C1
     need = load().mi355x_groupnorm_ws_floats(B, HW, Cc)
     if x.device.type == "cuda":
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
@@ -909,9 +919,12 @@ def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: flo
     a.x, a.ldx, a.gamma, a.beta, a.eps, a.silu = x.data_ptr(), x.stride(1), gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
     a.out, a.ldo, a.ws = out.data_ptr(), out.stride(1), ws.data_ptr()
     if colstats is not None:
-        assert HW % 32 == 0 and colstats.dtype == torch.float32 and colstats.is_contiguous() and colstats.numel() >= B * HW // 32 * Cc * 2
+        assert HW % 32 == 0 and colstats.dtype == torch.float32 and colstats.is_contiguous() and colstats.numel() >= B * HW // 32 * C1 * 2
         a.colstats = colstats.data_ptr()
-    _launch("mi355x_groupnorm", (C.byref(a),), "mi355x_groupnorm", keep=(ws, colstats))
+        if colstats2 is not None:
+            assert colstats2.dtype == torch.float32 and colstats2.is_contiguous() and colstats2.numel() >= B * HW // 32 * (Cc - C1) * 2
+            a.colstats2 = colstats2.data_ptr()
+    _launch("mi355x_groupnorm", (C.byref(a),), "mi355x_groupnorm", keep=(ws, colstats, x2, colstats2))
     return out
 
 

@@ -402,6 +402,29 @@ def conv_groupnorm_chain_case(B, Cin, Cout, H, W, dtype, *, ksplit=1, tile=0, si
     return _cmp(o1.float().view(B, H * W, Cout).permute(0, 2, 1), ref, dtype)
 
 
+def groupnorm_two_source_case(B, C1, C2, HW, dtype, *, stats=False, silu=True, seed=330):
+    """GroupNorm over Concatenate(x, x2) that never exists (ResidualConcatenator -> ResidualBlock): two-source kernels, optionally with each
+    part's column statistics (as its producer's epilogue would have written them) -- against torch.group_norm of the real concatenation.
+    The group width (C1 + C2) / 32 need not divide C1: groups straddle the two sources (1280 + 640 channels: 60 per group)."""
+    x = _rand(B, HW, C1, dtype=dtype, seed=seed) * 1.3 + 2.0
+    x2 = _rand(B, HW, C2, dtype=dtype, seed=seed + 1) * 0.7 - 1.0
+    Cc = C1 + C2
+    g = (1 + 0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 2)).to(dtype)
+    b = (0.1 * _rand(Cc, dtype=torch.float32, seed=seed + 3)).to(dtype)
+    out = torch.full((B, HW, Cc), float("nan"), dtype=dtype, device=DEV)
+    cs = cs2 = None
+    if stats:
+        def colstats(t):
+            blocks = t.float().reshape(B * HW // 32, 32, t.shape[2])
+            return torch.stack([blocks.sum(1), blocks.square().sum(1)], dim=-1).contiguous()
+        cs, cs2 = colstats(x), colstats(x2)
+    native.groupnorm_nhwc(x, g, b, 32, 1e-5, silu, out, x2=x2, colstats=cs, colstats2=cs2)
+    ref = F.group_norm(torch.cat([x.float(), x2.float()], dim=2).permute(0, 2, 1), 32, g.float(), b.float(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    return _cmp(out.float().permute(0, 2, 1), ref, dtype)
+
+
 # ------------------------------------------------------------------------------------------------ glue
 def layout_case(B, Cc, H, W, dtype, seed=100):
     x = _rand(B, Cc, H, W, dtype=dtype, seed=seed)
@@ -972,6 +995,11 @@ def all_cases():
             (f"colstats_{tag}_tile3", lambda dt=dt: colstats_case(320, 384, 640, dt, tile=3)),
             (f"colstats_{tag}_tile4_oddM", lambda dt=dt: colstats_case(77, 128, 64, dt, tile=4)),
             (f"colstats_{tag}_splitk3", lambda dt=dt: colstats_case(256, 3072, 320, dt, tile=1, ksplit=3)),
+            (f"groupnorm2_{tag}_1280+1280", lambda dt=dt: groupnorm_two_source_case(2, 1280, 1280, 1024, dt)),
+            (f"groupnorm2_{tag}_1280+640_straddling", lambda dt=dt: groupnorm_two_source_case(2, 1280, 640, 1024, dt)),
+            (f"groupnorm2_{tag}_640+320_stats", lambda dt=dt: groupnorm_two_source_case(2, 640, 320, 4096, dt, stats=True)),
+            (f"groupnorm2_{tag}_320+320_stats_nosilu", lambda dt=dt: groupnorm_two_source_case(1, 320, 320, 384, dt, stats=True, silu=False)),
+            (f"groupnorm2_{tag}_1280+640_stats", lambda dt=dt: groupnorm_two_source_case(2, 1280, 640, 256, dt, stats=True)),
             (f"conv_gn_{tag}_32x32x320", lambda dt=dt: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt)),
             (f"conv_gn_{tag}_splitk_16x16x640", lambda dt=dt: conv_groupnorm_chain_case(2, 640, 640, 16, 16, dt, ksplit=3, tile=1)),
             (f"conv_gn_{tag}_24x16x960_nosilu", lambda dt=dt: conv_groupnorm_chain_case(1, 320, 960, 24, 16, dt, silu=False)),
