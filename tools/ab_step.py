@@ -1,7 +1,7 @@
 """A/B of the lowering switches on the SDXL step, one process, one set of weights: step time (HIP graph) per variant and the
 per-family replay of the last one.  Variants are given as name=ENV1:val,ENV2:val ...; flags read at lowering time
 (REFINERS_AMD_LN_FUSE, REFINERS_AMD_QKV_MERGE, REFINERS_AMD_TUNING, REFINERS_AMD_KBLOCK, REFINERS_AMD_WEIGHT_PREFETCH,
-REFINERS_AMD_TIME_BATCH, REFINERS_AMD_ATTN_PIPE, REFINERS_AMD_GN_STATS, REFINERS_AMD_TIME_TABLE).
+REFINERS_AMD_TIME_BATCH, REFINERS_AMD_ATTN_PIPE, REFINERS_AMD_GN_STATS, REFINERS_AMD_TIME_TABLE, REFINERS_AMD_CAT_FUSE).
 
     python tools/ab_step.py --workload lora_ip base=REFINERS_AMD_LN_FUSE:0,REFINERS_AMD_QKV_MERGE:0,REFINERS_AMD_TUNING:0 all=
 """
@@ -23,7 +23,7 @@ from refiners_amd.engine import tuning  # noqa: E402
 from refiners_amd.engine.compiled import CompiledSDXL  # noqa: E402
 
 KEYS = ("REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH", "REFINERS_AMD_TIME_BATCH", "REFINERS_AMD_ATTN_PIPE",
-        "REFINERS_AMD_GN_STATS", "REFINERS_AMD_TIME_TABLE")
+        "REFINERS_AMD_GN_STATS", "REFINERS_AMD_TIME_TABLE", "REFINERS_AMD_CAT_FUSE")
 
 
 def main() -> None:
