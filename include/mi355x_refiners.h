@@ -163,11 +163,9 @@ typedef struct {
        The LoRAs adapt segment 0.  x A^T is computed ONCE per 32 rows, by extra workgroups at the head of the launch's grid (no column
        tile recomputes it; column groups share them: every group reads segment 0's x), rounded to `dtype` (the reference's intermediate tensor),
        handed to the output tiles through
-         lora_t     scratch, 128-BYTE aligned, >= groups * (GS + 4 * M * lora_r) bytes with GS = M * lora_r * sizeof(dtype) rounded up to a multiple of
-                    128 (group g's rows start at byte g * GS: a cache line never holds rows of two groups or of two 32-row blocks; behind the t blocks,
-                    [groups][M][lora_r] float32: the partial sums of producers that split K between two workgroups),
-         lora_flags int32[2 * groups * ceil(M / 32)] (the tiles' flags, then those producer pairs' own), zeroed once by the caller and private to
-                    this call site (they keep the last epoch),
+         lora_t     scratch, 128-BYTE aligned, >= groups * GS bytes with GS = M * lora_r * sizeof(dtype) rounded up to a multiple of 128 (group g's
+                    rows start at byte g * GS: a cache line never holds rows of two groups or of two 32-row blocks),
+         lora_flags int32[groups * ceil(M / 32)], zeroed once by the caller and private to this call site (they keep the last epoch),
          lora_epoch device pointer to an int32 whose value differs from every value left in lora_flags: increment it (mi355x_epoch_bump)
                     before each launch, or once per replay of a recorded program whose LoRA launches each own their flags,
        and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with out_f32 or the 8-wave tile;

@@ -106,8 +106,6 @@ struct GemmP {
     int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
     const int* lora_epoch;
     int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
-    int lp_ks;             // 1, or 2: every 32-row block has TWO producers, one per half of K; the second adds the first's float32 partial (kept behind the
-                           // t blocks in lora_t, its own flags behind lora_flags) before the LayerNorm correction, the rounding and the publication
     int64_t lora_gs;       // bytes from one group's t to the next: M * lora_r * sizeof(T) rounded up to 128 (a 128-byte line never holds two groups' rows)
     int lora_dbg;          // probing only (mi355x_set_option "lora_dbg", tools/probe_lora.py; timing, not results): 1 = producers exit at once (valid only
                            // while the flags still hold the epoch), 4 = tiles skip the LoRA term entirely, 8 = in-loop hand-off but no product, 16 = product but no hand-off
@@ -176,9 +174,6 @@ template <int RUN> MI_DEV void colsum16(float (&a)[RUN], float (&b)[RUN], int c1
                             // step (tools/ab_step.py, profiles/r04_d_ab_gn_prio.log): 25.379 -> 25.314 ms, three interleaved rounds each within 0.01 ms.
                             // (-DMI355X_GEMM_PRIO=0 through refiners_amd.build_native.build_variant rebuilds the old loop for an A/B.)
 #endif
-#ifndef MI355X_LORA_KSPLIT
-#define MI355X_LORA_KSPLIT 1  // two producer workgroups per 32-row block, each over half of K, where the producers are a launch's critical path (0: off)
-#endif
 constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
 constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)
 constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch (control-lora-*-rank128)
@@ -202,6 +197,11 @@ MI_DEV void st_agent8(void* p, uint64_t v) { __hip_atomic_store(reinterpret_cast
 //  wave, no LDS, no barrier, one producer per row block serving all column groups: correct, and 1.3-2x SLOWER per launch (N = K = 1280:
 //  27.0 vs 17.5 us; Q|K|V^T 62.6 vs 40.2; step 31.05 vs 25.9 ms, profiles/r04_b_*): beside tiles that keep the CU's vector-memory queue full a
 //  producer pays 2-3 us per dependent round trip whatever it asks for, and fragment-shaped loads put 4x the lines through that queue.)
+// (Also tried and removed in round 4: TWO producers per 32-row block, one per half of K, the second adding the first's float32 partial before it
+//  corrects, rounds and publishes -- for the 64 x 64-tile classes whose producers are the launch's critical path (15.7 us against tiles of 13.9).
+//  Correct (58 kernel cases, full-size parity, the two-stream stress test), and slower: N = K = 1280 18.25 vs 16.61 us, FF2 47.45 vs 45.25, step
+//  25.638 vs 25.280 ms in the same process (profiles/r04_h_probe_lora_ksplit.log, r04_h_ab_ksplit.log): twice the producer workgroups beside the
+//  tiles and a second dependent hand-off cost more than the halved K loop returns.)
 template <typename T, bool CONV, int RI, int PST>
 __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -209,17 +209,11 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
     static_assert(PST >= 2 && PST <= 8, "LoRA producer: 2..8 stages");
     const int tid = threadIdx.x, lane = tid & 63, wid = wave_id(), g = lane >> 4, c16 = lane & 15;
     const int npb = (p.M + LORA_PM - 1) / LORA_PM;
-    // K split (lp_ks == 2; plain segments only): the first npb * groups workgroups take K blocks [0, h0), the next npb * groups the rest.  The first
-    // halves have the LOWER workgroup ids, so they are dispatched before the second halves that will wait for them (same argument as tiles / producers).
-    const int kh = p.lp_ks > 1 ? q / (npb * p.lora_groups) : 0;
-    const int qq0 = q - kh * npb * p.lora_groups;
-    const int pgi = qq0 / npb, tm = qq0 - pgi * npb, m0 = tm * LORA_PM;
+    const int pgi = q / npb, tm = q - pgi * npb, m0 = tm * LORA_PM;
     const int tag = *p.lora_epoch;
     if (p.lora_dbg & 32) __builtin_amdgcn_s_setprio(3);  // (probing: producers' instructions win the CU's issue arbitration against co-resident tiles)
     const SegP& sp = p.seg[0];  // the LoRAs adapt segment 0 (the conv / Linear itself, not a fused shortcut)
-    const int h0 = p.lp_ks > 1 ? (sp.nkb + 1) / 2 : sp.nkb;
-    const int kb0 = kh ? h0 : 0;              // first K block of this producer
-    const int nkb = kh ? sp.nkb - h0 : h0;    // ... and how many it multiplies
+    const int nkb = sp.nkb;
     // ---- this thread's piece of the x tile: row tid >> 3, logical chunk tid & 7 (swizzled source chunk, lane-linear LDS image) ----
     const int row = tid >> 3, pch = tid & 7;
     const int xcoff = (pch ^ swz<128>(row)) << 4;
@@ -234,8 +228,8 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
         xox = rem - xoy * p.OW;
     }
     const char* xbase = nullptr;
+    int64_t xoff = 0, woff = 0;
     const int64_t xstep = CONV ? 128 : (sp.xkb ? (int64_t)p.M * 128 : 128), wstep = (int64_t)p.lora_r * 128;
-    int64_t xoff = (int64_t)kb0 * xstep, woff = (int64_t)kb0 * wstep;  // (kb0 > 0 only without CONV: the tap walk below starts at block 0)
     int tap = 0, cb = 0;
     auto set_tap = [&]() __attribute__((always_inline)) {
         int dy = tap / sp.ksize, dx = tap - dy * sp.ksize;
@@ -285,8 +279,7 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
     float mean = 0.f, inv = 1.f;
     constexpr int MAXP = 48;  // partials held in registers at once (K <= 1536 in one batch)
     f32x2 lst[MAXP];
-    const bool publisher = kh == p.lp_ks - 1;  // the producer that corrects, rounds and publishes t (with lp_ks == 2: the second half)
-    const float* sp2 = p.ln_stats && publisher ? p.ln_stats + (int64_t)min(m, p.M - 1) * 2 : nullptr;
+    const float* sp2 = p.ln_stats ? p.ln_stats + (int64_t)min(m, p.M - 1) * 2 : nullptr;
     const int64_t pstride = (int64_t)p.M * 2;
     if (sp2) {
 #pragma unroll
@@ -323,44 +316,6 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
             for (int j = 0; j < RI; ++j) {
                 const frag_t af = lds_read_frag(st + PXB, tile_off<128>((rg * RI + j) * 16 + c16, 4 * kk + g));
                 mma_step<T>(ta[j], af, xf);  // D[rank 16 (rg RI + j) + 4 g + r][row 16 rb + c16]
-            }
-        }
-    }
-    if (p.lp_ks > 1) {
-        // float32 partials [groups][M][R] behind the t blocks; their flags [groups][npb] behind the tiles' flags.  Same hand-off form as t itself:
-        // write-through 8-byte stores, vmcnt(0), barrier, flag; the reader polls with L1-bypassing loads (bounded by the wall clock), then reads the
-        // partial with L1-bypassing loads as well.
-        float* part = reinterpret_cast<float*>(p.lora_t + p.lora_groups * p.lora_gs) + (int64_t)pgi * p.M * p.lora_r;
-        int* pflag = p.lora_flags + p.lora_groups * npb + pgi * npb + tm;
-        if (kh == 0) {
-            if (m < p.M) {
-#pragma unroll
-                for (int j = 0; j < RI; ++j) {
-                    float* dst = part + (int64_t)m * p.lora_r + (rg * RI + j) * 16 + 4 * g;
-                    st_agent8(dst, __builtin_bit_cast(uint64_t, f32x2{ta[j][0], ta[j][1]}));
-                    st_agent8(dst + 2, __builtin_bit_cast(uint64_t, f32x2{ta[j][2], ta[j][3]}));
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(pflag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (tid == 0) {
-            const uint64_t t0 = wall_clock64();
-            while (__hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-                __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > 200000000ull) __builtin_trap();  // 2 s: a lost first half must not hang the GPU
-            }
-        }
-        __syncthreads();
-        if (m < p.M) {
-#pragma unroll
-            for (int j = 0; j < RI; ++j) {
-                const uint64_t* src = reinterpret_cast<const uint64_t*>(part + (int64_t)m * p.lora_r + (rg * RI + j) * 16 + 4 * g);
-                const f32x2 lo = __builtin_bit_cast(f32x2, __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const f32x2 hi = __builtin_bit_cast(f32x2, __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                ta[j] = f32x4{lo[0] + ta[j][0], lo[1] + ta[j][1], hi[0] + ta[j][2], hi[1] + ta[j][3]};  // first half + second half: a fixed order
             }
         }
     }
@@ -451,7 +406,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     int bid = (int)blockIdx.x - p.pf_blocks;
     if constexpr (LORA) {
         if (bid < p.lp_blocks) {  // LoRA producer role: see lora_producer (a separate function; nothing of it lives in the tiles' path)
-            if ((p.lora_dbg & 1) || bid >= (p.M + LORA_PM - 1) / LORA_PM * p.lora_groups * p.lp_ks) return;  // (probing) / padding up to a multiple of 8
+            if ((p.lora_dbg & 1) || bid >= (p.M + LORA_PM - 1) / LORA_PM * p.lora_groups) return;  // (probing) / padding up to a multiple of 8
             constexpr int RING = KG * NSTAGE * (BM + BN) * 128;
             constexpr int PB1 = (LORA_PM + 32) * 128, PB2 = (LORA_PM + 64) * 128, PB4 = (LORA_PM + 128) * 128;  // bytes per producer stage
             constexpr int P1 = RING / PB1 < 8 ? RING / PB1 : 8, P2 = RING / PB2 < 8 ? RING / PB2 : 8, P4 = RING / PB4;
@@ -1339,11 +1294,8 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     q.pf_blocks = (q.pf_blocks + 7) / 8 * 8;  // a multiple of 8: compute block b still lands on XCD b % 8
     if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
     q.pf_mode = g_pf_mode;
-    q.lora_dbg = g_lora_dbg;  // (bit 64: no K-split producer pairs -- the A/B switch of tools/probe_lora.py)
-    // K-split producer pairs where the producers are the launch's critical path: the 64 x 64 tile's 32 KB ring holds three K blocks, a producer of a
-    // K = 1280 launch then needs longer than the tiles it serves (profiles/r04_c_probe_lora.log: 15.7 vs 13.9 us)
-    q.lp_ks = (MI355X_LORA_KSPLIT && LORA && !CONV && BM * BN == 64 * 64 && q.lora_groups == 1 && q.seg[0].nkb >= 16 && !(q.lora_dbg & 64)) ? 2 : 1;
-    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups * q.lp_ks + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
+    q.lora_dbg = g_lora_dbg;
+    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
     const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), q.ln_stats ? LDS : LDS - BM * 8, stream, q);

@@ -523,7 +523,7 @@ class LoraSync:
         self.keep: list = []
 
     def flags(self, groups: int, M: int) -> Tensor:
-        f = torch.zeros(2 * groups * ((M + 31) // 32), dtype=torch.int32, device=self.device)  # the tiles' flags, then the K-split producer pairs' own
+        f = torch.zeros(groups * ((M + 31) // 32), dtype=torch.int32, device=self.device)
         self.keep.append(f)
         return f
 
@@ -541,11 +541,9 @@ _eager_sync: dict[int, "LoraSync"] = {}
 
 
 def lora_scratch_rows(groups: int, M: int, R: int, dtype: torch.dtype) -> int:
-    """Rows of R elements the in-launch LoRA hand-off scratch needs: every group's t block starts on a 128-byte line, and behind the t blocks
-    there is room for the float32 partials of K-split producer pairs, [groups][M][R] (mi355x_gemm_args.lora_t)."""
-    es = 4 if dtype == torch.float32 else 2
-    rb = R * es
-    return groups * (((M * rb + 127) // 128 * 128) // rb) + groups * M * 4 // es
+    """Rows of R elements the in-launch LoRA hand-off scratch needs: every group's block starts on a 128-byte line (mi355x_gemm_args.lora_t)."""
+    rb = R * (4 if dtype == torch.float32 else 2)
+    return groups * (((M * rb + 127) // 128 * 128) // rb)
 
 
 def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: int, keep: list, sync: Optional[tuple]) -> None:
@@ -573,7 +571,7 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
         sync = (ls.scratch(len(groups), a.M, R, dtype), ls.flags(len(groups), a.M), ls)
     t, flags, ls = sync
     assert t.numel() >= lora_scratch_rows(len(groups), a.M, R, dtype) * R and t.dtype == dtype and t.data_ptr() % 128 == 0
-    assert flags.numel() >= 2 * len(groups) * ((a.M + 31) // 32) and flags.dtype == torch.int32
+    assert flags.numel() >= len(groups) * ((a.M + 31) // 32) and flags.dtype == torch.int32
     a.lora_t, a.lora_flags, a.lora_epoch = t.data_ptr(), flags.data_ptr(), ls.epoch.data_ptr()
     keep.append((lora, t, flags, ls))
 

@@ -1,6 +1,6 @@
 """Where the in-launch LoRA's time goes, per shape class of the SDXL step (hot weights, HIP graph of N launches, bf16):
   plain      the un-adapted launch (what lora_mode="merged" runs)
-  full       producers + tiles, epoch bumped before every launch (what lora_mode="fused" runs); full,1prod = the same without K-split producer pairs
+  full       producers + tiles, epoch bumped before every launch (what lora_mode="fused" runs)
   nowait     the same launches WITHOUT the bump: the flags still hold the epoch, no tile ever waits (producers still run)
   tail       nowait + producers exit at once (mi355x_set_option lora_dbg 1): only the tiles' hand-off + up-projection remain
   as-plain / hooks-only / mma-only   tail minus: everything (the LoRA kernel variant doing an un-adapted launch's work) / the post-loop product /
@@ -92,8 +92,8 @@ def case(M, K, N, *, geglu=False, ln=False, qkv=False, tile=0, ranks=(16, 16), o
     if only is None:
         res["bump+plain"] = graph_time(bump_plain)
         res["full"] = graph_time(full)
-        lib.mi355x_set_option(b"lora_dbg", 64)  # no K-split producer pairs (the round-3 form: one producer per 32-row block over all of K)
-        res["full,1prod"] = graph_time(full)
+        lib.mi355x_set_option(b"lora_dbg", 32)  # producers at s_setprio 3
+        res["full+prio"] = graph_time(full)
         lib.mi355x_set_option(b"lora_dbg", 0)
     sync.bump()
     native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, lora=lora, lora_sync=(t, flags, sync), **kw)  # flags now hold the epoch
