@@ -165,7 +165,7 @@ typedef struct {
        handed to the output tiles through
          lora_t     scratch, 128-BYTE aligned, >= groups * GS bytes with GS = M * lora_r * sizeof(dtype) rounded up to a multiple of 128 (group g's
                     rows start at byte g * GS: a cache line never holds rows of two groups or of two 32-row blocks),
-         lora_flags int32[groups * ceil(M / 16)] (one flag per producer: 32 rows, or 16), zeroed once by the caller and private to this call site (they keep the last epoch),
+         lora_flags int32[groups * ceil(M / 32)], zeroed once by the caller and private to this call site (they keep the last epoch),
          lora_epoch device pointer to an int32 whose value differs from every value left in lora_flags: increment it (mi355x_epoch_bump)
                     before each launch, or once per replay of a recorded program whose LoRA launches each own their flags,
        and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with out_f32 or the 8-wave tile;

@@ -106,7 +106,6 @@ struct GemmP {
     int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
     const int* lora_epoch;
     int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
-    int lp_pm;             // rows per producer workgroup = rows per flag: 32, or 16
     int64_t lora_gs;       // bytes from one group's t to the next: M * lora_r * sizeof(T) rounded up to 128 (a 128-byte line never holds two groups' rows)
     int lora_dbg;          // probing only (mi355x_set_option "lora_dbg", tools/probe_lora.py; timing, not results): 1 = producers exit at once (valid only
                            // while the flags still hold the epoch), 4 = tiles skip the LoRA term entirely, 8 = in-loop hand-off but no product, 16 = product but no hand-off
@@ -175,12 +174,8 @@ template <int RUN> MI_DEV void colsum16(float (&a)[RUN], float (&b)[RUN], int c1
                             // step (tools/ab_step.py, profiles/r04_d_ab_gn_prio.log): 25.379 -> 25.314 ms, three interleaved rounds each within 0.01 ms.
                             // (-DMI355X_GEMM_PRIO=0 through refiners_amd.build_native.build_variant rebuilds the old loop for an A/B.)
 #endif
-#ifndef MI355X_LORA_PM16
-#define MI355X_LORA_PM16 1  // 16-row LoRA producers for the rank-32 launches of the 64 x 64 tile (0: 32-row producers everywhere; A/B builds)
-#endif
 constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
-constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop);
-                               // 16 (GemmP::lp_pm) for the rank-32 launches of the 64 x 64 tile, whose 32 KB ring then holds five stages instead of four
+constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)
 constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch (control-lora-*-rank128)
 
 // 8-byte relaxed agent-scope store: sc1 (write-through) on gfx950, the producer half of the hand-off forms the microarchitecture guide lists
@@ -207,22 +202,23 @@ MI_DEV void st_agent8(void* p, uint64_t v) { __hip_atomic_store(reinterpret_cast
 //  Correct (58 kernel cases, full-size parity, the two-stream stress test), and slower: N = K = 1280 18.25 vs 16.61 us, FF2 47.45 vs 45.25, step
 //  25.638 vs 25.280 ms in the same process (profiles/r04_h_probe_lora_ksplit.log, r04_h_ab_ksplit.log): twice the producer workgroups beside the
 //  tiles and a second dependent hand-off cost more than the halved K loop returns.)
-template <typename T, bool CONV, int RI, int PST, int PM = LORA_PM>
+// (And: 16-row producers for the rank-32 launches of the 64 x 64 tile -- five ring stages in the 32 KB instead of three K blocks in flight, twice the
+//  flags.  Correct on the same cases; per launch indistinguishable (N = K = 1280: 17.40 vs 17.42 us; FF2 46.27 vs 46.23), step 26.367 vs 26.260 ms in
+//  the same process (profiles/r04_i_probe_lora_pm16.log, r04_i_ab_pm16.log): ring depth is not what holds these producers back either.)
+template <typename T, bool CONV, int RI, int PST>
 __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NTHR = 256, PXB = PM * 128, PSTAGE = PXB + 32 * RI * 128, PD = PST - 1, PL = 1 + RI;
+    constexpr int NTHR = 256, PXB = LORA_PM * 128, PSTAGE = PXB + 32 * RI * 128, PD = PST - 1, PL = 1 + RI;
     static_assert(PST >= 2 && PST <= 8, "LoRA producer: 2..8 stages");
-    static_assert(PM == 32 || (PM == 16 && RI == 1), "16-row producers: rank 32 only (waves 0 / 1 take one rank block each, waves 2 / 3 only load)");
     const int tid = threadIdx.x, lane = tid & 63, wid = wave_id(), g = lane >> 4, c16 = lane & 15;
-    const int npb = (p.M + PM - 1) / PM;
-    const int pgi = q / npb, tm = q - pgi * npb, m0 = tm * PM;
-    const bool xloader = tid < PM * 8;  // threads that carry a 16-byte piece of the x tile (all 256 for 32 rows, the first two waves for 16)
+    const int npb = (p.M + LORA_PM - 1) / LORA_PM;
+    const int pgi = q / npb, tm = q - pgi * npb, m0 = tm * LORA_PM;
     const int tag = *p.lora_epoch;
     if (p.lora_dbg & 32) __builtin_amdgcn_s_setprio(3);  // (probing: producers' instructions win the CU's issue arbitration against co-resident tiles)
     const SegP& sp = p.seg[0];  // the LoRAs adapt segment 0 (the conv / Linear itself, not a fused shortcut)
     const int nkb = sp.nkb;
     // ---- this thread's piece of the x tile: row tid >> 3, logical chunk tid & 7 (swizzled source chunk, lane-linear LDS image) ----
-    const int row = (tid >> 3) & (PM - 1), pch = tid & 7;
+    const int row = tid >> 3, pch = tid & 7;
     const int xcoff = (pch ^ swz<128>(row)) << 4;
     const bool xvalid = m0 + row < p.M;
     const int xm = xvalid ? m0 + row : p.M - 1;
@@ -263,7 +259,7 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
         const char* src;
         if constexpr (CONV) src = xbase ? xbase + (int64_t)cb * 128 : p.zeros + xcoff;
         else src = xbase + xoff;
-        if (PM == 32 || xloader) glds16(src, st + wid * 64 * 16);  // (wave-uniform: whole waves are loaders or not)
+        glds16(src, st + wid * 64 * 16);
 #pragma unroll
         for (int j = 0; j < RI; ++j) glds16(pw[j] + woff, st + PXB + (j * NTHR + wid * 64) * 16);
         ++kb;
@@ -281,9 +277,7 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
     // ---- LayerNorm folded in: (mean, 1 / rstd) of this lane's row 16 rb + c16.  The producer launch's 32-column partials are requested
     // BEFORE the first stages and merged after their issue: one round trip, overlapped with the stages' (a serial load-merge chain
     // would be ln_parts dependent L2 round trips at the head of every producer).
-    // the wave's product: 32 rows -> row block wid & 1 x rank blocks (wid >> 1) RI ..; 16 rows -> the one row block x rank block wid (waves 0 and 1)
-    const int rb = PM == 32 ? (wid & 1) : 0, rg = PM == 32 ? (wid >> 1) : wid;
-    const bool mma_wave = PM == 32 || wid < 2;
+    const int rb = wid & 1, rg = wid >> 1;
     const int mrow = 16 * rb + c16, m = m0 + mrow;
     float mean = 0.f, inv = 1.f;
     constexpr int MAXP = 48;  // partials held in registers at once (K <= 1536 in one batch)
@@ -312,17 +306,12 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
 #pragma unroll
     for (int j = 0; j < RI; ++j) ta[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nkb; ++t) {
-        if (t + PD <= nkb) {  // block t has landed, the PD - 1 younger ones stay in flight (a wave that loads no x has RI requests per stage, not 1 + RI)
-            if (PM == 32 || xloader) wait_vm<(PD - 1) * PL>();
-            else wait_vm<(PD - 1) * RI>();
-        } else {
-            wait_vm0();
-        }
+        if (t + PD <= nkb) wait_vm<(PD - 1) * PL>();  // block t has landed, the PD - 1 younger ones stay in flight
+        else wait_vm0();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (t + PD < nkb) issue_p((t + PD) % PST);  // into the buffer block t - 1 was read from (every wave retired those reads above)
         const char* st = smem + (t % PST) * PSTAGE;
-        if (!mma_wave) continue;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const frag_t xf = lds_read_frag(st, tile_off<128>(16 * rb + c16, 4 * kk + g));
@@ -343,7 +332,7 @@ __device__ __forceinline__ void lora_producer(const GemmP& p, int q) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean * sa[e]) + ca[e] * inv;
         }
-        if (m < p.M && mma_wave) {
+        if (m < p.M) {
             char* dst = tg + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
             if constexpr (sizeof(T) == 4) {
                 st_agent8(dst, __builtin_bit_cast(uint64_t, f32x2{v[0], v[1]}));
@@ -420,15 +409,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     int bid = (int)blockIdx.x - p.pf_blocks;
     if constexpr (LORA) {
         if (bid < p.lp_blocks) {  // LoRA producer role: see lora_producer (a separate function; nothing of it lives in the tiles' path)
-            if ((p.lora_dbg & 1) || bid >= (p.M + p.lp_pm - 1) / p.lp_pm * p.lora_groups) return;  // (probing) / padding up to a multiple of 8
+            if ((p.lora_dbg & 1) || bid >= (p.M + LORA_PM - 1) / LORA_PM * p.lora_groups) return;  // (probing) / padding up to a multiple of 8
             constexpr int RING = KG * NSTAGE * (BM + BN) * 128;
-            if constexpr (!CONV && BM * BN == 64 * 64) {
-                if (p.lp_pm == 16) {  // (host: rank 32, one group)
-                    constexpr int P16 = RING / ((16 + 32) * 128) < 8 ? RING / ((16 + 32) * 128) : 8;
-                    lora_producer<T, false, 1, P16, 16>(p, bid);
-                    return;
-                }
-            }
             constexpr int PB1 = (LORA_PM + 32) * 128, PB2 = (LORA_PM + 64) * 128, PB4 = (LORA_PM + 128) * 128;  // bytes per producer stage
             constexpr int P1 = RING / PB1 < 8 ? RING / PB1 : 8, P2 = RING / PB2 < 8 ? RING / PB2 : 8, P4 = RING / PB4;
             if (p.lora_r == 32) lora_producer<T, CONV, 1, P1>(p, bid);
@@ -718,11 +700,11 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     auto lora_poll = [&]() __attribute__((always_inline)) {  // lanes 0 .. BM / 32 - 1 of EVERY wave: one flag each (no cross-wave hand-off needed)
         {
             const int z = opaque0();
-            const int nfl = (p.M + p.lp_pm - 1) / p.lp_pm, fb = m0 / p.lp_pm + lane + z;
+            const int nfl = (p.M + LORA_PM - 1) / LORA_PM, fb = m0 / LORA_PM + lane + z;
             // both are VECTOR loads (address through z): nothing here waits -- a scalar load of the epoch would park wave 0 on lgkmcnt(0)
             // for a memory round trip, and with it the workgroup's next barrier
             lora_tg = p.lora_epoch[z];
-            const bool mine = lane < BM / p.lp_pm && fb < nfl;
+            const bool mine = lane < BM / LORA_PM && fb < nfl;
             lora_fl = p.lora_flags[mine ? lgi * nfl + fb : 0];  // plain load (see above); lanes without a row block compare equal below
             lora_mine = mine;
         }
@@ -845,9 +827,9 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             if (p.lora_dbg & 16) lora_ok = 1;  // (probing: no hand-off at all, the product runs on whatever the registers hold)
             if (!lora_ok) {  // this wave did not see its flags set from inside the loop (a short K loop, or a producer still running): wait here, bounded by the wall clock
                 {
-                    const int nfl = (p.M + p.lp_pm - 1) / p.lp_pm, fb = m0 / p.lp_pm + lane;
+                    const int nfl = (p.M + LORA_PM - 1) / LORA_PM, fb = m0 / LORA_PM + lane;
                     const int tag = *p.lora_epoch;
-                    if (lane < BM / p.lp_pm && fb < nfl) {
+                    if (lane < BM / LORA_PM && fb < nfl) {
                         const int* fp = p.lora_flags + lgi * nfl + fb;
                         const uint64_t t0 = wall_clock64();
                         while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {  // L1-bypassing: correct whatever this CU has cached
@@ -1316,10 +1298,7 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
     q.pf_mode = g_pf_mode;
     q.lora_dbg = g_lora_dbg;
-    // 16-row producers where the producers are the launch's critical path: the 64 x 64 tile's 32 KB ring holds four 32-row stages (three K blocks in
-    // flight), a producer of a K = 1280 launch then needs longer than the tiles it serves (profiles/r04_c_probe_lora.log: 15.7 vs 13.9 us)
-    q.lp_pm = (MI355X_LORA_PM16 && LORA && !CONV && BM * BN == 64 * 64 && q.lora_groups == 1 && q.lora_r == 32 && q.seg[0].nkb >= 16 && !(g_lora_dbg & 64)) ? 16 : LORA_PM;
-    q.lp_blocks = LORA ? ((q.M + q.lp_pm - 1) / q.lp_pm * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
+    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
     const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), q.ln_stats ? LDS : LDS - BM * 8, stream, q);

@@ -523,7 +523,7 @@ class LoraSync:
         self.keep: list = []
 
     def flags(self, groups: int, M: int) -> Tensor:
-        f = torch.zeros(groups * ((M + 15) // 16), dtype=torch.int32, device=self.device)  # one flag per 32 rows, per 16 where the producers are 16-row ones
+        f = torch.zeros(groups * ((M + 31) // 32), dtype=torch.int32, device=self.device)
         self.keep.append(f)
         return f
 
@@ -571,7 +571,7 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
         sync = (ls.scratch(len(groups), a.M, R, dtype), ls.flags(len(groups), a.M), ls)
     t, flags, ls = sync
     assert t.numel() >= lora_scratch_rows(len(groups), a.M, R, dtype) * R and t.dtype == dtype and t.data_ptr() % 128 == 0
-    assert flags.numel() >= len(groups) * ((a.M + 15) // 16) and flags.dtype == torch.int32
+    assert flags.numel() >= len(groups) * ((a.M + 31) // 32) and flags.dtype == torch.int32
     a.lora_t, a.lora_flags, a.lora_epoch = t.data_ptr(), flags.data_ptr(), ls.epoch.data_ptr()
     keep.append((lora, t, flags, ls))
 

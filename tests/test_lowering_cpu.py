@@ -342,3 +342,40 @@ def test_groupnorm_takes_its_statistics_from_the_producing_launch_where_there_is
     low0, _, _ = lower("0")
     assert all(not e[1][0]._obj.colstats for e in low0.step if e[2] == "mi355x_groupnorm") and "gn_from_producer" not in low0.stats
     assert [e[2] for e in low0.step] == [e[2] for e in low.step][:-1]  # same program otherwise
+
+
+def test_a_residual_block_reads_a_concatenation_that_was_never_written(monkeypatch):
+    """ResidualConcatenator -> ResidualBlock (latent_diffusion/unet.py:69-85): the block's first GroupNorm takes the two parts as two sources (with both
+    producers' column statistics where they exist), its 1x1 shortcut as two K segments of conv2 -- no concat launch, the skip tensor stays where it is.
+    REFINERS_AMD_CAT_FUSE=0 writes the concatenation again.  Recorded on the CPU device: nothing is launched."""
+    from refiners_amd.engine.lowering_blocks import BlockLowering
+    from refiners_amd.engine.packing import Act, CatAct
+    from refiners_amd.engine.unet_lowering import UNetContext
+    from refiners_amd.latent_diffusion.blocks import ResidualBlock
+
+    torch.manual_seed(0)
+    first, block = ResidualBlock(64, 64), ResidualBlock(64 + 128, 128)
+    B, H, W = 2, 8, 8
+
+    def lower(flag: str):
+        monkeypatch.setenv("REFINERS_AMD_CAT_FUSE", flag)
+        low = BlockLowering(torch.device("cpu"), torch.float32)
+        ctx = UNetContext(low, B)
+        with low.in_step():
+            x = low.residual_block(first, Act(low.pool.get(B * H * W, 64), B, H, W), ctx)      # carries its producer's statistics
+            skip = Act(low.pool.get(B * H * W, 128), B, H, W)                                  # a skip tensor from somewhere else: none
+            out = low.residual_block(block, CatAct(x, skip), ctx)
+        return low, out
+
+    low, out = lower("1")
+    names = [e[2] for e in low.step]
+    assert "mi355x_concat2" not in names and "concat_materialised" not in low.stats and out.C == 128
+    gn = [e[1][0]._obj for e in low.step if e[2] == "mi355x_groupnorm"][2]  # the second block's first GroupNorm
+    assert gn.C == 192 and gn.C1 == 64 and gn.x2 and not gn.colstats  # two sources; the skip has no statistics, so the pass over both parts runs
+    conv2 = [e[1][0]._obj for e in low.step if e[2] == "mi355x_gemm(conv)"][-1]
+    assert conv2.nseg == 3 and [int(conv2.seg[i].k) for i in range(3)] == [128, 64, 128] and [int(conv2.seg[i].ksize) for i in range(3)] == [3, 1, 1]
+    low0, _ = lower("0")
+    names0 = [e[2] for e in low0.step]
+    assert names0.count("mi355x_concat2") == 1 and low0.stats["concat_materialised"] == 1 and len(names0) == len(names) + 1
+    conv2 = [e[1][0]._obj for e in low0.step if e[2] == "mi355x_gemm(conv)"][-1]
+    assert conv2.nseg == 2 and int(conv2.seg[1].k) == 192

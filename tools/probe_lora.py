@@ -92,8 +92,8 @@ def case(M, K, N, *, geglu=False, ln=False, qkv=False, tile=0, ranks=(16, 16), o
     if only is None:
         res["bump+plain"] = graph_time(bump_plain)
         res["full"] = graph_time(full)
-        lib.mi355x_set_option(b"lora_dbg", 64)  # 32-row producers everywhere (the round-3 form)
-        res["full,pm32"] = graph_time(full)
+        lib.mi355x_set_option(b"lora_dbg", 32)  # producers at s_setprio 3
+        res["full+prio"] = graph_time(full)
         lib.mi355x_set_option(b"lora_dbg", 0)
     sync.bump()
     native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, lora=lora, lora_sync=(t, flags, sync), **kw)  # flags now hold the epoch
