@@ -106,6 +106,7 @@ struct GemmP {
     int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
     const int* lora_epoch;
     int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
+    int lora_tt;           // 1 = no producers: the lp_blocks workgroups at the head of the grid are t-TILES (one per row tile; see gemm_kernel)
     int64_t lora_gs;       // bytes from one group's t to the next: M * lora_r * sizeof(T) rounded up to 128 (a 128-byte line never holds two groups' rows)
     int lora_dbg;          // probing only (mi355x_set_option "lora_dbg", tools/probe_lora.py; timing, not results): 1 = producers exit at once (valid only
                            // while the flags still hold the epoch), 4 = tiles skip the LoRA term entirely, 8 = in-loop hand-off but no product, 16 = product but no hand-off
@@ -173,6 +174,10 @@ template <int RUN> MI_DEV void colsum16(float (&a)[RUN], float (&b)[RUN], int c1
                             // workgroup's matrix instructions win the issue arbitration against this one's address arithmetic.  Same-process A/B of the whole
                             // step (tools/ab_step.py, profiles/r04_d_ab_gn_prio.log): 25.379 -> 25.314 ms, three interleaved rounds each within 0.01 ms.
                             // (-DMI355X_GEMM_PRIO=0 through refiners_amd.build_native.build_variant rebuilds the old loop for an A/B.)
+#endif
+#ifndef MI355X_LORA_TT
+#define MI355X_LORA_TT 1  // where t comes from t-tiles instead of producers: 0 = nowhere, 1 = launches with more than one column group (Q|K|V^T), 2 = every
+                          // launch whose tile is wide enough for groups x rank columns.  (lora_dbg 64 / 128 force 0 / 2 at run time: tools/probe_lora.py)
 #endif
 constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
 constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)
@@ -407,8 +412,20 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         return;
     }
     int bid = (int)blockIdx.x - p.pf_blocks;
+    // LORA, t-tile role (GemmP::lora_tt): workgroup `bid` of the grid's head runs the ORDINARY tile path on row tile `bid` against a virtual column tile
+    // whose "weights" are the stacked down rows of all column groups (virtual column v = group v / R, rank v % R; columns past groups x R re-read
+    // rank 0 and are dropped), and publishes t + the row blocks' flags instead of an output tile.  Same K loop as its neighbours, so t arrives when
+    // they leave theirs -- but a launch whose tiles fill the chip's resident slots exactly (Q|K|V^T at a CFG pair: 480 tiles of 128 x 128 on 2 x 256
+    // slots) no longer starts a third of them one producer-duration late behind 192 producer workgroups.
+    bool ttile = false;
+    if constexpr (LORA && !CONV) {
+        if (p.lora_tt && bid < p.lp_blocks) {
+            if ((p.lora_dbg & 1) || bid >= p.tiles_m) return;  // (probing) / padding up to a multiple of 8
+            ttile = true;
+        }
+    }
     if constexpr (LORA) {
-        if (bid < p.lp_blocks) {  // LoRA producer role: see lora_producer (a separate function; nothing of it lives in the tiles' path)
+        if (!ttile && bid < p.lp_blocks) {  // LoRA producer role: see lora_producer (a separate function; nothing of it lives in the tiles' path)
             if ((p.lora_dbg & 1) || bid >= (p.M + LORA_PM - 1) / LORA_PM * p.lora_groups) return;  // (probing) / padding up to a multiple of 8
             constexpr int RING = KG * NSTAGE * (BM + BN) * 128;
             constexpr int PB1 = (LORA_PM + 32) * 128, PB2 = (LORA_PM + 64) * 128, PB4 = (LORA_PM + 128) * 128;  // bytes per producer stage
@@ -418,12 +435,15 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             else if constexpr (P4 >= 2) lora_producer<T, CONV, 4, (P4 < 8 ? P4 : 8)>(p, bid);  // (the host routes rank-128 launches to the 128-column tiles)
             return;
         }
-        bid -= p.lp_blocks;
+        if (!ttile) bid -= p.lp_blocks;
     }
     const int split = p.ksplit > 1 ? bid / p.grid0 : 0;
     const int bx = bid - split * p.grid0;
     int tm, tn;
-    if (p.pn > 0) {  // rectangular regions (exact split of the tile grid, grid0 = 8 * hm * hn)
+    if (ttile) {
+        tm = bid;
+        tn = 0;
+    } else if (p.pn > 0) {  // rectangular regions (exact split of the tile grid, grid0 = 8 * hm * hn)
         const int xcd = bx & 7, idx = bx >> 3;
         const int rm = xcd / p.pn, rn = xcd - rm * p.pn;
         const int lm = idx / p.hn, ln = idx - lm * p.hn;
@@ -441,7 +461,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     }
     if (tm >= p.tiles_m || tn >= p.tiles_n) return;
     const int m0 = tm * BM, n0 = tn * BN;
-    const bool tr = !CONV && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
+    const bool tr = !CONV && !ttile && n0 >= p.nt_begin;  // workgroup-uniform: this tile is stored transposed (operand roles swapped)
 
     // ---- per-thread loader coordinates (fixed for the whole K loop) ----
     // Exactly one operand's rows are permuted inside each wave's 16*T-row span (see the header): the weights' normally, the
@@ -478,6 +498,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         const int rl = row % WNE, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
         const int n = n0 + (tr ? row : (row - rl) + 4 * NT * a + 4 * j + b);
         wnrow[it] = n < p.N ? n : p.N - 1;
+        if (LORA && ttile) wnrow[it] = n < p.lora_groups * p.lora_r ? n : 0;  // virtual column (n0 = 0)
     }
 
     f32x4 acc[MT][NT];
@@ -486,8 +507,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // in-launch LoRA: column group of this tile, and whether this workgroup adds the LoRA term (split-K: the first split only)
-    const int lgi = LORA ? (p.lora_groups > 1 && n0 >= p.lora_nb[1] ? 1 : 0) + (p.lora_groups > 2 && n0 >= p.lora_nb[2] ? 1 : 0) : 0;
-    const bool lora_tail = LORA && split == 0 && !(p.lora_dbg & 4);
+    const int lgi = LORA && !ttile ? (p.lora_groups > 1 && n0 >= p.lora_nb[1] ? 1 : 0) + (p.lora_groups > 2 && n0 >= p.lora_nb[2] ? 1 : 0) : 0;
+    const bool lora_tail = LORA && !ttile && split == 0 && !(p.lora_dbg & 4);
 
     // ---- K-block iteration state ----
     int seg = 0, kb = 0;  // kb = block index inside the current segment
@@ -568,6 +589,19 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         }
     };
     enter(seg, kb);
+    if constexpr (LORA && !CONV) {
+        if (ttile) {  // (one segment, no split-K: enter() is not called again)
+            const int rsh = p.lora_r == 32 ? 5 : p.lora_r == 64 ? 6 : 7;
+            wstep = (int64_t)p.lora_r * 128;
+            woff = 0;
+#pragma unroll
+            for (int it = 0; it < WI; ++it) {
+                const int gi = wnrow[it] >> rsh, r = wnrow[it] & (p.lora_r - 1);
+                const char* ab = gi == 0 ? p.lora_a[0] : gi == 1 ? p.lora_a[1] : p.lora_a[2];
+                wbase[it] = ab + (int64_t)r * 128 + wcoff[it];
+            }
+        }
+    }
     if constexpr (KG > 1) {
         if (kg == 1) advance();
     }
@@ -896,6 +930,60 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             }
     } else if (p.ln_stats) {
         __syncthreads();  // rowstat was written before the main loop by other waves; with max_kb >= 1 a barrier has passed, this covers total_kb == 0
+    }
+
+    if constexpr (LORA && !CONV) {
+        if (ttile) {
+            // ---- t-tile epilogue: what a producer publishes (t, or t / rstd = (x A'^T - mean sA) + cA / rstd with LayerNorm folded in), rounded to T,
+            // written through to L2; then the flags of the tile's 32-row blocks, for every group ----
+            constexpr int RUN = 4 * NT;
+            const int nv = wn * WNE + RUN * g;  // this lane's first virtual column: RUN consecutive ranks of ONE group (R >= 32 >= RUN)
+            const int rsh = p.lora_r == 32 ? 5 : p.lora_r == 64 ? 6 : 7;
+            const int gi = nv >> rsh, r0 = nv & (p.lora_r - 1);
+            const int tag = *p.lora_epoch;
+            if (gi < p.lora_groups) {
+                char* tg = p.lora_t + gi * p.lora_gs;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int mrow = wm * WME + 16 * i + c16, m = m0 + mrow;
+                    if (m >= p.M) continue;
+                    float v[RUN];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
+                    if (p.ln_stats) {
+                        const float mean = rowstat[2 * mrow], inv = 1.0f / rowstat[2 * mrow + 1];
+#pragma unroll
+                        for (int c = 0; c < RUN / 4; ++c) {
+                            const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + gi * p.lora_r + r0 + 4 * c);
+                            const f32x4 ca = *reinterpret_cast<const f32x4*>(p.lora_lc + gi * p.lora_r + r0 + 4 * c);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[4 * c + e] = (v[4 * c + e] - mean * sa[e]) + ca[e] * inv;
+                        }
+                    }
+                    char* dst = tg + ((int64_t)m * p.lora_r + r0) * (int)sizeof(T);
+                    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                        for (int c = 0; c < RUN / 2; ++c) st_agent8(dst + 8 * c, __builtin_bit_cast(uint64_t, f32x2{v[2 * c], v[2 * c + 1]}));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < RUN / 4; ++c) {
+                            const bf16x4 b4 = {(bf16_t)v[4 * c], (bf16_t)v[4 * c + 1], (bf16_t)v[4 * c + 2], (bf16_t)v[4 * c + 3]};
+                            st_agent8(dst + 8 * c, __builtin_bit_cast(uint64_t, b4));
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
+            __syncthreads();
+            constexpr int FB = BM / LORA_PM;
+            if (tid < p.lora_groups * FB) {
+                const int nfl = (p.M + LORA_PM - 1) / LORA_PM, fg = tid / FB, fb = m0 / LORA_PM + tid % FB;
+                if (fb < nfl) __hip_atomic_store(p.lora_flags + fg * nfl + fb, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
     }
 
     // ---- epilogue ----
@@ -1298,7 +1386,13 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
     if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
     q.pf_mode = g_pf_mode;
     q.lora_dbg = g_lora_dbg;
-    q.lp_blocks = LORA ? ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8 : 0;  // LoRA producers, ahead of every tile in dispatch order
+    q.lora_tt = 0;
+    if constexpr (LORA && !CONV && KG == 1) {
+        const int mode = (g_lora_dbg & 64) ? 0 : (g_lora_dbg & 128) ? 2 : MI355X_LORA_TT;
+        if (q.lora_groups * q.lora_r <= BN && q.ksplit <= 1 && q.nseg == 1 && (mode == 2 || (mode == 1 && q.lora_groups > 1))) q.lora_tt = 1;
+    }
+    // LoRA producers (or t-tiles), ahead of every output tile in dispatch order
+    q.lp_blocks = !LORA ? 0 : q.lora_tt ? (q.tiles_m + 7) / 8 * 8 : ((q.M + LORA_PM - 1) / LORA_PM * q.lora_groups + 7) / 8 * 8;
     const int grid = q.pf_blocks + q.lp_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
     // the (mean, rstd) rows are only allocated for launches that use them (64 x 64 tiles: 32 KB + 512 B would cost the fifth resident workgroup)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WM * WN * 64 * KG), q.ln_stats ? LDS : LDS - BM * 8, stream, q);

@@ -759,6 +759,17 @@ def gemm_lora_inlaunch_case(M, K, N, dtype, *, ranks=(16, 16), tile=0, geglu=Fal
     return _cmp(out, full + r.float(), dtype)
 
 
+def with_lora_source(bits, fn):
+    """Run a LoRA case with t forced to come from producer workgroups (64) or from t-tiles wherever the tile is wide enough (128): mi355x_set_option
+    lora_dbg -- the two sources of the same hand-off (csrc/gemm_kernel.cuh, GemmP::lora_tt); the library's own choice is what the plain cases run."""
+    lib = native.load()
+    lib.mi355x_set_option(b"lora_dbg", bits)
+    try:
+        return fn()
+    finally:
+        lib.mi355x_set_option(b"lora_dbg", 0)
+
+
 def gemm_qkv_lora_case(M, K, Cc, dtype, tile=0, seed=270):
     """Q | K | V^T from one launch with a different LoRA set per column group."""
     x = _rand(M, K, dtype=dtype, seed=seed)
@@ -1028,6 +1039,23 @@ def all_cases():
             (f"gemm_{tag}_lora1_ff2_2048x1280x5120", lambda dt=dt: gemm_lora_inlaunch_case(2048, 5120, 1280, dt)),
             (f"gemm_{tag}_lora1_repeat_shared_scratch", lambda dt=dt: gemm_lora_repeat_case(1024, 640, 1280, dt)),
             (f"gemm_{tag}_lora1_repeat_shared_scratch_2048x1280x3840", lambda dt=dt: gemm_lora_repeat_case(2048, 1280, 3840, dt, rounds=8)),
+            # the same hand-off with t from t-tiles (forced for one-group launches, whose default is producers) / from producers (forced for Q|K|V^T)
+            (f"gemm_{tag}_lora1_2048x1280x1280_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt))),
+            (f"gemm_{tag}_lora1_rank8_tile4_edges_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(300, 640, 200, dt, ranks=(8,), tile=4))),
+            (f"gemm_{tag}_lora1_tile2_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(520, 320, 384, dt, ranks=(16, 4), tile=2))),
+            (f"gemm_{tag}_lora1_tile3_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(154, 2048, 640, dt, tile=3))),
+            (f"gemm_{tag}_lora1_geglu_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(512, 640, 2560, dt, geglu=True))),
+            (f"gemm_{tag}_lora1_transposed_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(154, 2048, 640, dt, transposed=True))),
+            (f"gemm_{tag}_ln_lora_1024x1280_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_ln_lora_case(1024, 1280, 1280, dt))),
+            (f"gemm_{tag}_ln_lora_tile4_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_ln_lora_case(300, 640, 384, dt, tile=4))),
+            (f"gemm_{tag}_ln_lora_transposed_tile3_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_ln_lora_case(512, 640, 256, dt, tile=3, transposed=True))),
+            (f"gemm_{tag}_lora1_rank64_tile2_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(520, 320, 384, dt, ranks=(64,), tile=2))),
+            (f"gemm_{tag}_lora1_rank128_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, ranks=(128,)))),
+            (f"gemm_{tag}_lora1_ff2_2048x1280x5120_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_inlaunch_case(2048, 5120, 1280, dt))),
+            (f"gemm_{tag}_lora1_repeat_shared_scratch_tt", lambda dt=dt: with_lora_source(128, lambda: gemm_lora_repeat_case(1024, 640, 1280, dt))),
+            (f"gemm_{tag}_qkv_lora_tile1_shared64_prod", lambda dt=dt: with_lora_source(64, lambda: gemm_qkv_lora_case(1024, 1280, 1280, dt, tile=1))),
+            (f"gemm_{tag}_qkv_lora_tile1_oddM_prod", lambda dt=dt: with_lora_source(64, lambda: gemm_qkv_lora_case(301, 640, 384, dt, tile=1))),
+            (f"gemm_{tag}_qkv_lora_2048x1280_tile1", lambda dt=dt: gemm_qkv_lora_case(2048, 1280, 1280, dt, tile=1)),
             (f"conv_{tag}_lora1_2x64x128_32x32", lambda dt=dt: conv_lora_inlaunch_case(2, 64, 128, 32, 32, dt)),
             (f"conv_{tag}_lora1_rank128_stride2", lambda dt=dt: conv_lora_inlaunch_case(2, 128, 256, 32, 32, dt, ranks=(128,), stride=2)),
             (f"conv_{tag}_lora1_shortcut_tile1", lambda dt=dt: conv_lora_inlaunch_case(1, 64, 128, 24, 40, dt, ranks=(8,), shortcut=64, tile=1)),

@@ -1,6 +1,7 @@
 """Where the in-launch LoRA's time goes, per shape class of the SDXL step (hot weights, HIP graph of N launches, bf16):
   plain      the un-adapted launch (what lora_mode="merged" runs)
-  full       producers + tiles, epoch bumped before every launch (what lora_mode="fused" runs)
+  full       producers (or t-tiles) + tiles, epoch bumped before every launch (what lora_mode="fused" runs); full,prod / full,tt: the same with t
+             forced to come from producer workgroups / from t-tiles (mi355x_set_option lora_dbg 64 / 128)
   nowait     the same launches WITHOUT the bump: the flags still hold the epoch, no tile ever waits (producers still run)
   tail       nowait + producers exit at once (mi355x_set_option lora_dbg 1): only the tiles' hand-off + up-projection remain
   as-plain / hooks-only / mma-only   tail minus: everything (the LoRA kernel variant doing an un-adapted launch's work) / the post-loop product /
@@ -92,8 +93,10 @@ def case(M, K, N, *, geglu=False, ln=False, qkv=False, tile=0, ranks=(16, 16), o
     if only is None:
         res["bump+plain"] = graph_time(bump_plain)
         res["full"] = graph_time(full)
-        lib.mi355x_set_option(b"lora_dbg", 32)  # producers at s_setprio 3
-        res["full+prio"] = graph_time(full)
+        lib.mi355x_set_option(b"lora_dbg", 64)  # t from producer workgroups everywhere
+        res["full,prod"] = graph_time(full)
+        lib.mi355x_set_option(b"lora_dbg", 128)  # t from t-tiles wherever the tile is wide enough for groups x rank columns
+        res["full,tt"] = graph_time(full)
         lib.mi355x_set_option(b"lora_dbg", 0)
     sync.bump()
     native.gemm([(x, w)], out, bias=bias, geglu=geglu, tile=tile, lora=lora, lora_sync=(t, flags, sync), **kw)  # flags now hold the epoch
@@ -124,7 +127,9 @@ def main():
     for tile in (0, 1):
         case(2048, 1280, 1280, tile=tile)
     case(2048, 1280, 1280, ln=True)
-    case(2048, 1280, 3840, ln=True, qkv=True)
+    case(2048, 1280, 3840, ln=True, qkv=True)           # (the heuristic's tile: 128 x 64 -- too narrow for three groups' t columns)
+    case(2048, 1280, 3840, ln=True, qkv=True, tile=1)   # what the engine's tuning table launches
+    case(8192, 640, 1920, ln=True, qkv=True, tile=1)
     case(2048, 1280, 10240, geglu=True, ln=True)
     case(2048, 5120, 1280)
     case(8192, 640, 640)
