@@ -179,6 +179,9 @@ template <int RUN> MI_DEV void colsum16(float (&a)[RUN], float (&b)[RUN], int c1
 #define MI355X_LORA_TT 1  // where t comes from t-tiles instead of producers: 0 = nowhere, 1 = launches with more than one column group (Q|K|V^T), 2 = every
                           // launch whose tile is wide enough for groups x rank columns.  (lora_dbg 64 / 128 force 0 / 2 at run time: tools/probe_lora.py)
 #endif
+#ifndef MI355X_LORA_TT_HOOKS
+#define MI355X_LORA_TT_HOOKS 0  // (1: the tiles of a t-tile launch keep the in-loop flag look of the producer design -- A/B builds only)
+#endif
 constexpr int LORA_RC = 32;    // ranks per up-projection step (one K step of the epilogue product)
 constexpr int LORA_PM = 32;    // rows per LoRA producer workgroup: small blocks = many short workgroups with a deep LDS ring (latency-bound loop)
 constexpr int LORA_RMAX = 128;  // largest stacked rank handled inside a launch (control-lora-*-rank128)
@@ -418,10 +421,12 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     // they leave theirs -- but a launch whose tiles fill the chip's resident slots exactly (Q|K|V^T at a CFG pair: 480 tiles of 128 x 128 on 2 x 256
     // slots) no longer starts a third of them one producer-duration late behind 192 producer workgroups.
     bool ttile = false;
+    int tt_tag = 0;
     if constexpr (LORA && !CONV) {
         if (p.lora_tt && bid < p.lp_blocks) {
             if ((p.lora_dbg & 1) || bid >= p.tiles_m) return;  // (probing) / padding up to a multiple of 8
             ttile = true;
+            tt_tag = *p.lora_epoch;  // (requested now: by the epilogue it has long arrived)
         }
     }
     if constexpr (LORA) {
@@ -600,6 +605,16 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                 const char* ab = gi == 0 ? p.lora_a[0] : gi == 1 ? p.lora_a[1] : p.lora_a[2];
                 wbase[it] = ab + (int64_t)r * 128 + wcoff[it];
             }
+            // (Tried: asking for every line of the down rows up front, through the LDS-DMA path into LDS nobody reads -- they are not covered by the weight
+            //  prefetch and come from HBM in a replayed step.  Nothing for these launches: 25.899 vs 25.909 ms, profiles/r04_k_ab_tt.log.)
+            if (p.ln_stats && wid == 0) {
+                // sA / cA of the epilogue: small, cold (HBM in a replayed step) and on the path between this tile's last MFMA and the flags every tile
+                // of the row block is waiting for -- staged now into the up rows' LDS slot (a t-tile stages none), older than every stage load.
+                // (All 64 lanes of wave 0, 16 bytes each: 1 KB per vector, of which the first groups x R floats are real; the rest re-read the last piece.)
+                const int piece = min(lane, p.lora_groups * p.lora_r / 4 - 1);
+                glds16(p.lora_ls + 4 * piece, lora_b0);
+                glds16(p.lora_lc + 4 * piece, lora_b0 + 1024);
+            }
         }
     }
     if constexpr (KG > 1) {
@@ -725,7 +740,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     frag_t tfr[LORA ? MT : 1][L_KS];
     int lora_fl = 0, lora_tg = 1, lora_ok = 0;
     bool lora_mine = false;
-    const int hook_t = (lora_tail && max_kb >= 4 && !(p.lora_dbg & 16)) ? max_kb - 4 : -2;
+    // (t-tile launches: t is published when the tiles leave their loops, an in-loop look at the flags never finds them set -- no hooks, straight to the wait)
+    const int hook_t = (lora_tail && max_kb >= 4 && !(p.lora_dbg & 16) && !(p.lora_tt && MI355X_LORA_TT_HOOKS == 0)) ? max_kb - 4 : -2;
     auto opaque0 = [&]() __attribute__((always_inline)) {
         int z;
         asm volatile("v_mov_b32 %0, 0" : "=v"(z));
@@ -940,7 +956,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             const int nv = wn * WNE + RUN * g;  // this lane's first virtual column: RUN consecutive ranks of ONE group (R >= 32 >= RUN)
             const int rsh = p.lora_r == 32 ? 5 : p.lora_r == 64 ? 6 : 7;
             const int gi = nv >> rsh, r0 = nv & (p.lora_r - 1);
-            const int tag = *p.lora_epoch;
+            const float* lsl = reinterpret_cast<const float*>(lora_b0);  // [groups x R] sA, then at + 256 floats cA (staged by the prologue)
             if (gi < p.lora_groups) {
                 char* tg = p.lora_t + gi * p.lora_gs;
 #pragma unroll
@@ -956,8 +972,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                         const float mean = rowstat[2 * mrow], inv = 1.0f / rowstat[2 * mrow + 1];
 #pragma unroll
                         for (int c = 0; c < RUN / 4; ++c) {
-                            const f32x4 sa = *reinterpret_cast<const f32x4*>(p.lora_ls + gi * p.lora_r + r0 + 4 * c);
-                            const f32x4 ca = *reinterpret_cast<const f32x4*>(p.lora_lc + gi * p.lora_r + r0 + 4 * c);
+                            const f32x4 sa = *reinterpret_cast<const f32x4*>(lsl + gi * p.lora_r + r0 + 4 * c);
+                            const f32x4 ca = *reinterpret_cast<const f32x4*>(lsl + 256 + gi * p.lora_r + r0 + 4 * c);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[4 * c + e] = (v[4 * c + e] - mean * sa[e]) + ca[e] * inv;
                         }
@@ -980,7 +996,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
             constexpr int FB = BM / LORA_PM;
             if (tid < p.lora_groups * FB) {
                 const int nfl = (p.M + LORA_PM - 1) / LORA_PM, fg = tid / FB, fb = m0 / LORA_PM + tid % FB;
-                if (fb < nfl) __hip_atomic_store(p.lora_flags + fg * nfl + fb, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fb < nfl) __hip_atomic_store(p.lora_flags + fg * nfl + fb, tt_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
         }
