@@ -161,7 +161,8 @@ typedef struct {
        convolutions' weights packed like w, same kernel size / stride / padding as segment 0; the up convolutions must be 1x1);
        lora_b: [N][lora_r] row-major, the up-projections already multiplied by their scales (rows follow the same N-packing as w).
        The LoRAs adapt segment 0.  x A^T is computed ONCE per 32 rows, by extra workgroups at the head of the launch's grid (no column
-       tile recomputes it; column groups share them: every group reads segment 0's x), rounded to `dtype` (the reference's intermediate tensor),
+       tile recomputes it; every group reads segment 0's x; which kind of workgroup -- a small producer per 32 rows and group, or one
+       ordinary tile per row tile for all groups -- is the library's choice per launch), rounded to `dtype` (the reference's intermediate tensor),
        handed to the output tiles through
          lora_t     scratch, 128-BYTE aligned, >= groups * GS bytes with GS = M * lora_r * sizeof(dtype) rounded up to a multiple of 128 (group g's
                     rows start at byte g * GS: a cache line never holds rows of two groups or of two 32-row blocks),

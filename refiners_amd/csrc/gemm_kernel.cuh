@@ -36,7 +36,10 @@
 //     staged into LDS.  Producers have the lowest workgroup ids of the launch, so they are dispatched before any tile that waits for
 //     them (a tile that does not find its flags set spins after the loop, bounded by the wall clock, and traps rather than hangs).
 //     Per-column-group A so that a merged Q|K|V launch keeps its three LoRA sets; Conv2dLora = the same with the conv loader (down
-//     conv of the parent's kernel size / stride, 1x1 up conv);
+//     conv of the parent's kernel size / stride, 1x1 up conv).  A launch with SEVERAL column groups whose tile is wide enough (Q|K|V^T
+//     on the 128-column tile) gets t from "t-tiles" instead: one ordinary tile per row tile at the head of the grid, run against the
+//     stacked down rows of all groups as a virtual column tile, whose epilogue publishes t and the flags (GemmP::lora_tt) -- 16
+//     workgroups instead of 192 in front of 480 tiles that fill the chip's 512 resident slots;
 //   * bf16 -> v_mfma_f32_16x16x32_bf16, f32 (parity mode) -> v_mfma_f32_16x16x4_f32; identical LDS image.
 #pragma once
 #include <type_traits>
