@@ -18,11 +18,17 @@ _table: Optional[dict] = None
 enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
 
 
+def table_path() -> Path:
+    """REFINERS_AMD_TUNING_TABLE names another table (a file name beside this module, or a path): A/B runs of a candidate entry (tools/ab_step.py)."""
+    name = os.environ.get("REFINERS_AMD_TUNING_TABLE")
+    return TABLE_PATH if not name else (Path(name) if os.sep in name else TABLE_PATH.parent / name)
+
+
 def table() -> dict:
     global _table
     if _table is None:
         try:
-            _table = {k: tuple(v) for k, v in json.loads(TABLE_PATH.read_text())["choices"].items()}
+            _table = {k: tuple(v) for k, v in json.loads(table_path().read_text())["choices"].items()}
         except (OSError, ValueError, KeyError):
             _table = {}
     return _table
@@ -42,4 +48,4 @@ def lookup(signature: str, stages: int = 0) -> tuple[int, int]:
 
 
 def summary() -> dict:
-    return {"table": TABLE_PATH.name if table() else None, "entries": len(table()), "enabled": enabled}
+    return {"table": table_path().name if table() else None, "entries": len(table()), "enabled": enabled}

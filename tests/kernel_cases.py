@@ -1056,6 +1056,7 @@ def all_cases():
             (f"gemm_{tag}_qkv_lora_tile1_shared64_prod", lambda dt=dt: with_lora_source(64, lambda: gemm_qkv_lora_case(1024, 1280, 1280, dt, tile=1))),
             (f"gemm_{tag}_qkv_lora_tile1_oddM_prod", lambda dt=dt: with_lora_source(64, lambda: gemm_qkv_lora_case(301, 640, 384, dt, tile=1))),
             (f"gemm_{tag}_qkv_lora_2048x1280_tile1", lambda dt=dt: gemm_qkv_lora_case(2048, 1280, 1280, dt, tile=1)),
+            (f"gemm_{tag}_qkv_lora_8192x640_tile1", lambda dt=dt: gemm_qkv_lora_case(8192, 640, 640, dt, tile=1)),  # the 4096-token level's launch: 64 t-tiles
             (f"conv_{tag}_lora1_2x64x128_32x32", lambda dt=dt: conv_lora_inlaunch_case(2, 64, 128, 32, 32, dt)),
             (f"conv_{tag}_lora1_rank128_stride2", lambda dt=dt: conv_lora_inlaunch_case(2, 128, 256, 32, 32, dt, ranks=(128,), stride=2)),
             (f"conv_{tag}_lora1_shortcut_tile1", lambda dt=dt: conv_lora_inlaunch_case(1, 64, 128, 24, 40, dt, ranks=(8,), shortcut=64, tile=1)),
