@@ -281,11 +281,12 @@ EXPORTS = [
 ]
 
 _lib: Optional[C.CDLL] = None
+_lib_path: Optional[str] = None
 
 
 def load(path: Optional[Path] = None) -> C.CDLL:
     """Load the shared library (once). Raises NativeError if it has not been built."""
-    global _lib
+    global _lib, _lib_path
     if _lib is not None:
         return _lib
     p = Path(path) if path else LIB_PATH
@@ -331,8 +332,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     if lib.mi355x_abi_version() != 6:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
-    import os
-
+    _lib_path = str(p)
     attention_pipeline_from_env()
     return lib
 
@@ -363,7 +363,8 @@ def switch_library(path: Optional[Path]) -> C.CDLL:
 
 
 def loaded_library_path() -> Optional[str]:
-    return str(LIB_PATH) if _lib is not None else None
+    """The shared library the process is bound to (the product library unless a tool switched to an experiment build), None before load()."""
+    return _lib_path if _lib is not None else None
 
 
 def check(status: int, what: str) -> None:

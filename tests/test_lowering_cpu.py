@@ -379,3 +379,30 @@ def test_a_residual_block_reads_a_concatenation_that_was_never_written(monkeypat
     assert names0.count("mi355x_concat2") == 1 and low0.stats["concat_materialised"] == 1 and len(names0) == len(names) + 1
     conv2 = [e[1][0]._obj for e in low0.step if e[2] == "mi355x_gemm(conv)"][-1]
     assert conv2.nseg == 2 and int(conv2.seg[1].k) == 192
+
+
+def test_tuning_table_lookup_rules(tmp_path, monkeypatch):
+    """engine/tuning.py: exact signature first; a `...lora` launch without its own entry takes the un-adapted launch's tile if a LoRA kernel exists for it
+    (4-wave tiles, two LDS stages); REFINERS_AMD_TUNING_TABLE selects a candidate table; and the two Q|K|V^T launches of the SDXL step with live LoRAs
+    sit on the 128-column tile, the only one wide enough for the three groups' t columns (csrc/gemm_kernel.cuh, GemmP::lora_tt)."""
+    import json
+
+    from refiners_amd.engine import tuning
+
+    monkeypatch.delenv("REFINERS_AMD_TUNING_TABLE", raising=False)
+    monkeypatch.setattr(tuning, "_table", None)
+    monkeypatch.setattr(tuning, "enabled", True)
+    for sig in ("gemm:bf16:2048x3840x1280:s1:T2560lnlora", "gemm:bf16:8192x1920x640:s1:T1280lnlora"):
+        assert tuning.lookup(sig) == (1, 2), sig
+    assert tuning.lookup("gemm:bf16:1x1x1:s1:") == (0, 0) and tuning.lookup("gemm:bf16:1x1x1:s1:", stages=3) == (0, 3)
+    cand = tmp_path / "cand.json"
+    cand.write_text(json.dumps({"choices": {"gemm:bf16:64x64x64:s1:": [6, 3], "gemm:bf16:128x64x64:s1:": [2, 4], "gemm:bf16:128x64x64:s1:lora": [3, 2]}}))
+    monkeypatch.setenv("REFINERS_AMD_TUNING_TABLE", str(cand))
+    monkeypatch.setattr(tuning, "_table", None)
+    assert tuning.summary()["table"] == "cand.json" and tuning.summary()["entries"] == 3
+    assert tuning.lookup("gemm:bf16:64x64x64:s1:") == (6, 3)
+    assert tuning.lookup("gemm:bf16:64x64x64:s1:lora") == (1, 2)      # the 8-wave tile has no LoRA kernel: 128 x 128, two stages
+    assert tuning.lookup("gemm:bf16:128x64x64:s1:lora") == (3, 2)     # its own entry wins over the un-adapted launch's
+    monkeypatch.setattr(tuning, "enabled", False)
+    assert tuning.lookup("gemm:bf16:64x64x64:s1:") == (0, 0)
+    monkeypatch.setattr(tuning, "_table", None)  # (the next user re-reads the product table)
