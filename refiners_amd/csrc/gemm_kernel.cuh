@@ -112,7 +112,8 @@ struct GemmP {
     int lora_tt;           // 1 = no producers: the lp_blocks workgroups at the head of the grid are t-TILES (one per row tile; see gemm_kernel)
     int64_t lora_gs;       // bytes from one group's t to the next: M * lora_r * sizeof(T) rounded up to 128 (a 128-byte line never holds two groups' rows)
     int lora_dbg;          // probing only (mi355x_set_option "lora_dbg", tools/probe_lora.py; timing, not results): 1 = producers exit at once (valid only
-                           // while the flags still hold the epoch), 4 = tiles skip the LoRA term entirely, 8 = in-loop hand-off but no product, 16 = product but no hand-off
+                           // while the flags still hold the epoch), 4 = tiles skip the LoRA term entirely, 8 = in-loop hand-off but no product, 16 = product but no hand-off,
+                           // 32 = producers at s_setprio 3, 64 = t from producers everywhere, 128 = t from t-tiles wherever the tile is wide enough (results stay right)
     // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
     // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
     const char* pf_ptr[MI355X_MAX_PREFETCH];
