@@ -743,15 +743,21 @@ def weight_spans(a: GemmArgs) -> list[tuple[int, int]]:
     return out
 
 
-def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 19, bytes_per_block: int = 128 << 10, min_blocks: int = 32,
-                         max_blocks: int = 128) -> dict:
+def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 19, bytes_per_block: int = 128 << 10, min_blocks: Optional[int] = None,
+                         max_blocks: Optional[int] = None) -> dict:
     """Post-pass over a recorded program that is replayed again and again (a denoising step, an encoder): every GEMM / conv
     launch gets the weight operands of the NEXT GEMM / conv launch as its `prefetch` spans (the last one wraps around to the
     first).  Weights are read exactly once per replay from HBM (5.1 GB per SDXL step), so without this every kernel starts on
     cold lines and its short K loop cannot hide DRAM latency: in place, launches run 25-40 % slower than the same launch on
     hot weights; with the weights pulled into the Infinity Cache one launch ahead the step is 7-8 % shorter
     (tools/probe_prefetch.py, tools/probe_step.py, profiles/r01_t*).  A burst of 32-128 prefetch workgroups at the head of
-    the grid beats a thin continuous stream: one workgroup sustains only ~20 GB/s of misses."""
+    the grid beats a thin continuous stream: one workgroup sustains only ~20 GB/s of misses.  Prefetch workgroups per launch: 32 ... 128 by the
+    bytes to pull; REFINERS_AMD_PF_BLOCKS="min,max" moves the bounds (an A/B lever: these workgroups sit in front of the launch's own tiles)."""
+    import os
+
+    lo, hi = (os.environ.get("REFINERS_AMD_PF_BLOCKS", "") + ",").split(",")[:2]
+    min_blocks = min_blocks if min_blocks is not None else int(lo or 32)
+    max_blocks = max(min_blocks, max_blocks if max_blocks is not None else int(hi or 128))
     gemms = [e[1][0]._obj for e in ops if e[0] is not None and e[2].startswith("mi355x_gemm")]
     linked = nbytes_total = 0
     for i, a in enumerate(gemms):

@@ -228,6 +228,14 @@ def test_weight_prefetch_links_every_gemm_to_the_next_ones_weights():
     assert (g[3].prefetch[0], g[3].prefetch_bytes[0]) == (0x60000000, (639 * 2048 + 640) * 2)  # column slice: last row to K only
     assert (g[4].prefetch[0], g[4].prefetch_bytes[0]) == (0x10000000, 1280 * 1280 * 2)        # wraps around for the next replay
     assert all(32 <= a.prefetch_blocks <= 128 for a in g)
+    import os
+
+    os.environ["REFINERS_AMD_PF_BLOCKS"] = "16,64"  # the A/B lever on the number of prefetch workgroups
+    try:
+        native.link_weight_prefetch(ops)
+        assert [a.prefetch_blocks for a in g] == [64, 25, 57, 20, 25]  # ceil(bytes / 128 KB) clamped to [16, 64]
+    finally:
+        del os.environ["REFINERS_AMD_PF_BLOCKS"]
     native.link_weight_prefetch(ops, enable=False)
     assert all(not a.prefetch[0] and a.prefetch_blocks == 0 for a in g)
 
