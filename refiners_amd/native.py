@@ -752,10 +752,10 @@ def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 1
     hot weights; with the weights pulled into the Infinity Cache one launch ahead the step is 7-8 % shorter
     (tools/probe_prefetch.py, tools/probe_step.py, profiles/r01_t*).  A burst of 32-128 prefetch workgroups at the head of
     the grid beats a thin continuous stream: one workgroup sustains only ~20 GB/s of misses.  Prefetch workgroups per launch: 32 ... 128 by the
-    bytes to pull; REFINERS_AMD_PF_BLOCKS="min,max" moves the bounds (an A/B lever: these workgroups sit in front of the launch's own tiles)."""
+    bytes to pull; REFINERS_AMD_PF_BLOCKS="min-max" moves the bounds (an A/B lever: these workgroups sit in front of the launch's own tiles)."""
     import os
 
-    lo, hi = (os.environ.get("REFINERS_AMD_PF_BLOCKS", "") + ",").split(",")[:2]
+    lo, hi = (os.environ.get("REFINERS_AMD_PF_BLOCKS", "").replace("-", ",") + ",").split(",")[:2]  # "min,max" or "min-max" (tools/ab_step.py splits its variants on commas)
     min_blocks = min_blocks if min_blocks is not None else int(lo or 32)
     max_blocks = max(min_blocks, max_blocks if max_blocks is not None else int(hi or 128))
     gemms = [e[1][0]._obj for e in ops if e[0] is not None and e[2].startswith("mi355x_gemm")]

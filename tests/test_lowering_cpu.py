@@ -230,7 +230,7 @@ def test_weight_prefetch_links_every_gemm_to_the_next_ones_weights():
     assert all(32 <= a.prefetch_blocks <= 128 for a in g)
     import os
 
-    os.environ["REFINERS_AMD_PF_BLOCKS"] = "16,64"  # the A/B lever on the number of prefetch workgroups
+    os.environ["REFINERS_AMD_PF_BLOCKS"] = "16-64"  # the A/B lever on the number of prefetch workgroups
     try:
         native.link_weight_prefetch(ops)
         assert [a.prefetch_blocks for a in g] == [64, 25, 57, 20, 25]  # ceil(bytes / 128 KB) clamped to [16, 64]
