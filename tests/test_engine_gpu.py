@@ -156,15 +156,13 @@ def test_sd1_float32_matches_reference():
 
 def test_full_size_step_matches_oracle():
     """BASELINE.json config 2 geometry (1024x1024 -> 128x128 latents, CFG pair), float32, against the CPU oracle."""
-    from oracle import unet_oracle as O
-
     unet = SDXLUNet(4, device="meta")
     S.load_mirror_weights(unet, S.weights("sdxl", 0), device="cuda", dtype=torch.float32)
-    inp = S.synth.sdxl_inputs(1, (128, 128), seed=7)
+    _, inp = S.full_size_inputs("bare_step0")
     sd = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0)
     sd.set_inputs(inp["x"].cuda(), clip_text_embedding=inp["text"].cuda(), pooled_text_embedding=inp["pooled"].cuda(), time_ids=inp["time_ids"].cuda())
     x1 = sd.step(0).clone()
-    ref = O.sdxl_cfg_step(S.weights("sdxl", 0), inp["x"], 0, 50, inp["text"], inp["pooled"], inp["time_ids"], condition_scale=5.0)
+    ref = S.full_size_oracle("bare_step0")  # the oracle's step, committed by oracle/make_golden_full_size.py (computed here if the recipe changed)
     l2, mx = S.rel_err(x1, ref)
     print(f"full-size f32 step: l2 {l2:.2e} max {mx:.2e}")
     assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
@@ -611,16 +609,10 @@ def test_merged_weights_keep_the_lora_delta():
 
 @pytest.fixture(scope="module")
 def full_size_lora_ip_oracle():
-    """BASELINE configs[2] at its benchmarked geometry (128x128 latents, CFG pair): one CPU-oracle step, shared by the tests below."""
-    from oracle import unet_oracle as O
-
-    shapes = S.key_shapes("sdxl")
-    specs = {"loras": [S.synth.lora_spec(shapes, "l1", 1.0, seed=5), S.synth.lora_spec(shapes, "l2", 0.8, seed=5)],
-             "ip": S.synth.ip_spec(shapes, 0.6, batch=2, seed=5), "control": []}
-    inp = S.synth.sdxl_inputs(1, (128, 128), seed=8)
-    ref = O.sdxl_cfg_step(S.weights("sdxl", 0), inp["x"], 7, 50, inp["text"], inp["pooled"], inp["time_ids"], condition_scale=5.0,
-                          loras=specs["loras"], ip=specs["ip"])
-    return specs, inp, ref
+    """BASELINE configs[2] at its benchmarked geometry (128x128 latents, CFG pair): one CPU-oracle step, shared by the tests below
+    (committed by oracle/make_golden_full_size.py; computed here if the recipe in tests/support.py changed)."""
+    specs, inp = S.full_size_inputs("lora_ip_step7")
+    return specs, inp, S.full_size_oracle("lora_ip_step7")
 
 
 @pytest.mark.parametrize("mode", ["merged", "fused"])
@@ -673,15 +665,15 @@ def test_full_size_control_batch_of_four():
     (a) against the mirror's unfused Chain forward (the reference's ATen path) on the same GPU for the whole batch,
     (b) batch invariance (reference tests/e2e/test_diffusion.py:1539-1597): image 0 of the batch == the same image alone,
     (c) that single image against the CPU oracle."""
-    from oracle import unet_oracle as O
     from refiners_amd.latent_diffusion.sampling import SDXLDenoiser
 
     n = 4
-    ctl = S.synth.control_spec("canny", 0.9, 2 * n, (128, 128), seed=6)
+    fs_specs, fs_inp = S.full_size_inputs("control_single_step12")
+    ctl = fs_specs["control_batch"]  # control_spec("canny", 0.9, 2 n, (128, 128), seed=6)
     unet = SDXLUNet(4, device="meta")
     S.load_mirror_weights(unet, S.weights("sdxl", 0), device="cuda", dtype=torch.float32)
     S.synth.apply_adapters(unet, refiners_amd.namespace(), device="cuda", dtype=torch.float32, loras=[], ip=None, control=[ctl])
-    inp = {k: v.cuda() for k, v in S.synth.sdxl_inputs(n, (128, 128), seed=9).items()}
+    inp = {k: v.cuda() for k, v in fs_inp.items()}
     sd = CompiledSDXL(unet, num_inference_steps=30, condition_scale=7.5)
     sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], conditions={"canny": ctl["condition"].cuda()})
     x4 = sd.step(12).clone()
@@ -693,8 +685,7 @@ def test_full_size_control_batch_of_four():
     print(f"full-size control x4 f32 vs unfused mirror: l2 {l2:.2e} max {mx:.2e}")
     assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
     pick = torch.tensor([0, n], device="cuda")  # [neg_0 .. neg_3, cond_0 .. cond_3] -> [neg_0, cond_0]
-    one = S.synth.control_spec("canny", 0.9, 2, (128, 128), seed=6)
-    one["condition"] = ctl["condition"][pick.cpu()]
+    one = fs_specs["control"][0]  # the same adapter fed rows 0 and n of the batch's condition picture
     sd1 = CompiledSDXL(unet, num_inference_steps=30, condition_scale=7.5)
     sd1.set_inputs(inp["x"][:1], clip_text_embedding=inp["text"][pick], pooled_text_embedding=inp["pooled"][pick], time_ids=inp["time_ids"][pick],
                    conditions={"canny": one["condition"].cuda()})
@@ -702,9 +693,7 @@ def test_full_size_control_batch_of_four():
     l2, mx = S.rel_err(x1, x4[:1])
     print(f"full-size control batch invariance: l2 {l2:.2e} max {mx:.2e}")
     assert mx < 5e-3, (l2, mx)
-    cpu = {k: v.cpu() for k, v in inp.items()}
-    refo = O.sdxl_cfg_step(S.weights("sdxl", 0), cpu["x"][:1], 12, 30, cpu["text"][pick.cpu()], cpu["pooled"][pick.cpu()], cpu["time_ids"][pick.cpu()], condition_scale=7.5,
-                           control=[one])
+    refo = S.full_size_oracle("control_single_step12")
     l2, mx = S.rel_err(x1, refo)
     print(f"full-size control single image vs oracle: l2 {l2:.2e} max {mx:.2e}")
     assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
