@@ -13,8 +13,8 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libmi355x_refiners.so"
-SOURCES = ["gemm.hip", "gemm_conv.hip", "attention.hip", "attention_general.hip", "norm.hip", "elementwise.hip"]
-HEADERS = ["common.cuh", "gemm_kernel.cuh", "../../include/mi355x_refiners.h"]
+SOURCES = ["gemm.hip", "gemm_conv.hip", "gemm8.hip", "attention.hip", "attention_general.hip", "norm.hip", "elementwise.hip"]
+HEADERS = ["common.cuh", "gemm_params.cuh", "gemm_epilogue.cuh", "gemm_kernel.cuh", "gemm8_kernel.cuh", "../../include/mi355x_refiners.h"]
 ARCH = "gfx950"
 
 
@@ -55,7 +55,10 @@ def build_native(force: bool = False, verbose: bool = False, defines: list[str] 
         # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified), which removes the
         # v_accvgpr_read/write traffic between the softmax / epilogue VALU code and the matrix cores (attention inner
         # loop: 1062 -> 876 instructions) and lowers the total register count of every kernel.
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", *[f"-D{d}" for d in (defines or [])],
+        # -pragma-unroll-threshold (gemm8.hip only): the shared tile epilogue's row loop must unroll fully over the 8 x 4 accumulator blocks of the
+        # 256 x 256 tile -- a partly unrolled loop indexes the accumulators at run time, i.e. puts all 128 of them into scratch memory
+        extra = ["-mllvm", "-pragma-unroll-threshold=100000"] if src == "gemm8.hip" else []
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", *extra, *[f"-D{d}" for d in (defines or [])],
                "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

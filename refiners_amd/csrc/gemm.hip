@@ -2,6 +2,7 @@
 // (The implicit-GEMM convolution instantiations live in gemm_conv.hip so that the two halves compile in parallel.)
 #include <climits>
 
+#include "gemm8_kernel.cuh"
 #include "gemm_kernel.cuh"
 
 namespace mi355x {
@@ -87,6 +88,12 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         d.w = static_cast<const char*>(g.w);
         d.ldxb = g.ldx * es;
         d.ldwb = g.ldw * es;
+        {  // operand extents from x / w (the 8-phase loop's buffer descriptors)
+            const int64_t taps = a->conv ? (int64_t)g.ksize * g.ksize : 1, kbytes = (int64_t)g.k * es, nkb_all = taps * (g.k / bke);
+            const int64_t xrows = a->conv ? (int64_t)a->B * g.H * g.W : (int64_t)a->M;
+            d.xbytes = xkb ? nkb_all * a->M * 128 : (xrows - 1) * d.ldxb + kbytes;
+            d.wbytes = wkb ? nkb_all * a->N * 128 : ((int64_t)a->N - 1) * d.ldwb + taps * kbytes;
+        }
         if (a->conv) {
             if ((g.ksize != 1 && g.ksize != 3) || (g.stride != 1 && g.stride != 2) || (g.ups != 1 && g.ups != 2)) return MI355X_ESHAPE;
             if (g.H <= 0 || g.W <= 0) return MI355X_ESHAPE;
@@ -205,6 +212,10 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((g_tile ? g_tile : a->tile) == 7 && gemm8_ok(p)) {  // the 256 x 256 tile on the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
+        if (a->conv) return a->dtype == MI355X_F32 ? launch_conv8_f32(p, st) : launch_conv8_bf16(p, st);
+        return a->dtype == MI355X_F32 ? launch_gemm8_f32(p, st) : launch_gemm8_bf16(p, st);
+    }
     if (a->conv) return a->dtype == MI355X_F32 ? launch_conv_f32(p, st) : launch_conv_bf16(p, st);
     if (a->dtype == MI355X_F32) return launch_tile<float, false>(p, st);
     return launch_tile<bf16_t, false>(p, st);

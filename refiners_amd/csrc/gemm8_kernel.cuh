@@ -1,0 +1,442 @@
+// gemm8_kernel.cuh: the second main loop of mi355x_gemm -- 256 x 256 output tile, 8 waves, EIGHT phases per two K tiles (gfx950).
+//
+//   out[M,N] = epi( sum_s X_s[M,K_s] . W_s[N,K_s]^T )        same contract, same LDS image, same epilogue as gemm_kernel.cuh
+//
+// Why a second loop: the 4-wave / two-phase loop of gemm_kernel.cuh has one barrier per K block with every wave of the workgroup in the
+// same phase -- its waves sit on s_waitcnt / s_barrier half of their cycles (profiles/r04_g_pmc_sq.json) and no tile shape changed that
+// (DESIGN.md section 4).  This loop is the CDNA programming guide's 256^2 template (cdna_hip_programming.md "The 256^2 8-phase template"):
+//   * 8 waves = 2 (M) x 4 (N), a wave owns 128 x 64 outputs = acc[8][4] MMA tiles (128 registers), split into four 64 x 32 QUADRANTS;
+//   * a phase = { LDS reads of the fragments one quadrant needs | LDS-DMA issue of ONE half tile of a later K tile } barrier { 16 MFMA of that
+//     quadrant over the whole 128-byte K tile } barrier;  4 phases per K tile, the loop body covers two K tiles (LDS buffers 0 / 1);
+//   * the two 4-wave halves (wm = 0 / 1) run ONE BARRIER APART: while one half issues its 16 MFMAs the other half reads LDS and issues
+//     loads, so each SIMD (one wave of each half) always has a wave in the matrix pipe; s_setprio 1 around the MFMA cluster;
+//   * vmcnt is counted, never 0 in steady state: waits only in phases 4 and 8 (`vmcnt(6)`: the three youngest half tiles stay in flight),
+//     raw s_barrier (a __syncthreads() would drain the LDS-DMA queue);
+//   * fragment registers: X quadrant rows (8 x 16 B) are re-read per half, both W halves (2 x 4 x 16 B) stay in registers for the K tile:
+//     24 ds_read_b128 per wave and K tile for 64 MFMA (the 128 x 128 / 4-wave tile: 32 for 64).
+// Half tiles (what one phase stages = 128 rows x 128 B = 2 loads per thread):
+//   X half h = rows { 128 wm + 64 h + r }: the rows quadrant row h of BOTH wave rows;   W half h = LDS rows { 64 wn + 32 h + r } likewise.
+// Per iteration (K tiles t -> buffer 0, t + 1 -> buffer 1), phase: reads | stage:
+//   1: W0 X0 (buf 0) | X1 of t+1 -> buf 1      5: W0 X0 (buf 1) | X1 of t+2 -> buf 0
+//   2: W1            | W0 of t+2 -> buf 0      6: W1            | W0 of t+3 -> buf 1
+//   3: X1            | X0 of t+2 -> buf 0      7: X1            | X0 of t+3 -> buf 1
+//   4: --            | W1 of t+2 -> buf 0 ; vmcnt(6): tile t+1 complete     8: -- | W1 of t+3 -> buf 1 ; vmcnt(6): tile t+2 complete
+// Hazards (guide, same section): a half tile is READ one phase after the wait that retires it or later (the other half of the workgroup
+// passes that wait one barrier later); a buffer is RE-STAGED two phases after its last ds_read, or one phase after when an lgkmcnt in front of
+// the reading phase's first barrier retired those reads (phase 1 / 5: `lgkmcnt(8)` retires the four W0 reads, which are issued first).
+// Loader: buffer_load_dwordx4 ... lds (LDS-DMA through a buffer descriptor): per-lane 32-bit offset that is constant over the K loop, the
+// running K offset in the instruction's SCALAR offset, the descriptor per segment -- no vector ALU work per load -- and out-of-range lanes
+// (conv padding, rows beyond M / N) are given offset 0x80000000, for which the hardware writes zeros to LDS (no zero page, no select).
+// Not in this loop (the host keeps such launches on gemm_kernel.cuh): in-launch LoRA, transposed column groups, operands of 2 GB and more.
+#pragma once
+#include "gemm_epilogue.cuh"
+
+namespace mi355x {
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+MI_DEV rsrc_t make_rsrc(const char* base, int64_t bytes) {
+    // wave-uniform by construction; readfirstlane makes that provable (guide T20: otherwise every load sits in a waterfall loop)
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const int n = __builtin_amdgcn_readfirstlane((int)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, n, 0x00020000);
+}
+// 16 bytes per lane, global -> LDS: lane i lands at lds_wave_base + 16 i; source = descriptor base + voff (per lane) + soff (scalar)
+MI_DEV void blds16(rsrc_t rs, char* lds_wave_base, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// Workgroup -> tile (the XCD-aware rasterisation planned by plan_grid)
+MI_DEV void tile_coords(const GemmP& p, int bx, int& tm, int& tn) {
+    if (p.pn > 0) {  // rectangular regions (exact split of the tile grid, grid0 = 8 * hm * hn)
+        const int xcd = bx & 7, idx = bx >> 3;
+        const int rm = xcd / p.pn, rn = xcd - rm * p.pn;
+        const int lm = idx / p.hn, ln = idx - lm * p.hn;
+        tm = rm * p.hm + lm;
+        tn = rn * p.hn + ln;
+    } else {  // contiguous chunk of the row-major (pn == 0) or column-major (pn == -1) tile order per XCD
+        const int id = xcd_remap(bx, p.grid0);
+        if (p.pn == 0) {
+            tm = id / p.tiles_n;
+            tn = id - tm * p.tiles_n;
+        } else {
+            tn = id / p.tiles_m;
+            tm = id - tn * p.tiles_m;
+        }
+    }
+}
+
+// Prefetch role (GemmP::pf_ptr): the first pf_blocks workgroups touch every 64 bytes of the next launch's weights
+template <int NTHR_ALL> MI_DEV void prefetch_role(const GemmP& p, int tid_all) {
+    int acc = 0;
+    const int64_t stride = (int64_t)p.pf_blocks * NTHR_ALL * 64;
+    constexpr int U = 8;
+#pragma unroll
+    for (int sp = 0; sp < MI355X_MAX_PREFETCH; ++sp) {
+        const char* base = p.pf_ptr[sp];
+        const int64_t bytes = base ? p.pf_bytes[sp] : 0;
+        for (int64_t off = ((int64_t)blockIdx.x * NTHR_ALL + tid_all) * 64; off < bytes; off += stride * U) {
+            int v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t o = off + u * stride;
+                const int* src = reinterpret_cast<const int*>(base + (o < bytes ? o : off));
+                v[u] = p.pf_mode == 2 ? __builtin_nontemporal_load(src) : *src;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= v[u];
+        }
+    }
+    if (acc == 0x5a5a1234 && p.pf_bytes[0] < 0) *reinterpret_cast<int*>(p.out) = acc;  // never taken: keeps the loads alive
+}
+
+#ifndef MI355X_G8_PRIO
+#define MI355X_G8_PRIO 1  // s_setprio 1 around every MFMA cluster (guide T5: +21..39 % on this schedule)
+#endif
+
+template <typename T, bool CONV>
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
+    constexpr int BM = 256, BN = 256, NTHR = 512, MT = 8, NT = 4;
+    constexpr int XB = BM * 128, BUFB = (BM + BN) * 128;  // bytes: X tile, one LDS buffer (X tile + W tile)
+    constexpr uint32_t OOB = 0x80000000u;                  // per-lane offset beyond every descriptor's num_records: the load writes zeros
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rowstat = reinterpret_cast<float*>(smem + 2 * BUFB);  // [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    const int g = lane >> 4, c16 = lane & 15;
+    const int wm = wid >> 2, wn = wid & 3;
+    if ((int)blockIdx.x < p.pf_blocks) {
+        prefetch_role<NTHR>(p, tid);
+        return;
+    }
+    const int bid = (int)blockIdx.x - p.pf_blocks;
+    const int split = p.ksplit > 1 ? bid / p.grid0 : 0;
+    int tm, tn;
+    tile_coords(p, bid - split * p.grid0, tm, tn);
+    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- loader geometry.  Half tile (h), load (s): 128 rows x 8 chunks = 1024 pieces of 16 B = 2 loads x 512 threads; piece s * 512 + tid is
+    // (local row lr = s * 64 + 8 wid + (lane >> 3), physical chunk lane & 7).  X: LDS row = 128 s + 64 h + (lr & 63);  W: LDS row = 64 (lr >> 5)
+    // + 32 h + (lr & 31).  A wave's 64 pieces are 8 consecutive LDS rows = 1 KB, lane-linear.  The bank swizzle of row R is (R >> 1) & 7, which
+    // for every one of these rows equals 4 (wid & 1) + (lane >> 4): ONE source-chunk offset per thread.
+    const int lr8 = lane >> 3;
+    const uint32_t coff = (uint32_t)(((lane & 7) ^ (4 * (wid & 1) + (lane >> 4))) << 4);
+    int xrow[2][2];  // global row m (or -1)
+    int wrow[2][2];  // global weight row n (or -1)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int m = m0 + 128 * s + 64 * h + 8 * wid + lr8;
+            xrow[h][s] = m < p.M ? m : -1;
+            // LDS row R of the W tile holds output column n0 + (R - rl) + 16 a + 4 j + b, rl = R % 64 = 16 j + 4 a + b (gemm_kernel.cuh header: every
+            // lane then owns 16 consecutive output columns)
+            const int R = 64 * (2 * s + (wid >> 2)) + 32 * h + 8 * (wid & 3) + lr8;
+            const int rl = R & 63, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
+            const int n = n0 + (R - rl) + 16 * a + 4 * j + b;
+            wrow[h][s] = n < p.N ? n : -1;
+        }
+    int xb[2][2], xyx[2][2];  // conv: image index, (oy | ox << 16) of the output pixel
+    if constexpr (CONV) {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int m = xrow[h][s] < 0 ? 0 : xrow[h][s];
+                const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW;
+                xb[h][s] = b;
+                xyx[h][s] = oy | ((rem - oy * p.OW) << 16);
+            }
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- this workgroup's K range ----
+    int seg0 = 0, kb0 = 0, nk = 0;
+    for (int s = 0; s < p.nseg; ++s) nk += p.seg[s].nkb;
+    if (p.ksplit > 1) {
+        const int first = split * p.kb_per_split;
+        nk = min(p.kb_per_split, nk - first);
+        kb0 = first;
+        while (seg0 < p.nseg - 1 && kb0 >= p.seg[seg0].nkb) {
+            kb0 -= p.seg[seg0].nkb;
+            ++seg0;
+        }
+    }
+
+    // ---- two independent cursors (the X halves of a K tile are staged in other phases than its W halves) ----
+    uint32_t xvo[2][2], wvo[2][2];  // per-lane byte offsets into the current segment's x / w
+    rsrc_t xrs, wrs;
+    int x_seg = seg0, x_kb = kb0, x_nkb = 0, x_cpb = 1, x_cb = 0, x_tap = 0;
+    int w_seg = seg0, w_kb = kb0, w_nkb = 0;
+    uint32_t x_so = 0, x_step = 128, w_so = 0, w_step = 128;
+    int c_ks = 1, c_pad = 0, c_st = 1, c_up = 0, c_H = 1, c_W = 1;  // conv: the current segment's geometry, held in scalars (set_tap runs inside the K loop)
+    uint32_t c_ld = 0;
+    auto set_tap = [&]() __attribute__((always_inline)) {
+        int dy = x_tap / c_ks, dx = x_tap - dy * c_ks;
+        dy -= c_pad;
+        dx -= c_pad;
+        const int HH = c_H << c_up, WW = c_W << c_up;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int iy = (xyx[h][s] & 0xffff) * c_st + dy, ix = (xyx[h][s] >> 16) * c_st + dx;
+                const bool ok = xrow[h][s] >= 0 && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
+                const int pix = (xb[h][s] * c_H + (iy >> c_up)) * c_W + (ix >> c_up);
+                xvo[h][s] = ok ? (uint32_t)pix * c_ld + coff : OOB;
+            }
+    };
+    auto enter_x = [&](int s, int kb) __attribute__((always_inline)) {
+        const SegP& sp = p.seg[s];
+        x_nkb = sp.nkb;
+        xrs = make_rsrc(sp.x, sp.xbytes);
+        if constexpr (CONV) {
+            x_cpb = sp.cpb;
+            x_tap = kb / sp.cpb;
+            x_cb = kb - x_tap * sp.cpb;
+            x_so = (uint32_t)x_cb * 128u;
+            c_ks = sp.ksize, c_pad = sp.pad, c_st = sp.stride, c_up = sp.ups_shift, c_H = sp.H, c_W = sp.W, c_ld = (uint32_t)sp.ldxb;
+            set_tap();
+        } else {
+            x_step = sp.xkb ? (uint32_t)p.M * 128u : 128u;
+            x_so = (uint32_t)kb * x_step;
+            const uint32_t ld = sp.xkb ? 128u : (uint32_t)sp.ldxb;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) xvo[h][s2] = xrow[h][s2] >= 0 ? (uint32_t)xrow[h][s2] * ld + coff : OOB;
+        }
+    };
+    auto enter_w = [&](int s, int kb) __attribute__((always_inline)) {
+        const SegP& sp = p.seg[s];
+        w_nkb = sp.nkb;
+        wrs = make_rsrc(sp.w, sp.wbytes);
+        w_step = sp.wkb ? (uint32_t)p.N * 128u : 128u;
+        w_so = (uint32_t)kb * w_step;
+        const uint32_t ld = sp.wkb ? 128u : (uint32_t)sp.ldwb;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) wvo[h][s2] = wrow[h][s2] >= 0 ? (uint32_t)wrow[h][s2] * ld + coff : OOB;
+    };
+    auto adv_x = [&]() __attribute__((always_inline)) {  // one K tile forward (called behind the stage of X half 1)
+        ++x_kb;
+        if constexpr (CONV) {
+            x_so += 128u;
+            if (++x_cb == x_cpb) {
+                x_cb = 0;
+                x_so = 0;
+                ++x_tap;
+                if (x_kb < x_nkb) set_tap();
+            }
+        } else {
+            x_so += x_step;
+        }
+        if (x_kb == x_nkb) {
+            x_kb = 0;
+            if (++x_seg < p.nseg) enter_x(x_seg, 0);
+        }
+    };
+    auto adv_w = [&]() __attribute__((always_inline)) {
+        ++w_kb;
+        w_so += w_step;
+        if (w_kb == w_nkb) {
+            w_kb = 0;
+            if (++w_seg < p.nseg) enter_w(w_seg, 0);
+        }
+    };
+    auto stage_x = [&](int h, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) blds16(xrs, smem + buf * BUFB + (128 * s + 64 * h + 8 * wid) * 128, xvo[h][s], x_so);
+    };
+    auto stage_w = [&](int h, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) blds16(wrs, smem + buf * BUFB + XB + (64 * (2 * s + (wid >> 2)) + 32 * h + 8 * (wid & 3)) * 128, wvo[h][s], w_so);
+    };
+
+    // ---- fragments ----
+    // row 16 q + c16 of a tile, logical chunk 4 kk + g: byte offset 128 (16 q) + fo[kk]
+    int fo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fo[kk] = c16 * 128 + (((4 * kk + g) ^ ((c16 >> 1) & 7)) << 4);
+    frag_t xf[4][2];     // X quadrant rows: [16-row block][K half]
+    frag_t wf[2][2][2];  // W halves: [h][16-row block][K half]
+    auto read_x = [&](int h, int buf) __attribute__((always_inline)) {
+        const char* xs = smem + buf * BUFB + (128 * wm + 64 * h) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xf[i][kk] = lds_read_frag(xs, i * 2048 + fo[kk]);
+    };
+    auto read_w = [&](int h, int buf) __attribute__((always_inline)) {
+        const char* ws = smem + buf * BUFB + XB + (64 * wn + 32 * h) * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) wf[h][j][kk] = lds_read_frag(ws, j * 2048 + fo[kk]);
+    };
+    auto mma_q = [&](auto hxc, auto hwc) __attribute__((always_inline)) {  // quadrant (hx, hw): 16 MMA steps
+        constexpr int hx = decltype(hxc)::value, hw = decltype(hwc)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma_step<T>(acc[4 * hx + i][2 * hw + j], wf[hw][j][kk], xf[i][kk]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+    auto bar = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_barrier(); };
+    auto lgkm0 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto lgkm8 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); };
+    // the compute half of a phase: barrier | the fragments have arrived | 16 MFMA at raised priority | barrier
+    auto compute = [&](auto hxc, auto hwc, bool reads) __attribute__((always_inline)) {
+        fence();
+        bar();
+        if (reads) lgkm0();
+        fence();
+        if constexpr (MI355X_G8_PRIO != 0) __builtin_amdgcn_s_setprio(1);
+        mma_q(hxc, hwc);
+        if constexpr (MI355X_G8_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+        fence();
+        bar();
+        fence();
+    };
+
+    // ---- prologue: K tile 0 completely, three half tiles of K tile 1 ----
+    enter_x(x_seg, x_kb);
+    enter_w(w_seg, w_kb);
+    stage_w(0, 0);
+    stage_x(0, 0);
+    stage_w(1, 0);
+    adv_w();
+    stage_x(1, 0);
+    adv_x();
+    if (nk > 1) {
+        stage_w(0, 1);
+        stage_x(0, 1);
+        stage_w(1, 1);
+        adv_w();
+    }
+    if (p.ln_stats) ln_rowstat<BM, NTHR>(p, m0, tid, rowstat);
+    if (nk > 1) wait_vm<6>();
+    else wait_vm0();
+    fence();
+    bar();
+    if (wm == 1) bar();  // the second half of the workgroup runs one barrier behind the first from here on
+    fence();
+
+    // ---- main loop: two K tiles per trip.  GUARD = false: tiles t .. t + 3 exist (no conditions anywhere); true: the last one or two trips ----
+    auto trip = [&](auto guardc, int t) __attribute__((always_inline)) {
+        constexpr bool G = decltype(guardc)::value;
+        const bool e1 = !G || t + 1 < nk, e2 = !G || t + 2 < nk, e3 = !G || t + 3 < nk;
+        // phase 1
+        read_w(0, 0);
+        fence();  // (the four W reads first: lgkmcnt(8) below counts on it)
+        read_x(0, 0);
+        if (e1) stage_x(1, 1);
+        lgkm8();
+        if (e1) adv_x();  // (behind the counted wait: a segment change issues scalar loads, which share lgkmcnt with the LDS reads)
+        compute(I0{}, I0{}, true);
+        // phase 2
+        read_w(1, 0);
+        if (e2) stage_w(0, 0);
+        compute(I0{}, I1{}, true);
+        // phase 3
+        read_x(1, 0);
+        if (e2) stage_x(0, 0);
+        compute(I1{}, I1{}, true);
+        // phase 4
+        if (e2) {
+            stage_w(1, 0);
+            adv_w();
+            wait_vm<6>();
+        } else {
+            wait_vm0();
+        }
+        compute(I1{}, I0{}, false);
+        if (G && !e1) return;
+        // phase 5
+        read_w(0, 1);
+        fence();
+        read_x(0, 1);
+        if (e2) stage_x(1, 0);
+        lgkm8();
+        if (e2) adv_x();
+        compute(I0{}, I0{}, true);
+        // phase 6
+        read_w(1, 1);
+        if (e3) stage_w(0, 1);
+        compute(I0{}, I1{}, true);
+        // phase 7
+        read_x(1, 1);
+        if (e3) stage_x(0, 1);
+        compute(I1{}, I1{}, true);
+        // phase 8
+        if (e3) {
+            stage_w(1, 1);
+            adv_w();
+            wait_vm<6>();
+        } else {
+            wait_vm0();
+        }
+        compute(I1{}, I0{}, false);
+    };
+    int t = 0;
+    for (; t + 3 < nk; t += 2) trip(std::false_type{}, t);
+    for (; t < nk; t += 2) trip(std::true_type{}, t);
+    if (wm == 0) bar();  // (balances the extra barrier of the second half)
+
+    tile_epilogue<T, MT, NT, BM, CONV>(p, acc, rowstat, m0, n0, wm, wn, lane, false, split);
+}
+
+template <typename T, bool CONV>
+int launch_gemm8(const GemmP& p, hipStream_t stream) {
+    constexpr int LDS = 2 * (256 + 256) * 128 + 256 * 8;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kfn = gemm8_kernel<T, CONV>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set[dev] = true;
+    }
+    GemmP q = p;
+    plan_grid(q, 256, 256, CONV, 2);
+    q.lora_dbg = 0;
+    q.lora_tt = 0;
+    q.lp_blocks = 0;
+    const int grid = q.pf_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, stream, q);
+    if (q.ksplit > 1) {
+        const int rb = ((q.M + 31) / 32) * ((q.N + 63) / 64);
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb), dim3(256), 0, stream, q);
+    }
+    return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
+}
+
+// Can this launch run on the 8-phase loop?  (No in-launch LoRA, no transposed column group; every operand below 2 GB: 32-bit buffer offsets
+// with 0x80000000 as the out-of-range marker.)
+inline bool gemm8_ok(const GemmP& p) {
+    if (p.lora_b || p.out_t) return false;
+    for (int s = 0; s < p.nseg; ++s)
+        if (p.seg[s].xbytes <= 0 || p.seg[s].wbytes <= 0 || p.seg[s].xbytes >= (1ll << 31) || p.seg[s].wbytes >= (1ll << 31)) return false;
+    return true;
+}
+
+int launch_gemm8_f32(const GemmP& p, hipStream_t stream);
+int launch_gemm8_bf16(const GemmP& p, hipStream_t stream);
+int launch_conv8_f32(const GemmP& p, hipStream_t stream);
+int launch_conv8_bf16(const GemmP& p, hipStream_t stream);
+
+}  // namespace mi355x

@@ -42,136 +42,9 @@
 //     workgroups instead of 192 in front of 480 tiles that fill the chip's 512 resident slots;
 //   * bf16 -> v_mfma_f32_16x16x32_bf16, f32 (parity mode) -> v_mfma_f32_16x16x4_f32; identical LDS image.
 #pragma once
-#include <type_traits>
-
-#include "../../include/mi355x_refiners.h"
-#include "common.cuh"
+#include "gemm_epilogue.cuh"
 
 namespace mi355x {
-
-struct SegP {
-    const char* x;
-    const char* w;
-    int64_t ldxb;  // bytes
-    int64_t ldwb;  // bytes
-    int nkb;       // number of 128-byte K blocks in this segment
-    int cpb;       // conv: K blocks per tap (= channels*sizeof(T)/128)
-    int ksize, stride, ups_shift, H, W;
-    int wkb, xkb;  // operand stored K-blocked: [K block][row][128 B]
-    int pad;  // zero rows / columns before the image (ksize / 2, or 0 for the bottom/right-only padding of Downsample(padding=0))
-};
-
-struct GemmP {
-    int M, N, nseg;
-    int OH, OW;
-    SegP seg[MI355X_MAX_SEG];
-    char* out;
-    int64_t ldo;  // elements
-    const char* bias;
-    const char* rowbias;
-    int64_t ld_rowbias;  // elements
-    int rows_per_group;
-    int geglu;
-    int gelu;  // activation on every output column (after bias / row bias, before the residual): 1 = erf-GELU, 2 = x * sigmoid(1.702 x)
-    const char* res;
-    int64_t ldres;  // elements
-    const char* zeros;
-    int tiles_m, tiles_n;
-    int ksplit, kb_per_split, grid0;  // split-K: ksplit workgroups per tile, each accumulating kb_per_split K blocks
-    float* partial;                   // [ksplit][M][N] float32 partial sums (split-K only)
-    int tile_hint;                    // 0 = heuristic, 1..6 = caller's choice
-    int stage_hint;                   // 0 = heuristic, 2..4 = caller's choice
-    int out_kb;                       // GEGLU output stored K-blocked ([column block][M rows][128 B]) for the GEMM that consumes it as x
-    // transposed column group: columns n >= nt_begin are stored as out_t[(n - nt_begin) * ldt + m]
-    int nt_begin;
-    char* out_t;
-    int64_t ldt;  // elements
-    // LayerNorm folded into this launch (consumer side) / row statistics written by this launch (producer side)
-    const float* ln_stats;  // [ln_parts][M][2] (mean, M2) per 32-column chunk of the normalised tensor, or NULL
-    int ln_parts;
-    float ln_eps;
-    const float* ln_s;  // [N]: sum_k W'[n][k]
-    const float* ln_c;  // [N]: sum_k beta[k] W[n][k] (+ bias[n])
-    float* stats_out;   // [N / 32][M][2], or NULL
-    float* colstats;    // GroupNorm statistics of the output (producer side): [ceil(M / 32)][N][2] = per (32-row block, column) (sum, sum of squares)
-                        // of the values AS STORED, rows beyond M excluded; or NULL
-    int out_f32;        // store `out` as float32 (scores for mi355x_softmax_rows)
-    // LoRA inside the launch: per column group g (columns >= lora_nb[g]) the K-blocked stacked down rows, [K blocks][lora_r][128 B];
-    // lora_b: [N][lora_r] pre-scaled up-projections (row n = output column n), row-major
-    const char* lora_a[3];
-    int lora_nb[3];
-    int lora_groups;
-    int lora_r;            // stacked rank: 32, 64 or 128
-    const char* lora_b;
-    const float* lora_ls;  // LayerNorm folded into this launch AND LoRA: [groups][lora_r] sum_k A'[r][k] and
-    const float* lora_lc;  //                                            [groups][lora_r] sum_k beta[k] A[r][k]
-    char* lora_t;          // [groups][M][lora_r] of T: the producers' t = x A^T (already divided by rstd when LayerNorm is folded in)
-    int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
-    const int* lora_epoch;
-    int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
-    int lora_tt;           // 1 = no producers: the lp_blocks workgroups at the head of the grid are t-TILES (one per row tile; see gemm_kernel)
-    int64_t lora_gs;       // bytes from one group's t to the next: M * lora_r * sizeof(T) rounded up to 128 (a 128-byte line never holds two groups' rows)
-    int lora_dbg;          // probing only (mi355x_set_option "lora_dbg", tools/probe_lora.py; timing, not results): 1 = producers exit at once (valid only
-                           // while the flags still hold the epoch), 4 = tiles skip the LoRA term entirely, 8 = in-loop hand-off but no product, 16 = product but no hand-off,
-                           // 32 = producers at s_setprio 3, 64 = t from producers everywhere, 128 = t from t-tiles wherever the tile is wide enough (results stay right)
-    // weight prefetch for the NEXT launch: the first pf_blocks workgroups of the grid do no tile work, they touch every 64 bytes of
-    // [pf_ptr, pf_ptr + pf_bytes) so that those lines sit in the Infinity Cache when the next kernel asks for them
-    const char* pf_ptr[MI355X_MAX_PREFETCH];
-    int64_t pf_bytes[MI355X_MAX_PREFETCH];
-    int pf_blocks, pf_mode;  // pf_mode: 1 = plain loads, 2 = non-temporal loads (L2 evict-first)
-    int pn, hm, hn;          // XCD rasterisation: the 8 XCDs own a pm x pn grid of hm x hn-tile regions
-    int vec_ok;
-};
-
-// Chan's pairwise update of (count, mean, M2); exact for empty operands.
-MI_DEV void stat_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
-    const float nt = n + nb;
-    if (nt > 0.f) {
-        const float d = mb - mean, f = nb / nt;
-        mean += d * f;
-        m2 += m2b + d * d * n * f;
-        n = nt;
-    }
-}
-
-// Column sums over the 16 lanes of a lane group (lane c16 = one row): a[e], b[e] hold this lane's contribution to column e of RUN; on return
-// lane c16 holds the 16-lane totals of column `c16 % RUN` in a[0], b[0].  Recursive halving: each exchange adds the partner's half and keeps
-// half of the columns (RUN = 8: one full exchange first, the two 8-lane halves then end with the same totals), 15 / 14 exchanges per
-// quantity instead of 64 for an all-reduce, a fixed tree (deterministic).  The exchanges are DPP moves inside the 16-lane row (no LDS round
-// trip: __shfl_xor compiles to ds_bpermute): partner = row_mirror (15 - c), row_half_mirror (c ^ 7), quad_perm (c ^ 2), (c ^ 1) -- every
-// partner differs from the lane in exactly the bit that decides which half it keeps, and the four steps together reach all 16 lanes.
-template <int CTRL> MI_DEV float dpp_f32(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-template <int RUN> MI_DEV void colsum16(float (&a)[RUN], float (&b)[RUN], int c16) {
-    static_assert(RUN == 8 || RUN == 16, "8 or 16 columns per lane");
-    constexpr int ROW_MIRROR = 0x140, ROW_HALF_MIRROR = 0x141, QUAD_XOR2 = 0x4E, QUAD_XOR1 = 0xB1;
-    auto step = [&](auto ctrl, int w) __attribute__((always_inline)) {  // w = the lane bit of this exchange = number of columns kept
-        constexpr int CTRL = decltype(ctrl)::value;
-        const bool up = (c16 & w) != 0;
-#pragma unroll
-        for (int e = 0; e < RUN / 2; ++e) {
-            if (e < w) {
-                const float sa = up ? a[e] : a[e + w], sb = up ? b[e] : b[e + w];
-                const float ka = up ? a[e + w] : a[e], kb = up ? b[e + w] : b[e];
-                a[e] = ka + dpp_f32<CTRL>(sa);
-                b[e] = kb + dpp_f32<CTRL>(sb);
-            }
-        }
-    };
-    if constexpr (RUN == 8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            a[e] += dpp_f32<ROW_MIRROR>(a[e]);
-            b[e] += dpp_f32<ROW_MIRROR>(b[e]);
-        }
-    } else {
-        step(std::integral_constant<int, ROW_MIRROR>{}, 8);
-    }
-    step(std::integral_constant<int, ROW_HALF_MIRROR>{}, 4);
-    step(std::integral_constant<int, QUAD_XOR2>{}, 2);
-    step(std::integral_constant<int, QUAD_XOR1>{}, 1);
-}
 
 #ifndef MI355X_GEMM_PRIO
 #define MI355X_GEMM_PRIO 1  // s_setprio 1 around the K loop's MFMA + LDS-read phases, 0 around its wait / barrier / stage-issue section: the co-resident
@@ -667,55 +540,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
     for (int s0 = 0; s0 < D; ++s0)
         if (s0 < my_kb) issue(s0);
 
-    if (p.ln_stats) {
-        // LayerNorm consumer: (mean, rstd) of the tile's BM rows from the producer's 32-column partials, TPR threads per row,
-        // merged in a fixed order.  Placed behind the prologue's LDS-DMA issue so that its latency overlaps theirs (the compiler
-        // drains vmcnt before the first use of an ordinary load anyway; the first loop iteration then finds its stage landed).
-        constexpr int TPR = NTHR_ALL / BM;
-        static_assert(TPR >= 1 && (TPR & (TPR - 1)) == 0 && TPR <= 8, "threads per row");
-        const int row = tid_all / TPR, sub = tid_all % TPR;
-        const int m = min(m0 + row, p.M - 1);
-        float cn = 0.f, mean = 0.f, m2 = 0.f;
-        // all of this thread's partials are loaded BEFORE the first merge (independent loads, one L2 round trip instead of
-        // ln_parts / TPR serialized ones: 20 dependent trips at the head of every consumer cost more than the LayerNorm launch saved)
-        constexpr int MAXP = 24;
-        const float* sp = p.ln_stats + (int64_t)m * 2;
-        const int64_t pstride = (int64_t)p.M * 2;
-        f32x2 st[MAXP];
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int part = sub + i * TPR;
-            st[i] = part < p.ln_parts ? *reinterpret_cast<const f32x2*>(sp + part * pstride) : f32x2{0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i)
-            if (sub + i * TPR < p.ln_parts) {  // Chan's update with equal counts of 32: n = 32 i so far, f = 32 / (32 (i + 1)) is a constant
-                const float d = st[i][0] - mean, f = 1.0f / (float)(i + 1);
-                mean += d * f;
-                m2 += st[i][1] + d * d * (32.0f * i) * f;
-                cn = 32.0f * (i + 1);
-            }
-        for (int part = sub + MAXP * TPR; part < p.ln_parts; part += TPR) {  // wider than MAXP * TPR * 32 columns: the slow way
-            const f32x2 s2 = *reinterpret_cast<const f32x2*>(sp + part * pstride);
-            stat_merge(cn, mean, m2, 32.f, s2[0], s2[1]);
-        }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) {
-            const float nb = __shfl_xor(cn, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
-            // both partners must combine in the SAME order to end up with identical bits: lower sub-index first
-            if (sub & o) {
-                float n2 = nb, me2 = mb, q2 = qb;
-                stat_merge(n2, me2, q2, cn, mean, m2);
-                cn = n2, mean = me2, m2 = q2;
-            } else {
-                stat_merge(cn, mean, m2, nb, mb, qb);
-            }
-        }
-        if (sub == 0) {
-            rowstat[2 * row] = mean;
-            rowstat[2 * row + 1] = rsqrtf(m2 / cn + p.ln_eps);
-        }
-    }
+    if (p.ln_stats) ln_rowstat<BM, NTHR_ALL>(p, m0, tid_all, rowstat);
 
     // ---- main loop, software-pipelined through REGISTERS as well: the MFMAs of one half K block (32 bf16 / 16 f32 deep) run
     // while the fragments of the next half are being read from LDS, so no LDS latency is exposed to the matrix pipe:
@@ -1006,350 +831,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
         }
     }
 
-    // ---- epilogue ----
-    constexpr int EPC = DT<T>::EPC;
-    T* out = reinterpret_cast<T*>(p.out);
-    const T* bias = reinterpret_cast<const T*>(p.bias);
-    const T* rowbias = reinterpret_cast<const T*>(p.rowbias);
-    const T* res = reinterpret_cast<const T*>(p.res);
-
-    if constexpr (!CONV) {
-        if (tr) {
-            // transposed tile: every lane owns RUN_T = 4*MT consecutive ROWS m of NT columns n = n0 + wn*WNE + 16 j + c16
-            constexpr int RUN_T = 4 * MT;
-            T* out_t = reinterpret_cast<T*>(p.out_t);
-            const int mb = m0 + wm * WME + RUN_T * g;
-            const bool fullm = p.vec_ok && mb + RUN_T <= p.M;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wn * WNE + 16 * j + c16;
-                if (n >= p.N) continue;
-                float v[RUN_T];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];
-                if (p.ln_stats) {
-                    const float s = p.ln_s[n], c = p.ln_c[n];
-#pragma unroll
-                    for (int e = 0; e < RUN_T; ++e) {
-                        const int row = min(wm * WME + RUN_T * g + e, BM - 1);
-                        v[e] = rowstat[2 * row + 1] * (v[e] - rowstat[2 * row] * s) + c;
-                    }
-                } else if (bias) {
-                    const float b = to_f32(bias[n]);
-#pragma unroll
-                    for (int e = 0; e < RUN_T; ++e) v[e] += b;
-                }
-                T* op = out_t + (int64_t)(n - p.nt_begin) * p.ldt + mb;
-                if (fullm) {
-#pragma unroll
-                    for (int c = 0; c < RUN_T / EPC; ++c) {
-                        Vec16<T> ov;
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
-                        store16<T>(op + c * EPC, ov);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < RUN_T; ++e)
-                        if (mb + e < p.M) op[e] = from_f32<T>(v[e]);
-                }
-            }
-            return;
-        }
-    }
-
-    // every lane owns RUN = 4*NT consecutive columns of MT rows
-    constexpr int RUN = 4 * NT;
-    const int nl = wn * WNE + RUN * g;
-    const int n = n0 + nl;
-    const bool full = p.vec_ok && (n + RUN <= p.N);
-    if (p.ksplit > 1) {  // split-K: raw float32 partial sums; bias / residual / conversion happen in splitk_reduce_kernel
-        float* part = p.partial + (int64_t)split * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m0 + wm * WME + 16 * i + c16;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int nn = n + 4 * j;
-                if (nn + 4 <= p.N) *reinterpret_cast<f32x4*>(part + (int64_t)m * p.N + nn) = acc[i][j];
-                else
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (nn + r < p.N) part[(int64_t)m * p.N + nn + r] = acc[i][j][r];
-            }
-        }
-        return;
-    }
-    float cs_a[RUN], cs_b[RUN];  // GemmP::colstats: the even row of the current 32-row block
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int mrow = wm * WME + 16 * i + c16;
-        const int m = m0 + mrow;
-        // rows beyond M keep going through the arithmetic when statistics are produced (the shuffles below need all lanes);
-        // their stores are suppressed
-        const bool mok = m < p.M;
-        if (!mok && !p.stats_out && !p.colstats) continue;
-        float v[RUN];
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
-        if (full) {
-            if (p.ln_stats) {  // y = rstd * (acc - mean * s[n]) + c[n]   (c carries the Linear's bias)
-                const float mean = rowstat[2 * mrow], rstd = rowstat[2 * mrow + 1];
-#pragma unroll
-                for (int c = 0; c < RUN / 4; ++c) {
-                    const f32x4 sv = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4 * c), cv = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * c + e] = rstd * (v[4 * c + e] - mean * sv[e]) + cv[e];
-                }
-            } else if (bias) {
-#pragma unroll
-                for (int c = 0; c < RUN / EPC; ++c) {
-                    Vec16<T> bv = load16<T>(bias + n + c * EPC);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
-                }
-            }
-            if (rowbias && mok) {
-                const T* rb = rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n;
-#pragma unroll
-                for (int c = 0; c < RUN / EPC; ++c) {
-                    Vec16<T> bv = load16<T>(rb + c * EPC);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
-                }
-            }
-            if (p.gelu) {
-#pragma unroll
-                for (int e = 0; e < RUN; ++e) v[e] = p.gelu == 1 ? gelu_exact(v[e]) : quick_gelu(v[e]);
-            }
-            if (p.geglu) {
-                if constexpr (NT == 4) {
-                    constexpr int HR = RUN / 2;
-                    const int no = (n0 + wn * WNE) / 2 + HR * g;
-                    float o[HR];
-#pragma unroll
-                    for (int e = 0; e < HR; ++e) o[e] = v[e] * gelu_exact(v[HR + e]);
-                    if (res) {
-                        const T* rp = res + (int64_t)m * p.ldres + no;
-#pragma unroll
-                        for (int c = 0; c < HR / EPC; ++c) {
-                            Vec16<T> rv = load16<T>(rp + c * EPC);
-#pragma unroll
-                            for (int e = 0; e < EPC; ++e) o[c * EPC + e] += rv.get(e);
-                        }
-                    }
-                    constexpr int BKE = 128 / (int)sizeof(T);  // elements per 128-byte K block of the consumer
-                    T* op = p.out_kb ? out + ((int64_t)(no / BKE) * p.M + m) * BKE + no % BKE : out + (int64_t)m * p.ldo + no;
-#pragma unroll
-                    for (int c = 0; c < HR / EPC; ++c) {
-                        Vec16<T> ov;
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) ov.set(e, o[c * EPC + e]);
-                        store16<T>(op + c * EPC, ov);
-                    }
-                }
-            } else {
-                if (res && mok) {
-                    const T* rp = res + (int64_t)m * p.ldres + n;
-#pragma unroll
-                    for (int c = 0; c < RUN / EPC; ++c) {
-                        Vec16<T> rv = load16<T>(rp + c * EPC);
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) v[c * EPC + e] += rv.get(e);
-                    }
-                }
-                if (p.out_f32) {
-                    if (mok) {
-                        float* of = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
-#pragma unroll
-                        for (int c = 0; c < RUN / 4; ++c) *reinterpret_cast<f32x4*>(of + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
-                    }
-                    continue;
-                }
-                T* op = out + (int64_t)m * p.ldo + n;
-                float rs = 0.f;  // sum of the values AS STORED (rounded to T): the next LayerNorm normalises the stored tensor
-#pragma unroll
-                for (int c = 0; c < RUN / EPC; ++c) {
-                    Vec16<T> ov;
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
-                    if (mok) store16<T>(op + c * EPC, ov);
-                    if (p.stats_out || p.colstats) {
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) {
-                            v[c * EPC + e] = ov.get(e);
-                            rs += ov.get(e);
-                        }
-                    }
-                }
-                if (p.colstats) {
-                    // GroupNorm statistics for the consumer of this tensor: (sum, sum of squares) per column over each 32-row block = the two
-                    // 16-row MMA blocks 2h, 2h + 1 of this wave (i even: remember the row, i odd: add, reduce over the 16 lanes, store)
-                    if ((i & 1) == 0) {
-#pragma unroll
-                        for (int e = 0; e < RUN; ++e) {
-                            cs_a[e] = mok ? v[e] : 0.f;
-                            cs_b[e] = mok ? v[e] * v[e] : 0.f;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < RUN; ++e) {
-                            cs_a[e] += mok ? v[e] : 0.f;
-                            cs_b[e] += mok ? v[e] * v[e] : 0.f;
-                        }
-                        colsum16<RUN>(cs_a, cs_b, c16);
-                        const int blk = (m0 + wm * WME + 16 * (i - 1)) >> 5;  // (tiles start on multiples of 64 rows)
-                        if ((RUN == 16 || c16 < 8) && (blk << 5) < p.M) {
-                            f32x2 st = {cs_a[0], cs_b[0]};
-                            *reinterpret_cast<f32x2*>(p.colstats + ((int64_t)blk * p.N + n + (c16 & (RUN - 1))) * 2) = st;
-                        }
-                    }
-                }
-                if (p.stats_out) {
-                    // (mean, M2) of this lane's RUN columns, Chan-merged over the lane groups that share a 32-column chunk:
-                    // RUN = 16 -> groups (g, g^1); RUN = 8 -> all four groups.  Lower group first on both sides: identical bits.
-                    float mean = rs * (1.0f / RUN), m2 = 0.f, cn = (float)RUN;
-#pragma unroll
-                    for (int e = 0; e < RUN; ++e) m2 += (v[e] - mean) * (v[e] - mean);
-                    constexpr int GPC = 32 / RUN;  // lane groups per 32-column chunk
-#pragma unroll
-                    for (int o = 16; o < 16 * GPC; o <<= 1) {
-                        const float nb = __shfl_xor(cn, o), mb2 = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
-                        if (lane & o) {
-                            float n2 = nb, me2 = mb2, q2 = qb;
-                            stat_merge(n2, me2, q2, cn, mean, m2);
-                            cn = n2, mean = me2, m2 = q2;
-                        } else {
-                            stat_merge(cn, mean, m2, nb, mb2, qb);
-                        }
-                    }
-                    if (mok && (g % GPC) == 0) {
-                        const int chunk = n / 32;
-                        f32x2 st = {mean, m2};
-                        *reinterpret_cast<f32x2*>(p.stats_out + ((int64_t)chunk * p.M + m) * 2) = st;
-                    }
-                }
-            }
-        } else if (mok) {
-            // guarded scalar path (N edge tiles, unaligned outputs); geglu / LayerNorm fusion are never routed here (host checks)
-#pragma unroll
-            for (int e = 0; e < RUN; ++e) {
-                const int nn = n + e;
-                if (nn < p.N) {
-                    float val = v[e];
-                    if (bias) val += to_f32(bias[nn]);
-                    if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
-                    if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
-                    if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
-                    if (p.out_f32) reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + nn] = val;
-                    else out[(int64_t)m * p.ldo + nn] = from_f32<T>(val);
-                }
-            }
-        }
-    }
+    tile_epilogue<T, MT, NT, BM, CONV>(p, acc, rowstat, m0, n0, wm, wn, lane, tr, split);
 }
-
-// out[m][n] = dtype( sum_s partial[s][m][n] (fixed order) + bias[n] + rowbias[m / rpg][n] + res[m][n] ).  One workgroup = 32 rows x 64 columns:
-// thread (ty, tx) = (t >> 4, t & 15) owns rows 2 ty, 2 ty + 1 of the block at columns 4 tx .. 4 tx + 3 -- every partial it needs is requested up front
-// (2 rows x ksplit independent 16-byte loads), (M / 32) x (N / 64) workgroups keep the memory system as busy as the old grid-stride form -- and the
-// per-column sums GemmP::colstats asks for are 2 local adds + one fixed-order sum of the sixteen row pairs through LDS.
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
-    __shared__ float red[15][16][8];
-    constexpr int MAXS = 4;  // splits whose partials are all in flight at once (more: a serial tail)
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int nbx = (p.N + 63) / 64;
-    const int bm = blockIdx.x / nbx, bn = blockIdx.x - bm * nbx;
-    const int n = bn * 64 + tx * 4;
-    T* out = reinterpret_cast<T*>(p.out);
-    const T* bias = reinterpret_cast<const T*>(p.bias);
-    const T* rowbias = reinterpret_cast<const T*>(p.rowbias);
-    const T* res = reinterpret_cast<const T*>(p.res);
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool full4 = n + 4 <= p.N;
-    if (n < p.N) {
-        f32x4 part[2][MAXS];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int m = min(bm * 32 + ty * 2 + r, p.M - 1);
-#pragma unroll
-            for (int s = 0; s < MAXS; ++s) {
-                part[r][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (s < p.ksplit) {
-                    const float* pp = p.partial + ((int64_t)s * p.M + m) * p.N + n;
-                    if (full4) part[r][s] = *reinterpret_cast<const f32x4*>(pp);
-                    else
-                        for (int q = 0; q < 4; ++q)
-                            if (n + q < p.N) part[r][s][q] = pp[q];
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int m = bm * 32 + ty * 2 + r;
-            if (m >= p.M) break;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < MAXS; ++s)
-                if (s < p.ksplit) v[0] += part[r][s][0], v[1] += part[r][s][1], v[2] += part[r][s][2], v[3] += part[r][s][3];
-            for (int s = MAXS; s < p.ksplit; ++s) {
-                const float* pp = p.partial + ((int64_t)s * p.M + m) * p.N + n;
-                for (int q = 0; q < 4; ++q)
-                    if (n + q < p.N) v[q] += pp[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nn = n + q;
-                if (nn >= p.N) break;
-                float val = v[q];
-                if (bias) val += to_f32(bias[nn]);
-                if (rowbias) val += to_f32(rowbias[(int64_t)(m / p.rows_per_group) * p.ld_rowbias + nn]);
-                if (p.gelu) val = p.gelu == 1 ? gelu_exact(val) : quick_gelu(val);
-                if (res) val += to_f32(res[(int64_t)m * p.ldres + nn]);
-                const T o = from_f32<T>(val);
-                out[(int64_t)m * p.ldo + nn] = o;
-                const float f = to_f32(o);
-                s1[q] += f;
-                s2[q] += f * f;
-            }
-        }
-    }
-    if (p.colstats) {  // (workgroup-uniform)
-        if (ty > 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                red[ty - 1][tx][q] = s1[q];
-                red[ty - 1][tx][4 + q] = s2[q];
-            }
-        }
-        __syncthreads();
-        if (ty == 0 && n < p.N) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (n + q >= p.N) break;
-                float a = s1[q], b = s2[q];
-#pragma unroll
-                for (int j = 0; j < 15; ++j) {
-                    a += red[j][tx][q];
-                    b += red[j][tx][4 + q];
-                }
-                f32x2 st = {a, b};
-                *reinterpret_cast<f32x2*>(p.colstats + ((int64_t)bm * p.N + n + q) * 2) = st;
-            }
-        }
-    }
-}
-
-extern int g_pf_blocks;  // default number of prefetch workgroups when the caller gives spans but no count (0 = prefetch off)
-extern int g_pf_mode;    // 1 = plain loads, 2 = non-temporal
-extern int g_tile;       // 0 = heuristic / caller's hint, 1..6 = force a tile configuration (probing / A-B runs)
-extern int g_stages;     // 0 = heuristic / caller's hint, 2..4 = force the LDS pipeline depth
-extern int g_lora_dbg;   // probing: see GemmP::lora_dbg
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
 int launch_cfg(const GemmP& p, hipStream_t stream) {
@@ -1366,45 +849,7 @@ int launch_cfg(const GemmP& p, hipStream_t stream) {
         attr_set[dev] = true;
     }
     GemmP q = p;
-    q.tiles_n = (p.N + BN - 1) / BN;
-    q.tiles_m = (p.M + BM - 1) / BM;
-    // How the 8 XCDs (private L2 each) share the tile grid.  Bytes pulled into the L2s ~ nx * |X| + nw * |W| where nx / nw =
-    // number of XCDs that touch each activation row / weight row; |X|, |W| in K-elements per row (a 3x3 conv reads every
-    // activation row through 9 taps but it is ONE row in L2).  Candidates: exact pm x pn rectangles, or balanced contiguous
-    // chunks of the row-major (nx = 1, nw = 8) / column-major (nx = 8, nw = 1) order.
-    double kx = 0, kw = 0;
-    for (int sgi = 0; sgi < p.nseg; ++sgi) {
-        const SegP& sg = p.seg[sgi];
-        kw += sg.nkb;
-        kx += CONV ? (double)sg.nkb / (sg.ksize * sg.ksize) : (double)sg.nkb;
-    }
-    const double bx_ = (double)p.M * kx, bw_ = (double)p.N * kw;
-    double best = bx_ + 8.0 * bw_;  // row-major chunks
-    q.pn = 0;
-    q.hm = q.hn = 0;
-    if (8.0 * bx_ + bw_ < best) {
-        best = 8.0 * bx_ + bw_;
-        q.pn = -1;
-    }
-    for (int pm = 2; pm <= 4; pm *= 2) {
-        const int pn = 8 / pm;
-        if (q.tiles_m % pm || q.tiles_n % pn) continue;
-        const double cost = pn * bx_ + pm * bw_;
-        if (cost < best) {
-            best = cost;
-            q.pn = pn;
-            q.hm = q.tiles_m / pm;
-            q.hn = q.tiles_n / pn;
-        }
-    }
-    q.grid0 = q.tiles_m * q.tiles_n;
-    bool any_pf = false;
-    for (int i = 0; i < MI355X_MAX_PREFETCH; ++i) any_pf = any_pf || (q.pf_ptr[i] && q.pf_bytes[i] > 0);
-    if (!any_pf || g_pf_blocks == 0) q.pf_blocks = 0;
-    else if (q.pf_blocks <= 0) q.pf_blocks = g_pf_blocks;
-    q.pf_blocks = (q.pf_blocks + 7) / 8 * 8;  // a multiple of 8: compute block b still lands on XCD b % 8
-    if (KG > 1) q.pf_blocks = (q.pf_blocks / 2 + 7) / 8 * 8;  // twice the threads per prefetch workgroup
-    q.pf_mode = g_pf_mode;
+    plan_grid(q, BM, BN, CONV, KG);
     q.lora_dbg = g_lora_dbg;
     q.lora_tt = 0;
     if constexpr (LORA && !CONV && KG == 1) {

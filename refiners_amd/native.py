@@ -8,6 +8,7 @@ raises `NativeError` (the fused fluxion nodes decide, *before* calling, whether 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Any, Optional, Sequence
 
@@ -300,6 +301,8 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     except OSError as e:  # e.g. no HIP runtime on this machine
         raise NativeError(f"cannot load {p}: {e}") from e
     lib.mi355x_abi_version.restype = C.c_int
+    if os.environ.get("REFINERS_AMD_FORCE_TILE"):  # probing: every GEMM / conv launch that can run on this tile configuration does (tools, A/B runs)
+        lib.mi355x_set_option(b"tile", int(os.environ["REFINERS_AMD_FORCE_TILE"]))
     lib.mi355x_device_info.argtypes = [C.c_char_p, C.c_int32]
     lib.mi355x_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
     lib.mi355x_epoch_bump.argtypes = [C.c_void_p, C.c_void_p]

@@ -22,7 +22,7 @@ def set_tile(v, st=0):
 def main():
     shapes = [("FF1", 2048, 1280, 10240, True), ("QKV", 2048, 1280, 3840, False), ("FF2", 2048, 5120, 1280, False), ("proj", 2048, 1280, 1280, False),
               ("FF1x4", 8192, 1280, 10240, True), ("QKVx4", 8192, 1280, 3840, False), ("640", 8192, 640, 640, False), ("4096^3", 4096, 4096, 4096, False)]
-    tiles = [(0, 0), (1, 2), (1, 3), (3, 2), (4, 2), (6, 2)]
+    tiles = [(0, 0), (1, 2), (3, 2), (4, 2), (7, 0)]
     for name, M, K, N, geglu in shapes:
         sets = []
         for _ in range(6):
