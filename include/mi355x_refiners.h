@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 6
+#define MI355X_ABI_VERSION 7
 
 enum { MI355X_F32 = 0, MI355X_BF16 = 1 };
 
@@ -112,7 +112,13 @@ typedef struct {
     const void* zeros;      /* >= 256 zero bytes in device memory; required when conv == 1 */
     int32_t tile;           /* 0 = let the library choose; 1: 128x128  2: 128x64  3: 64x128  4: 64x64 (M x N);
                                6: 128x128 computed by 8 waves in two K groups (even / odd K blocks, summed through LDS in a fixed order):
-                               for launches with fewer output tiles than CUs */
+                               for launches with fewer output tiles than CUs;
+                               7: 256x256 on the 8-wave / eight-phase main loop (one workgroup per CU, counted LDS-DMA waits, the two halves of the
+                               workgroup one barrier apart): the large-grid shapes;  8: the same loop as a persistent "stream-K" launch -- one
+                               workgroup per CU, each taking an equal share of (output tiles x K tiles), partial tiles summed in a fixed order
+                               through sk_ws -- for launches whose 256x256 tiles do not fill a whole number of rounds (needs sk_ws / sk_flags;
+                               falls back to 7 without them).  7 / 8 do not combine with in-launch LoRA, out_t, ksplit or operands of 2 GB and
+                               more: such launches run on the library's own choice among 1..4 */
     int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
                                partial sums into `ws`, a second launch adds them in a fixed order (deterministic) and
                                applies the epilogue.  Not combinable with geglu. */
@@ -189,6 +195,13 @@ typedef struct {
        >= ceil(M / 32) * N * 2 floats, 8-byte aligned.  Written by the epilogue (by the reduction pass when ksplit > 1), fixed summation order.
        Needs the vectorisable epilogue, N a multiple of 16; not combinable with geglu / out_t / out_f32 / the 8-wave tile.  NULL: off. */
     float* colstats_out;
+    /* tile 8 only.  sk_ws: sk_slots x 256 KB of float32 scratch (16-byte aligned) -- one slot per workgroup, so sk_slots bounds the number of
+       workgroups (256 = one per CU of an MI355X); sk_flags: int32[sk_slots + 1], zeroed once by the caller: [0, sk_slots) are hand-off flags that
+       the kernel leaves zero again, the last word is an error flag the kernel raises if a deposit never arrived (after 2 s).  Both may be shared by
+       every launch that runs on one stream; launches that may run concurrently need their own. */
+    void* sk_ws;
+    int32_t* sk_flags;
+    int32_t sk_slots;
 } mi355x_gemm_args;
 
 int mi355x_gemm(const mi355x_gemm_args* args, void* stream);

@@ -12,6 +12,8 @@ int g_pf_mode = 1;
 int g_tile = 0;
 int g_stages = 0;
 int g_lora_dbg = 0;
+int g_sk_g = 0;
+int g_g8_persist = 1;
 
 namespace {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -25,6 +27,14 @@ extern "C" int mi355x_set_option(const char* name, int value);
 extern "C" int mi355x_set_option(const char* name, int value) {
     // debugging / A-B switches; not part of the stable contract
     if (!name) return MI355X_EARG;
+    if (name[0] == 'g' && name[1] == '8') {  // "g8persist"
+        g_g8_persist = value;
+        return MI355X_OK;
+    }
+    if (name[0] == 's' && name[1] == 'k') {  // "skg": number of stream-K workgroups (0 = one per CU)
+        g_sk_g = value;
+        return MI355X_OK;
+    }
     if (name[0] == 's') {  // "stages"
         g_stages = value;
         return MI355X_OK;
@@ -212,9 +222,14 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if ((g_tile ? g_tile : a->tile) == 7 && gemm8_ok(p)) {  // the 256 x 256 tile on the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
-        if (a->conv) return a->dtype == MI355X_F32 ? launch_conv8_f32(p, st) : launch_conv8_bf16(p, st);
-        return a->dtype == MI355X_F32 ? launch_gemm8_f32(p, st) : launch_gemm8_bf16(p, st);
+    const int tile_req = g_tile ? g_tile : a->tile;
+    if ((tile_req == 7 || tile_req == 8) && gemm8_ok(p)) {  // the 256 x 256 tile on the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
+        const bool sk = tile_req == 8 && a->sk_ws && a->sk_flags && a->sk_slots > 0 && (reinterpret_cast<uintptr_t>(a->sk_ws) & 15) == 0;
+        p.sk_ws = static_cast<float*>(a->sk_ws);
+        p.sk_flags = a->sk_flags;
+        p.sk_cap = a->sk_slots;
+        if (a->conv) return a->dtype == MI355X_F32 ? launch_conv8_f32(p, st, sk) : launch_conv8_bf16(p, st, sk);
+        return a->dtype == MI355X_F32 ? launch_gemm8_f32(p, st, sk) : launch_gemm8_bf16(p, st, sk);
     }
     if (a->conv) return a->dtype == MI355X_F32 ? launch_conv_f32(p, st) : launch_conv_bf16(p, st);
     if (a->dtype == MI355X_F32) return launch_tile<float, false>(p, st);

@@ -27,13 +27,16 @@
 // Loader: buffer_load_dwordx4 ... lds (LDS-DMA through a buffer descriptor): per-lane 32-bit offset that is constant over the K loop, the
 // running K offset in the instruction's SCALAR offset, the descriptor per segment -- no vector ALU work per load -- and out-of-range lanes
 // (conv padding, rows beyond M / N) are given offset 0x80000000, for which the hardware writes zeros to LDS (no zero page, no select).
-// Not in this loop (the host keeps such launches on gemm_kernel.cuh): in-launch LoRA, transposed column groups, operands of 2 GB and more.
+// Not in this loop (the host keeps such launches on gemm_kernel.cuh): in-launch LoRA, operands of 2 GB and more.
 #pragma once
+#include <vector>
+
 #include "gemm_epilogue.cuh"
 
 namespace mi355x {
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 MI_DEV rsrc_t make_rsrc(const char* base, int64_t bytes) {
     // wave-uniform by construction; readfirstlane makes that provable (guide T20: otherwise every load sits in a waterfall loop)
@@ -103,312 +106,436 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* rowstat = reinterpret_cast<float*>(smem + 2 * BUFB);  // [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer)
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
-    const int g = lane >> 4, c16 = lane & 15;
+    const int tid0 = threadIdx.x, wid = wave_id();
     const int wm = wid >> 2, wn = wid & 3;
     if ((int)blockIdx.x < p.pf_blocks) {
-        prefetch_role<NTHR>(p, tid);
+        prefetch_role<NTHR>(p, tid0);
         return;
     }
     const int bid = (int)blockIdx.x - p.pf_blocks;
-    const int split = p.ksplit > 1 ? bid / p.grid0 : 0;
-    int tm, tn;
-    tile_coords(p, bid - split * p.grid0, tm, tn);
-    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- loader geometry.  Half tile (h), load (s): 128 rows x 8 chunks = 1024 pieces of 16 B = 2 loads x 512 threads; piece s * 512 + tid is
-    // (local row lr = s * 64 + 8 wid + (lane >> 3), physical chunk lane & 7).  X: LDS row = 128 s + 64 h + (lr & 63);  W: LDS row = 64 (lr >> 5)
-    // + 32 h + (lr & 31).  A wave's 64 pieces are 8 consecutive LDS rows = 1 KB, lane-linear.  The bank swizzle of row R is (R >> 1) & 7, which
-    // for every one of these rows equals 4 (wid & 1) + (lane >> 4): ONE source-chunk offset per thread.
-    const int lr8 = lane >> 3;
-    const uint32_t coff = (uint32_t)(((lane & 7) ^ (4 * (wid & 1) + (lane >> 4))) << 4);
-    int xrow[2][2];  // global row m (or -1)
-    int wrow[2][2];  // global weight row n (or -1)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int m = m0 + 128 * s + 64 * h + 8 * wid + lr8;
-            xrow[h][s] = m < p.M ? m : -1;
-            // LDS row R of the W tile holds output column n0 + (R - rl) + 16 a + 4 j + b, rl = R % 64 = 16 j + 4 a + b (gemm_kernel.cuh header: every
-            // lane then owns 16 consecutive output columns)
-            const int R = 64 * (2 * s + (wid >> 2)) + 32 * h + 8 * (wid & 3) + lr8;
-            const int rl = R & 63, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
-            const int n = n0 + (R - rl) + 16 * a + 4 * j + b;
-            wrow[h][s] = n < p.N ? n : -1;
-        }
-    int xb[2][2], xyx[2][2];  // conv: image index, (oy | ox << 16) of the output pixel
-    if constexpr (CONV) {
-        const int ohw = p.OH * p.OW;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int m = xrow[h][s] < 0 ? 0 : xrow[h][s];
-                const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW;
-                xb[h][s] = b;
-                xyx[h][s] = oy | ((rem - oy * p.OW) << 16);
-            }
+    // ---- this workgroup's span of the launch's work.  The unit of work is one K tile of one output tile; an output tile is sk_nk consecutive units.
+    //   sk_mode 0: whole tiles: workgroup b takes tiles b, b + sk_g, ... in the XCD-aware rasterisation of plan_grid (sk_g = tiles: one each);
+    //   sk_mode 1 ("stream-K"): sk_g persistent workgroups split the tiles x sk_nk units evenly (+-1) and contiguously, workgroup b taking span b.
+    //   A span is walked BACKWARDS.  If it ends inside a tile, the workgroup first computes that tile's K tiles up to the span's end and DEPOSITS
+    //   its float32 accumulators in sk_ws, raising flag b; then whole tiles; if it starts inside a tile, it finally computes that tile's LAST K
+    //   range, COLLECTS what workgroups b - 1, b - 2, ... deposited for the earlier ranges (in that fixed order: the sum depends on the
+    //   decomposition, not on timing -- bit-reproducible) and runs the tile's epilogue.  A deposit is the first thing a workgroup does, a collect
+    //   the last, and an owner only ever waits for workgroups with LOWER ids, which the dispatcher started before it (no deadlock, whatever else
+    //   shares the GPU).  Flags are zero between launches: the owner clears what it consumed.
+    const int nk_tile = p.sk_nk;
+    int64_t u0 = 0, u1 = 0;
+    if (p.sk_mode == 1) {
+        const int64_t U = (int64_t)p.grid0 * nk_tile;
+        u0 = U * bid / p.sk_g;
+        u1 = U * (bid + 1) / p.sk_g;
     }
+    int tile_next = bid;  // sk_mode 0: whole tiles bid, bid + sk_g, bid + 2 sk_g, ... (sk_g = the number of workgroups; = the number of tiles for one tile each)
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- this workgroup's K range ----
-    int seg0 = 0, kb0 = 0, nk = 0;
-    for (int s = 0; s < p.nseg; ++s) nk += p.seg[s].nkb;
-    if (p.ksplit > 1) {
-        const int first = split * p.kb_per_split;
-        nk = min(p.kb_per_split, nk - first);
-        kb0 = first;
-        while (seg0 < p.nseg - 1 && kb0 >= p.seg[seg0].nkb) {
-            kb0 -= p.seg[seg0].nkb;
-            ++seg0;
-        }
-    }
-
-    // ---- two independent cursors (the X halves of a K tile are staged in other phases than its W halves) ----
-    uint32_t xvo[2][2], wvo[2][2];  // per-lane byte offsets into the current segment's x / w
-    rsrc_t xrs, wrs;
-    int x_seg = seg0, x_kb = kb0, x_nkb = 0, x_cpb = 1, x_cb = 0, x_tap = 0;
-    int w_seg = seg0, w_kb = kb0, w_nkb = 0;
-    uint32_t x_so = 0, x_step = 128, w_so = 0, w_step = 128;
-    int c_ks = 1, c_pad = 0, c_st = 1, c_up = 0, c_H = 1, c_W = 1;  // conv: the current segment's geometry, held in scalars (set_tap runs inside the K loop)
-    uint32_t c_ld = 0;
-    auto set_tap = [&]() __attribute__((always_inline)) {
-        int dy = x_tap / c_ks, dx = x_tap - dy * c_ks;
-        dy -= c_pad;
-        dx -= c_pad;
-        const int HH = c_H << c_up, WW = c_W << c_up;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int iy = (xyx[h][s] & 0xffff) * c_st + dy, ix = (xyx[h][s] >> 16) * c_st + dx;
-                const bool ok = xrow[h][s] >= 0 && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
-                const int pix = (xb[h][s] * c_H + (iy >> c_up)) * c_W + (ix >> c_up);
-                xvo[h][s] = ok ? (uint32_t)pix * c_ld + coff : OOB;
-            }
-    };
-    auto enter_x = [&](int s, int kb) __attribute__((always_inline)) {
-        const SegP& sp = p.seg[s];
-        x_nkb = sp.nkb;
-        xrs = make_rsrc(sp.x, sp.xbytes);
-        if constexpr (CONV) {
-            x_cpb = sp.cpb;
-            x_tap = kb / sp.cpb;
-            x_cb = kb - x_tap * sp.cpb;
-            x_so = (uint32_t)x_cb * 128u;
-            c_ks = sp.ksize, c_pad = sp.pad, c_st = sp.stride, c_up = sp.ups_shift, c_H = sp.H, c_W = sp.W, c_ld = (uint32_t)sp.ldxb;
-            set_tap();
-        } else {
-            x_step = sp.xkb ? (uint32_t)p.M * 128u : 128u;
-            x_so = (uint32_t)kb * x_step;
-            const uint32_t ld = sp.xkb ? 128u : (uint32_t)sp.ldxb;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) xvo[h][s2] = xrow[h][s2] >= 0 ? (uint32_t)xrow[h][s2] * ld + coff : OOB;
-        }
-    };
-    auto enter_w = [&](int s, int kb) __attribute__((always_inline)) {
-        const SegP& sp = p.seg[s];
-        w_nkb = sp.nkb;
-        wrs = make_rsrc(sp.w, sp.wbytes);
-        w_step = sp.wkb ? (uint32_t)p.N * 128u : 128u;
-        w_so = (uint32_t)kb * w_step;
-        const uint32_t ld = sp.wkb ? 128u : (uint32_t)sp.ldwb;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) wvo[h][s2] = wrow[h][s2] >= 0 ? (uint32_t)wrow[h][s2] * ld + coff : OOB;
-    };
-    auto adv_x = [&]() __attribute__((always_inline)) {  // one K tile forward (called behind the stage of X half 1)
-        ++x_kb;
-        if constexpr (CONV) {
-            x_so += 128u;
-            if (++x_cb == x_cpb) {
-                x_cb = 0;
-                x_so = 0;
-                ++x_tap;
-                if (x_kb < x_nkb) set_tap();
-            }
-        } else {
-            x_so += x_step;
-        }
-        if (x_kb == x_nkb) {
-            x_kb = 0;
-            if (++x_seg < p.nseg) enter_x(x_seg, 0);
-        }
-    };
-    auto adv_w = [&]() __attribute__((always_inline)) {
-        ++w_kb;
-        w_so += w_step;
-        if (w_kb == w_nkb) {
-            w_kb = 0;
-            if (++w_seg < p.nseg) enter_w(w_seg, 0);
-        }
-    };
-    auto stage_x = [&](int h, int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) blds16(xrs, smem + buf * BUFB + (128 * s + 64 * h + 8 * wid) * 128, xvo[h][s], x_so);
-    };
-    auto stage_w = [&](int h, int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) blds16(wrs, smem + buf * BUFB + XB + (64 * (2 * s + (wid >> 2)) + 32 * h + 8 * (wid & 3)) * 128, wvo[h][s], w_so);
-    };
-
-    // ---- fragments ----
-    // row 16 q + c16 of a tile, logical chunk 4 kk + g: byte offset 128 (16 q) + fo[kk]
-    int fo[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fo[kk] = c16 * 128 + (((4 * kk + g) ^ ((c16 >> 1) & 7)) << 4);
-    frag_t xf[4][2];     // X quadrant rows: [16-row block][K half]
-    frag_t wf[2][2][2];  // W halves: [h][16-row block][K half]
-    auto read_x = [&](int h, int buf) __attribute__((always_inline)) {
-        const char* xs = smem + buf * BUFB + (128 * wm + 64 * h) * 128;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) xf[i][kk] = lds_read_frag(xs, i * 2048 + fo[kk]);
-    };
-    auto read_w = [&](int h, int buf) __attribute__((always_inline)) {
-        const char* ws = smem + buf * BUFB + XB + (64 * wn + 32 * h) * 128;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) wf[h][j][kk] = lds_read_frag(ws, j * 2048 + fo[kk]);
-    };
-    auto mma_q = [&](auto hxc, auto hwc) __attribute__((always_inline)) {  // quadrant (hx, hw): 16 MMA steps
-        constexpr int hx = decltype(hxc)::value, hw = decltype(hwc)::value;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma_step<T>(acc[4 * hx + i][2 * hw + j], wf[hw][j][kk], xf[i][kk]);
-    };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     auto bar = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_barrier(); };
     auto lgkm0 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     auto lgkm8 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); };
-    // the compute half of a phase: barrier | the fragments have arrived | 16 MFMA at raised priority | barrier
-    auto compute = [&](auto hxc, auto hwc, bool reads) __attribute__((always_inline)) {
-        fence();
-        bar();
-        if (reads) lgkm0();
-        fence();
-        if constexpr (MI355X_G8_PRIO != 0) __builtin_amdgcn_s_setprio(1);
-        mma_q(hxc, hwc);
-        if constexpr (MI355X_G8_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-        fence();
-        bar();
-        fence();
-    };
 
-    // ---- prologue: K tile 0 completely, three half tiles of K tile 1 ----
-    enter_x(x_seg, x_kb);
-    enter_w(w_seg, w_kb);
-    stage_w(0, 0);
-    stage_x(0, 0);
-    stage_w(1, 0);
-    adv_w();
-    stage_x(1, 0);
-    adv_x();
-    if (nk > 1) {
-        stage_w(0, 1);
-        stage_x(0, 1);
-        stage_w(1, 1);
-        adv_w();
-    }
-    if (p.ln_stats) ln_rowstat<BM, NTHR>(p, m0, tid, rowstat);
-    if (nk > 1) wait_vm<6>();
-    else wait_vm0();
-    fence();
-    bar();
-    if (wm == 1) bar();  // the second half of the workgroup runs one barrier behind the first from here on
-    fence();
-
-    // ---- main loop: two K tiles per trip.  GUARD = false: tiles t .. t + 3 exist (no conditions anywhere); true: the last one or two trips ----
-    auto trip = [&](auto guardc, int t) __attribute__((always_inline)) {
-        constexpr bool G = decltype(guardc)::value;
-        const bool e1 = !G || t + 1 < nk, e2 = !G || t + 2 < nk, e3 = !G || t + 3 < nk;
-        // phase 1
-        read_w(0, 0);
-        fence();  // (the four W reads first: lgkmcnt(8) below counts on it)
-        read_x(0, 0);
-        if (e1) stage_x(1, 1);
-        lgkm8();
-        if (e1) adv_x();  // (behind the counted wait: a segment change issues scalar loads, which share lgkmcnt with the LDS reads)
-        compute(I0{}, I0{}, true);
-        // phase 2
-        read_w(1, 0);
-        if (e2) stage_w(0, 0);
-        compute(I0{}, I1{}, true);
-        // phase 3
-        read_x(1, 0);
-        if (e2) stage_x(0, 0);
-        compute(I1{}, I1{}, true);
-        // phase 4
-        if (e2) {
-            stage_w(1, 0);
-            adv_w();
-            wait_vm<6>();
+    while (true) {
+        // (the thread id goes through an opaque move once per segment: nothing derived from it -- epilogue addresses, hand-over offsets -- can be
+        //  hoisted out of this loop and kept in registers through the K loop, which has none to spare)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+        // ---- loader geometry.  Half tile (h), load (s): 128 rows x 8 chunks = 1024 pieces of 16 B = 2 loads x 512 threads; piece s * 512 + tid is
+        // (local row lr = s * 64 + 8 wid + (lane >> 3), physical chunk lane & 7).  X: LDS row = 128 s + 64 h + (lr & 63);  W: LDS row = 64 (lr >> 5)
+        // + 32 h + (lr & 31).  A wave's 64 pieces are 8 consecutive LDS rows = 1 KB, lane-linear.  The bank swizzle of row R is (R >> 1) & 7, which
+        // for every one of these rows equals 4 (wid & 1) + (lane >> 4): ONE source-chunk offset per thread.
+        const int lr8 = lane >> 3;
+        const uint32_t coff = (uint32_t)(((lane & 7) ^ (4 * (wid & 1) + (lane >> 4))) << 4);
+        // row 16 q + c16 of a tile, logical chunk 4 kk + g: byte offset 128 (16 q) + fo[kk]
+        int fo[2];
+    #pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fo[kk] = c16 * 128 + (((4 * kk + g) ^ ((c16 >> 1) & 7)) << 4);
+        int tile, kfirst = 0, nk = nk_tile;
+        int64_t tbeg = 0;
+        bool owner = true, more;
+        if (p.sk_mode == 1) {
+            if (u0 >= u1) break;
+            tile = (int)((u1 - 1) / nk_tile);
+            tbeg = (int64_t)tile * nk_tile;
+            kfirst = u0 > tbeg ? (int)(u0 - tbeg) : 0;  // first K tile of this segment
+            nk = (int)(u1 - tbeg) - kfirst;             // K tiles of this segment
+            owner = kfirst + nk == nk_tile;             // this segment holds the tile's last K range: it ends with the tile's epilogue
+            u1 -= nk;
+            more = u0 < u1;
         } else {
-            wait_vm0();
+            if (tile_next >= p.grid0) break;
+            tile = tile_next;
+            tile_next += p.sk_g;
+            more = tile_next < p.grid0;
         }
-        compute(I1{}, I0{}, false);
-        if (G && !e1) return;
-        // phase 5
-        read_w(0, 1);
-        fence();
-        read_x(0, 1);
-        if (e2) stage_x(1, 0);
-        lgkm8();
-        if (e2) adv_x();
-        compute(I0{}, I0{}, true);
-        // phase 6
-        read_w(1, 1);
-        if (e3) stage_w(0, 1);
-        compute(I0{}, I1{}, true);
-        // phase 7
-        read_x(1, 1);
-        if (e3) stage_x(0, 1);
-        compute(I1{}, I1{}, true);
-        // phase 8
-        if (e3) {
+        int tm, tn;
+        if (p.sk_mode == 1) {  // tiles in row-major (sk_order 0) or column-major order along the unit axis
+            if (p.sk_order == 0) {
+                tm = tile / p.tiles_n;
+                tn = tile - tm * p.tiles_n;
+            } else {
+                tn = tile / p.tiles_m;
+                tm = tile - tn * p.tiles_m;
+            }
+        } else {
+            tile_coords(p, tile, tm, tn);
+        }
+        const int m0 = tm * BM, n0 = tn * BN;
+
+        // transposed tile (columns >= nt_begin, stored as out_t[n][m]): the tile of the TRANSPOSED problem -- the LDS slot that normally holds activation
+        // rows is filled from the weight rows n0 + R, the slot that normally holds (permuted) weight rows from the activation rows m0 + perm(R).  The K
+        // loop does not know; acc[i][j] then is the (weight rows 16 i.., activation rows 16 j..) block, and the epilogue gets its transpose.
+        const bool tr = !CONV && n0 >= p.nt_begin;
+        const int xs_lim = tr ? p.N : p.M, ws_lim = tr ? p.M : p.N, xs_0 = tr ? n0 : m0, ws_0 = tr ? m0 : n0;
+        int xrow[2][2];  // source row of the X slot's LDS row (or -1): an activation row m (transposed tile: a weight row n)
+        int wrow[2][2];  // source row of the W slot's LDS row (or -1): a weight row n (transposed tile: an activation row m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int rx = xs_0 + 128 * s + 64 * h + 8 * wid + lr8;
+                xrow[h][s] = rx < xs_lim ? rx : -1;
+                // LDS row R of the W slot holds source row (R - rl) + 16 a + 4 j + b, rl = R % 64 = 16 j + 4 a + b (gemm_kernel.cuh header: every lane
+                // then owns 16 consecutive output columns)
+                const int R = 64 * (2 * s + (wid >> 2)) + 32 * h + 8 * (wid & 3) + lr8;
+                const int rl = R & 63, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
+                const int rw = ws_0 + (R - rl) + 16 * a + 4 * j + b;
+                wrow[h][s] = rw < ws_lim ? rw : -1;
+            }
+        int xb[2][2], xyx[2][2];  // conv: image index, (oy | ox << 16) of the output pixel
+        if constexpr (CONV) {
+            const int ohw = p.OH * p.OW;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int m = xrow[h][s] < 0 ? 0 : xrow[h][s];
+                    const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW;
+                    xb[h][s] = b;
+                    xyx[h][s] = oy | ((rem - oy * p.OW) << 16);
+                }
+        }
+
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- the segment's position in the K segments of the launch ----
+        int seg0 = 0, kb0 = kfirst;
+        while (seg0 < p.nseg - 1 && kb0 >= p.seg[seg0].nkb) {
+            kb0 -= p.seg[seg0].nkb;
+            ++seg0;
+        }
+
+        // ---- two independent cursors (the X halves of a K tile are staged in other phases than its W halves) ----
+        uint32_t xvo[2][2], wvo[2][2];  // per-lane byte offsets into the current segment's x / w
+        rsrc_t xrs, wrs;
+        int x_seg = seg0, x_kb = kb0, x_nkb = 0, x_cpb = 1, x_cb = 0, x_tap = 0;
+        int w_seg = seg0, w_kb = kb0, w_nkb = 0;
+        uint32_t x_so = 0, x_step = 128, w_so = 0, w_step = 128;
+        int c_ks = 1, c_pad = 0, c_st = 1, c_up = 0, c_H = 1, c_W = 1;  // conv: the current segment's geometry, held in scalars (set_tap runs inside the K loop)
+        uint32_t c_ld = 0;
+        auto set_tap = [&]() __attribute__((always_inline)) {
+            int dy = x_tap / c_ks, dx = x_tap - dy * c_ks;
+            dy -= c_pad;
+            dx -= c_pad;
+            const int HH = c_H << c_up, WW = c_W << c_up;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int iy = (xyx[h][s] & 0xffff) * c_st + dy, ix = (xyx[h][s] >> 16) * c_st + dx;
+                    const bool ok = xrow[h][s] >= 0 && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
+                    const int pix = (xb[h][s] * c_H + (iy >> c_up)) * c_W + (ix >> c_up);
+                    xvo[h][s] = ok ? (uint32_t)pix * c_ld + coff : OOB;
+                }
+        };
+        auto enter_x = [&](int s, int kb) __attribute__((always_inline)) {
+            const SegP& sp = p.seg[s];
+            x_nkb = sp.nkb;
+            xrs = make_rsrc(sp.x, sp.xbytes);
+            if constexpr (CONV) {
+                x_cpb = sp.cpb;
+                x_tap = kb / sp.cpb;
+                x_cb = kb - x_tap * sp.cpb;
+                x_so = (uint32_t)x_cb * 128u;
+                c_ks = sp.ksize, c_pad = sp.pad, c_st = sp.stride, c_up = sp.ups_shift, c_H = sp.H, c_W = sp.W, c_ld = (uint32_t)sp.ldxb;
+                set_tap();
+            } else {
+                const bool kbl = tr ? sp.wkb : sp.xkb;
+                if (tr) xrs = make_rsrc(sp.w, sp.wbytes);
+                x_step = kbl ? (uint32_t)xs_lim * 128u : 128u;
+                x_so = (uint32_t)kb * x_step;
+                const uint32_t ld = kbl ? 128u : (uint32_t)(tr ? sp.ldwb : sp.ldxb);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) xvo[h][s2] = (uint32_t)xrow[h][s2] * ld + coff;  // (row -1: 2^32 - ld + coff, beyond every descriptor)
+            }
+        };
+        auto enter_w = [&](int s, int kb) __attribute__((always_inline)) {
+            const SegP& sp = p.seg[s];
+            w_nkb = sp.nkb;
+            const bool kbl = tr ? sp.xkb : sp.wkb;
+            wrs = tr ? make_rsrc(sp.x, sp.xbytes) : make_rsrc(sp.w, sp.wbytes);
+            w_step = kbl ? (uint32_t)ws_lim * 128u : 128u;
+            w_so = (uint32_t)kb * w_step;
+            const uint32_t ld = kbl ? 128u : (uint32_t)(tr ? sp.ldxb : sp.ldwb);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) wvo[h][s2] = (uint32_t)wrow[h][s2] * ld + coff;
+        };
+        auto adv_x = [&]() __attribute__((always_inline)) {  // one K tile forward (called behind the stage of X half 1)
+            ++x_kb;
+            if constexpr (CONV) {
+                x_so += 128u;
+                if (++x_cb == x_cpb) {
+                    x_cb = 0;
+                    x_so = 0;
+                    ++x_tap;
+                    if (x_kb < x_nkb) set_tap();
+                }
+            } else {
+                x_so += x_step;
+            }
+            if (x_kb == x_nkb) {
+                x_kb = 0;
+                if (++x_seg < p.nseg) enter_x(x_seg, 0);
+            }
+        };
+        auto adv_w = [&]() __attribute__((always_inline)) {
+            ++w_kb;
+            w_so += w_step;
+            if (w_kb == w_nkb) {
+                w_kb = 0;
+                if (++w_seg < p.nseg) enter_w(w_seg, 0);
+            }
+        };
+        auto stage_x = [&](int h, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) blds16(xrs, smem + buf * BUFB + (128 * s + 64 * h + 8 * wid) * 128, xvo[h][s], x_so);
+        };
+        auto stage_w = [&](int h, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) blds16(wrs, smem + buf * BUFB + XB + (64 * (2 * s + (wid >> 2)) + 32 * h + 8 * (wid & 3)) * 128, wvo[h][s], w_so);
+        };
+
+        // ---- fragments ----
+        frag_t xf[4][2];     // X quadrant rows: [16-row block][K half]
+        frag_t wf[2][2][2];  // W halves: [h][16-row block][K half]
+        auto read_x = [&](int h, int buf) __attribute__((always_inline)) {
+            const char* xs = smem + buf * BUFB + (128 * wm + 64 * h) * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) xf[i][kk] = lds_read_frag(xs, i * 2048 + fo[kk]);
+        };
+        auto read_w = [&](int h, int buf) __attribute__((always_inline)) {
+            const char* ws = smem + buf * BUFB + XB + (64 * wn + 32 * h) * 128;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) wf[h][j][kk] = lds_read_frag(ws, j * 2048 + fo[kk]);
+        };
+        auto mma_q = [&](auto hxc, auto hwc) __attribute__((always_inline)) {  // quadrant (hx, hw): 16 MMA steps
+            constexpr int hx = decltype(hxc)::value, hw = decltype(hwc)::value;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma_step<T>(acc[4 * hx + i][2 * hw + j], wf[hw][j][kk], xf[i][kk]);
+        };
+        // the compute half of a phase: barrier | the fragments have arrived | 16 MFMA at raised priority | barrier
+        auto compute = [&](auto hxc, auto hwc, bool reads) __attribute__((always_inline)) {
+            fence();
+            bar();
+            if (reads) lgkm0();
+            fence();
+            if constexpr (MI355X_G8_PRIO != 0) __builtin_amdgcn_s_setprio(1);
+            mma_q(hxc, hwc);
+            if constexpr (MI355X_G8_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+            fence();
+            bar();
+            fence();
+        };
+
+        // ---- prologue: K tile 0 completely, three half tiles of K tile 1 ----
+        enter_x(x_seg, x_kb);
+        enter_w(w_seg, w_kb);
+        stage_w(0, 0);
+        stage_x(0, 0);
+        stage_w(1, 0);
+        adv_w();
+        stage_x(1, 0);
+        adv_x();
+        if (nk > 1) {
+            stage_w(0, 1);
+            stage_x(0, 1);
             stage_w(1, 1);
             adv_w();
-            wait_vm<6>();
-        } else {
-            wait_vm0();
         }
-        compute(I1{}, I0{}, false);
-    };
-    int t = 0;
-    for (; t + 3 < nk; t += 2) trip(std::false_type{}, t);
-    for (; t < nk; t += 2) trip(std::true_type{}, t);
-    if (wm == 0) bar();  // (balances the extra barrier of the second half)
+        if (p.ln_stats && owner) ln_rowstat<BM, NTHR>(p, m0, tid, rowstat);
+        if (nk > 1) wait_vm<6>();
+        else wait_vm0();
+        fence();
+        bar();
+        if (wm == 1) bar();  // the second half of the workgroup runs one barrier behind the first from here on
+        fence();
 
-    tile_epilogue<T, MT, NT, BM, CONV>(p, acc, rowstat, m0, n0, wm, wn, lane, false, split);
+        // ---- main loop: two K tiles per trip.  GUARD = false: tiles t .. t + 3 exist (no conditions anywhere); true: the last one or two trips ----
+        auto trip = [&](auto guardc, int t) __attribute__((always_inline)) {
+            constexpr bool G = decltype(guardc)::value;
+            const bool e1 = !G || t + 1 < nk, e2 = !G || t + 2 < nk, e3 = !G || t + 3 < nk;
+            // phase 1
+            read_w(0, 0);
+            fence();  // (the four W reads first: lgkmcnt(8) below counts on it)
+            read_x(0, 0);
+            if (e1) stage_x(1, 1);
+            lgkm8();
+            if (e1) adv_x();  // (behind the counted wait: a segment change issues scalar loads, which share lgkmcnt with the LDS reads)
+            compute(I0{}, I0{}, true);
+            // phase 2
+            read_w(1, 0);
+            if (e2) stage_w(0, 0);
+            compute(I0{}, I1{}, true);
+            // phase 3
+            read_x(1, 0);
+            if (e2) stage_x(0, 0);
+            compute(I1{}, I1{}, true);
+            // phase 4
+            if (e2) {
+                stage_w(1, 0);
+                adv_w();
+                wait_vm<6>();
+            } else {
+                wait_vm0();
+            }
+            compute(I1{}, I0{}, false);
+            if (G && !e1) return;
+            // phase 5
+            read_w(0, 1);
+            fence();
+            read_x(0, 1);
+            if (e2) stage_x(1, 0);
+            lgkm8();
+            if (e2) adv_x();
+            compute(I0{}, I0{}, true);
+            // phase 6
+            read_w(1, 1);
+            if (e3) stage_w(0, 1);
+            compute(I0{}, I1{}, true);
+            // phase 7
+            read_x(1, 1);
+            if (e3) stage_x(0, 1);
+            compute(I1{}, I1{}, true);
+            // phase 8
+            if (e3) {
+                stage_w(1, 1);
+                adv_w();
+                wait_vm<6>();
+            } else {
+                wait_vm0();
+            }
+            compute(I1{}, I0{}, false);
+        };
+        int t = 0;
+        for (; t + 3 < nk; t += 2) trip(std::false_type{}, t);
+        for (; t < nk; t += 2) trip(std::true_type{}, t);
+        if (wm == 0) bar();  // (balances the extra barrier of the second half: every wave is past its last LDS read, every stage has landed)
+        fence();
+
+        // ---- stream-K hand-over.  Slot layout: [workgroup][wave][i][j][lane] float4 -- a wave's 64 lanes write / read 1 KB contiguous ----
+        if (!owner) {
+            // deposit: write-through (sc1) stores, acknowledged (vmcnt(0)) by every wave, barrier, then the flag (guide: "sc1 slab stores ->
+            // every wave s_waitcnt vmcnt(0) -> barrier -> relaxed agent-scope store"; the same hand-off form as the in-launch LoRA's t)
+            const rsrc_t srs = make_rsrc(reinterpret_cast<const char*>(p.sk_ws) + (int64_t)bid * (BM * BN * 4), BM * BN * 4);
+            const uint32_t so = (uint32_t)((wid * MT * NT) * 64 + lane) * 16u;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), srs, so + (uint32_t)((i * NT + j) * 1024), 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.sk_flags + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (kfirst > 0) {
+            // collect: workgroups bid - 1, bid - 2, ... hold the K tiles [.., kfirst) of this tile
+            const int64_t U = (int64_t)p.grid0 * nk_tile;
+            int have = kfirst, src = bid;
+            while (have > 0) {
+                --src;
+                const int64_t s0 = U * src / p.sk_g, s1 = U * (src + 1) / p.sk_g;
+                have -= (int)(s1 - (s0 > tbeg ? s0 : tbeg));
+                {   // every wave polls for itself (no cross-wave hand-off); relaxed agent-scope loads bypass the CU's L1
+                    const uint64_t t0 = wall_clock64();
+                    while (__hip_atomic_load(p.sk_flags + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (wall_clock64() - t0 > 200000000ull) {  // 2 s of the 100 MHz clock: a lost workgroup must not hang the GPU; the host finds the error word set
+                            if (lane == 0) __hip_atomic_store(p.sk_flags + p.sk_cap, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                const rsrc_t srs = make_rsrc(reinterpret_cast<const char*>(p.sk_ws) + (int64_t)src * (BM * BN * 4), BM * BN * 4);
+                const uint32_t so = (uint32_t)((wid * MT * NT) * 64 + lane) * 16u;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    f32x4 part[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) part[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, so + (uint32_t)((i * NT + j) * 1024), 0, 16));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] += part[j];
+                }
+            }
+            __syncthreads();  // every wave has seen the flags: clear them for the next launch (the slots are free once the loads above returned)
+            if (tid < bid - src) __hip_atomic_store(p.sk_flags + src + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if constexpr (!CONV) {
+            if (tr) {  // the transposed tile's blocks: 4 x 8 over (activation rows of wave column wn, weight rows of wave row wm)
+                f32x4 at[NT][MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) at[j][i] = acc[i][j];
+                tile_epilogue<T, NT, MT, BM, false, true>(p, at, rowstat, m0, n0, wn, wm, lane, true, 0);
+            } else {
+                tile_epilogue<T, MT, NT, BM, false>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0);
+            }
+        } else {
+            tile_epilogue<T, MT, NT, BM, true>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0);
+        }
+        if (more) {  // another segment follows: nobody may still be reading this tile's row statistics when the next tile's are written
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
 }
 
+extern int g_sk_g;        // probing: number of stream-K / persistent workgroups (0 = one per CU)
+extern int g_g8_persist;  // 1 = launches with more tiles than CUs run as one persistent workgroup per CU
+
 template <typename T, bool CONV>
-int launch_gemm8(const GemmP& p, hipStream_t stream) {
+int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
     constexpr int LDS = 2 * (256 + 256) * 128 + 256 * 8;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kfn = gemm8_kernel<T, CONV>;
     static bool attr_set[64] = {};
+    static int n_cu[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev);
         attr_set[dev] = true;
     }
     GemmP q = p;
@@ -416,27 +543,69 @@ int launch_gemm8(const GemmP& p, hipStream_t stream) {
     q.lora_dbg = 0;
     q.lora_tt = 0;
     q.lp_blocks = 0;
-    const int grid = q.pf_blocks + q.grid0 * (q.ksplit > 1 ? q.ksplit : 1);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, stream, q);
-    if (q.ksplit > 1) {
-        const int rb = ((q.M + 31) / 32) * ((q.N + 63) / 64);
-        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb), dim3(256), 0, stream, q);
+    q.ksplit = 1;
+    q.sk_nk = 0;
+    for (int s = 0; s < q.nseg; ++s) q.sk_nk += q.seg[s].nkb;
+    q.sk_mode = 0;
+    q.sk_g = q.grid0;  // one tile per workgroup
+    int ncu = dev >= 0 && dev < 64 && n_cu[dev] > 0 ? n_cu[dev] : 256;
+    if (g_sk_g > 0) ncu = g_sk_g;
+    if (streamk && q.sk_ws && q.sk_flags && q.grid0 % ncu != 0) {
+        // "stream-K": one persistent workgroup per CU (256 on MI355X; the decomposition -- hence the summation order -- depends on this number only),
+        // fewer when there is less than two K tiles of work for each
+        int G = ncu;
+        const int64_t U = (int64_t)q.grid0 * q.sk_nk;
+        if (U < 2 * (int64_t)G) G = (int)(U / 2 > 0 ? U / 2 : 1);
+        if (G > q.sk_cap) G = q.sk_cap;
+        if (G > 0 && q.grid0 % G != 0) {
+            q.sk_mode = 1;
+            q.sk_g = G;
+            // tile order along the unit axis: workgroup b runs on XCD b % 8; count, for both orders, the operand panels each XCD's L2 has to pull
+            double kx = 0, kw = 0;
+            for (int s = 0; s < q.nseg; ++s) {
+                kw += q.seg[s].nkb;
+                kx += CONV ? (double)q.seg[s].nkb / (q.seg[s].ksize * q.seg[s].ksize) : (double)q.seg[s].nkb;
+            }
+            double best = 0;
+            for (int order = 0; order < 2; ++order) {
+                std::vector<char> seen_m(8 * q.tiles_m, 0), seen_n(8 * q.tiles_n, 0);
+                for (int b = 0; b < G; ++b) {
+                    const int64_t s0 = U * b / G, s1 = U * (b + 1) / G;
+                    for (int64_t t = s0 / q.sk_nk; t <= (s1 - 1) / q.sk_nk; ++t) {
+                        const int tm = order == 0 ? (int)(t / q.tiles_n) : (int)(t % q.tiles_m), tn = order == 0 ? (int)(t % q.tiles_n) : (int)(t / q.tiles_m);
+                        seen_m[(b & 7) * q.tiles_m + tm] = 1;
+                        seen_n[(b & 7) * q.tiles_n + tn] = 1;
+                    }
+                }
+                double cost = 0;
+                for (char c : seen_m) cost += c ? kx : 0;
+                for (char c : seen_n) cost += c ? kw : 0;
+                if (order == 0 || cost < best) {
+                    best = cost;
+                    q.sk_order = order;
+                }
+            }
+        }
     }
+    if (q.sk_mode == 0 && g_g8_persist && q.grid0 > ncu && ncu % 8 == 0) q.sk_g = ncu;  // several whole tiles per workgroup: b, b + ncu, ... (the same XCD each time)
+    const int grid = q.pf_blocks + q.sk_g;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, stream, q);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
 
-// Can this launch run on the 8-phase loop?  (No in-launch LoRA, no transposed column group; every operand below 2 GB: 32-bit buffer offsets
-// with 0x80000000 as the out-of-range marker.)
+// Can this launch run on the 8-phase loop?  (No in-launch LoRA, no split-K workspace protocol, transposed column groups from a multiple of 256; every operand below
+// 2 GB: 32-bit buffer offsets with 0x80000000 as the out-of-range marker.)
 inline bool gemm8_ok(const GemmP& p) {
-    if (p.lora_b || p.out_t) return false;
+    if (p.lora_b || p.ksplit > 1) return false;
+    if (p.out_t && p.nt_begin % 256) return false;  // a tile is either stored row-major or transposed
     for (int s = 0; s < p.nseg; ++s)
         if (p.seg[s].xbytes <= 0 || p.seg[s].wbytes <= 0 || p.seg[s].xbytes >= (1ll << 31) || p.seg[s].wbytes >= (1ll << 31)) return false;
     return true;
 }
 
-int launch_gemm8_f32(const GemmP& p, hipStream_t stream);
-int launch_gemm8_bf16(const GemmP& p, hipStream_t stream);
-int launch_conv8_f32(const GemmP& p, hipStream_t stream);
-int launch_conv8_bf16(const GemmP& p, hipStream_t stream);
+int launch_gemm8_f32(const GemmP& p, hipStream_t stream, bool streamk);
+int launch_gemm8_bf16(const GemmP& p, hipStream_t stream, bool streamk);
+int launch_conv8_f32(const GemmP& p, hipStream_t stream, bool streamk);
+int launch_conv8_bf16(const GemmP& p, hipStream_t stream, bool streamk);
 
 }  // namespace mi355x

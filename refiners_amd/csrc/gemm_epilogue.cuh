@@ -64,7 +64,8 @@ MI_DEV void ln_rowstat(const GemmP& p, int m0, int tid_all, float* rowstat) {
 
 // The tile epilogue.  wm / wn: this wave's position in the workgroup's wave grid; m0 / n0: the tile's origin; tr: transposed tile (workgroup-uniform);
 // split: this workgroup's split-K index.
-template <typename T, int MT, int NT, int BM, bool CONV>
+// TR_ONLY: instantiate the transposed-tile path alone (the caller passes tr = true; block shapes the row-major path has no code for).
+template <typename T, int MT, int NT, int BM, bool CONV, bool TR_ONLY = false>
 MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* rowstat, int m0, int n0, int wm, int wn, int lane, bool tr, int split) {
     constexpr int WME = 16 * MT, WNE = 16 * NT;
     const int g = lane >> 4, c16 = lane & 15;
@@ -122,6 +123,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
         }
     }
 
+    if constexpr (!TR_ONLY) {
     // every lane owns RUN = 4*NT consecutive columns of MT rows
     constexpr int RUN = 4 * NT;
     const int nl = wn * WNE + RUN * g;
@@ -313,6 +315,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                 }
             }
         }
+    }
     }
 }
 

@@ -81,6 +81,12 @@ struct GemmP {
     int pf_blocks, pf_mode;  // pf_mode: 1 = plain loads, 2 = non-temporal loads (L2 evict-first)
     int pn, hm, hn;          // XCD rasterisation: the 8 XCDs own a pm x pn grid of hm x hn-tile regions
     int vec_ok;
+    // the 8-phase loop's work decomposition (gemm8_kernel.cuh): sk_nk K tiles per output tile; sk_g > 0: "stream-K", sk_g persistent workgroups share
+    // tiles x sk_nk units evenly, partial tiles meet in sk_ws ([sk_cap][256 x 256] float32) behind sk_flags ([sk_cap] = 1 while a deposit waits for
+    // its owner, 0 between launches; word sk_cap = error flag); sk_order: tile order along the unit axis (0 row-major, 1 column-major)
+    int sk_g, sk_nk, sk_order, sk_cap, sk_mode;  // sk_mode 0: workgroup b takes the whole tiles b, b + sk_g, ...; 1: stream-K
+    float* sk_ws;
+    int* sk_flags;
 };
 
 // Chan's pairwise update of (count, mean, M2); exact for empty operands.

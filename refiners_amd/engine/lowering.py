@@ -63,6 +63,7 @@ class Lowering:
         self.gn_stats = os.environ.get("REFINERS_AMD_GN_STATS", "1") != "0"
         self._cs_buf: list[Tensor] = []
         self._lsync: Any = None          # native.LoraSync: the epoch word every program of this lowering bumps once per replay
+        self._sk = native.StreamK(device)  # scratch of this lowering's stream-K launches (tile 8): allocated by the first one, shared by all (one stream)
         self._bumped: set[int] = set()   # id() of the op lists that already start with the bump
         self.device, self.dtype = device, dtype
         self.es = 4 if dtype == torch.float32 else 2
@@ -89,8 +90,10 @@ class Lowering:
             self.low.pool = self.low.prologue_pool if self.ops is self.low.prologue else self.low.step_pool
             self.rec = native.recording(self.ops)
             self.rec.__enter__()
+            self.sk_saved = native.set_streamk(self.low._sk)
 
         def __exit__(self, *exc: object) -> None:
+            native.set_streamk(self.sk_saved)
             self.rec.__exit__(*exc)
             self.low._target, self.low.pool = self.saved
 

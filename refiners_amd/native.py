@@ -151,6 +151,9 @@ class GemmArgs(C.Structure):
         ("lora_flags", C.c_void_p),
         ("lora_epoch", C.c_void_p),
         ("colstats_out", C.c_void_p),
+        ("sk_ws", C.c_void_p),
+        ("sk_flags", C.c_void_p),
+        ("sk_slots", C.c_int32),
     ]
 
 
@@ -332,7 +335,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
     lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
-    if lib.mi355x_abi_version() != 6:
+    if lib.mi355x_abi_version() != 7:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")
     _lib = lib
     _lib_path = str(p)
@@ -801,12 +804,65 @@ def _fill_colstats(a: GemmArgs, cs: Optional[Tensor], keep: list) -> None:
     keep.append(cs)
 
 
+class StreamK:
+    """Scratch of the stream-K launches (tile 8; mi355x_gemm_args.sk_ws / sk_flags): 256 slots of 256 KB + the hand-off flags.  Launches on ONE stream
+    share it (a recorded program owns one: Lowering.streamk(); eager calls use one per device); allocated on first use."""
+
+    SLOTS = 256
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.ws: Optional[Tensor] = None
+        self.flags: Optional[Tensor] = None
+
+    def tensors(self) -> tuple[Tensor, Tensor]:
+        if self.ws is None:
+            self.ws = torch.empty(self.SLOTS * 65536, dtype=torch.float32, device=self.device)
+            self.flags = torch.zeros(self.SLOTS + 1, dtype=torch.int32, device=self.device)
+        return self.ws, self.flags
+
+    def check(self) -> None:
+        """Raise if a launch reported a lost deposit (the flags are reset so that later launches start clean)."""
+        if self.flags is not None and int(self.flags[-1].item()) != 0:
+            self.flags.zero_()
+            raise NativeError("mi355x_gemm (stream-K): a workgroup's partial tile never arrived (MI355X_ELAUNCH)")
+
+
+_streamk_current: Optional[StreamK] = None
+_streamk_eager: dict[int, StreamK] = {}
+
+
+def set_streamk(sk: Optional[StreamK]) -> Optional[StreamK]:
+    """Make `sk` the scratch that tile-8 launches made from now on carry (a Lowering installs its own while it records); returns the previous one."""
+    global _streamk_current
+    old, _streamk_current = _streamk_current, sk
+    return old
+
+
+def attach_streamk(a: GemmArgs, sk: StreamK) -> None:
+    w, f = sk.tensors()
+    a.sk_ws, a.sk_flags, a.sk_slots = w.data_ptr(), f.data_ptr(), sk.SLOTS
+    a._sk_keep = sk
+
+
 def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor], stages: int = 0) -> None:
     if tile == 0 and ksplit <= 1:  # no explicit choice: the measured table of this GPU, if it knows the shape
         from .engine import tuning
 
         tile, stages = tuning.lookup(gemm_signature(a), stages)
+    elif ksplit > 1:  # the caller split K for want of tiles: where the table prefers the 8-wave loop (whole tiles or stream-K), that replaces the split
+        from .engine import tuning
+
+        t8, _ = tuning.lookup(gemm_signature(a), 0)
+        if t8 in (7, 8):
+            tile, ksplit, ws = t8, 1, None
     a.tile, a.ksplit, a.stages = tile, ksplit, stages
+    if tile == 8 or os.environ.get("REFINERS_AMD_FORCE_TILE") == "8":
+        sk = _streamk_current
+        if sk is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            sk = _streamk_eager.setdefault(dev.index, StreamK(dev))
+        attach_streamk(a, sk)
     if ksplit > 1:
         assert ws is not None and ws.is_contiguous(), "split-K needs a scratch tensor of ksplit * M * N float32"
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()

@@ -164,7 +164,7 @@ def gemm_vt_case(L, K, Cc, dtype, B=2, seed=40):
 
 
 # ------------------------------------------------------------------------------------------------ conv
-def conv_case(B, Cin, Cout, H, W, dtype, *, ksize=3, stride=1, ups=1, split=0, bias=True, rowbias=False, res=False, seed=50):
+def conv_case(B, Cin, Cout, H, W, dtype, *, ksize=3, stride=1, ups=1, split=0, bias=True, rowbias=False, res=False, seed=50, tile=0):
     x = _rand(B, Cin, H, W, dtype=dtype, seed=seed)
     w = _rand(Cout, Cin, ksize, ksize, dtype=dtype, seed=seed + 1, scale=(Cin * ksize * ksize) ** -0.5)
     b = _rand(Cout, dtype=dtype, seed=seed + 2) if bias else None
@@ -188,7 +188,7 @@ def conv_case(B, Cin, Cout, H, W, dtype, *, ksize=3, stride=1, ups=1, split=0, b
         r = _rand(B * OH * OW, Cout, dtype=dtype, seed=seed + 4)
         ref = ref + r.float().reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
     out = torch.empty(B * OH * OW, Cout, dtype=dtype, device=DEV)
-    native.conv_gemm(segs, out, B, OH, OW, bias=b, rowbias=rb, rows_per_group=OH * OW, res=r)
+    native.conv_gemm(segs, out, B, OH, OW, bias=b, rowbias=rb, rows_per_group=OH * OW, res=r, tile=tile)
     got = out.float().reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
     return _cmp(got, ref, dtype)
 
@@ -591,6 +591,27 @@ def gemm_kgroups_multiseg_case(M, K1, K2, N, dtype, seed=210):
     native.gemm([(x1, w1), (x2, native.KBlocked(w2))], out, tile=6)
     ref = x1.float() @ w1.float().t() + x2.float() @ w2.float().t()
     return _cmp(out, ref, dtype)
+
+
+def gemm_multiseg_case(M, K1, K2, N, dtype, tile, seed=212):
+    """Two K segments (one K-blocked) with an odd total K tile count on a forced tile; bias + residual."""
+    x1, x2 = _rand(M, K1, dtype=dtype, seed=seed), _rand(M, K2, dtype=dtype, seed=seed + 1)
+    w1, w2 = _rand(N, K1, dtype=dtype, seed=seed + 2, scale=(K1 + K2) ** -0.5), _rand(N, K2, dtype=dtype, seed=seed + 3, scale=(K1 + K2) ** -0.5)
+    b, r = _rand(N, dtype=dtype, seed=seed + 4), _rand(M, N, dtype=dtype, seed=seed + 5)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    native.gemm([(x1, w1), (x2, native.KBlocked(w2))], out, bias=b, res=r, tile=tile)
+    ref = x1.float() @ w1.float().t() + x2.float() @ w2.float().t() + b.float() + r.float()
+    return _cmp(out, ref, dtype)
+
+
+def conv_forced_tile_case(dtype, tile, seed=222):
+    """The conv loader's address arithmetic on a forced tile: stride 2, nearest-2x upsampling, and a fused 1x1 shortcut segment (three runs)."""
+    worst = (0.0, 1e-6, _tol(dtype))
+    for kw in ({"stride": 2}, {"ups": 2}, {"split": 640, "rowbias": True, "res": True}):
+        e = conv_case(1, 960 if "split" in kw else 320, 320, 16, 16, dtype, seed=seed, tile=tile, **kw)
+        if e[0] / e[1] > worst[0] / worst[1]:
+            worst = e
+    return worst
 
 
 def conv_tile_case(B, Cin, Cout, H, W, dtype, tile, stages, ksplit=1, seed=220):
@@ -1067,5 +1088,34 @@ def all_cases():
             (f"softmax_rows_{tag}_unaligned", lambda dt=dt: softmax_rows_case(5, 77, 77, dt)),
             (f"softmax_rows_{tag}_long", lambda dt=dt: softmax_rows_case(3, 20000, 20032, dt)),
             (f"gemm_{tag}_ln_chain_transposed", lambda dt=dt: gemm_ln_chain_case(1024, 1280, 1280, dt, transposed=True)),
+        ]
+        # round 5: the 8-wave / eight-phase loop (csrc/gemm8_kernel.cuh) -- tile 7 = whole 256 x 256 tiles per workgroup (persistent when there are more
+        # tiles than CUs), tile 8 = stream-K (partial tiles summed in a fixed order through the scratch of native.StreamK).  K tile counts around the
+        # loop's peel points (1 .. 5, odd / even), ragged M / N, every epilogue, transposed column groups, K-blocked operands, several K segments, conv.
+        kt = 128 // (4 if dt == torch.float32 else 2)  # elements per K tile
+        for tile in (7, 8):
+            for nkt in (1, 2, 3, 4, 5, 8):
+                cases.append((f"gemm_{tag}_tile{tile}_{nkt}ktiles", lambda dt=dt, tile=tile, nkt=nkt, kt=kt: gemm_tile_case(300, nkt * kt, 520, dt, tile, 0, seed=400 + nkt)))
+            cases += [
+                (f"gemm_{tag}_tile{tile}_2048x1280x1280_prefetch", lambda dt=dt, tile=tile: gemm_tile_case(2048, 1280, 1280, dt, tile, 0, prefetch=True)),
+                (f"gemm_{tag}_tile{tile}_many_tiles", lambda dt=dt, tile=tile: gemm_tile_case(4352, 256, 4608, dt, tile, 0, seed=410)),  # 17 x 18 = 306 tiles: more than CUs
+                (f"gemm_{tag}_tile{tile}_long_k_few_tiles", lambda dt=dt, tile=tile: gemm_tile_case(512, 5120, 768, dt, tile, 0, seed=411)),
+                (f"gemm_{tag}_tile{tile}_two_segments", lambda dt=dt, tile=tile: gemm_multiseg_case(600, 640, 320 + 64, 520, dt, tile)),
+                (f"gemm_{tag}_tile{tile}_geglu", lambda dt=dt, tile=tile: gemm_geglu_case(1024, 640, 2560, dt, tile=tile)),
+                (f"gemm_{tag}_tile{tile}_qkv", lambda dt=dt, tile=tile: gemm_qkv_case(1000, 640, 640, dt, tile=tile, bias=True, pad=32, seed=431)),
+                (f"gemm_{tag}_tile{tile}_qkv_2048x1280", lambda dt=dt, tile=tile: gemm_qkv_case(2048, 1280, 1280, dt, tile=tile)),
+                (f"gemm_{tag}_tile{tile}_t_only_ragged", lambda dt=dt, tile=tile: gemm_t_only_case(77 * 2, 2048, 640, dt, tile=tile)),
+                (f"gemm_{tag}_tile{tile}_ln_chain", lambda dt=dt, tile=tile: gemm_ln_chain_case(1000, 640, 640, dt, tile1=tile, tile2=tile)),
+                (f"gemm_{tag}_tile{tile}_ln_chain_geglu", lambda dt=dt, tile=tile: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile1=1, tile2=tile)),
+                (f"gemm_{tag}_tile{tile}_ln_chain_transposed", lambda dt=dt, tile=tile: gemm_ln_chain_case(1024, 1280, 1280, dt, transposed=True, tile1=tile, tile2=tile)),
+                (f"colstats_{tag}_tile{tile}", lambda dt=dt, tile=tile: colstats_case(600, 384, 640, dt, tile=tile)),
+                (f"colstats_{tag}_tile{tile}_edge_rows", lambda dt=dt, tile=tile: colstats_case(96, 256, 320, dt, tile=tile)),
+                (f"conv_{tag}_tile{tile}", lambda dt=dt, tile=tile: conv_tile_case(2, 320, 384, 16, 24, dt, tile, 0)),
+                (f"conv_{tag}_tile{tile}_odd_taps", lambda dt=dt, tile=tile: conv_tile_case(1, 64, 320, 40, 24, dt, tile, 0, seed=221)),
+                (f"conv_gn_{tag}_tile{tile}", lambda dt=dt, tile=tile: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt, tile=tile)),
+            ]
+        cases += [
+            (f"conv_{tag}_tile7_s2_ups_shortcut", lambda dt=dt: conv_forced_tile_case(dt, 7)),
+            (f"conv_{tag}_tile8_s2_ups_shortcut", lambda dt=dt: conv_forced_tile_case(dt, 8)),
         ]
     return cases

@@ -36,7 +36,7 @@ def test_library_exports_every_symbol_of_the_header():
     lib = native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mi355x_abi_version() == 6
+    assert lib.mi355x_abi_version() == 7
 
 
 def _dry(unet, B, H, W, dtype, tokens, pooled=True, conditions=(), condition_rows=None):

@@ -33,8 +33,12 @@ def step_ms(ops, iters: int = 4, reps: int = 3) -> float:
     return statistics.median(vals)
 
 
-def candidates(a) -> list[tuple[int, int]]:
+def candidates(a, only=None) -> list[tuple[int, int]]:
     out = []
+    if not a.lora_b and not (a.out_t and a.nt_begin % 256):  # the 8-wave / eight-phase loop: 7 = whole 256 x 256 tiles, 8 = stream-K
+        out += [(7, 0), (8, 0)]
+    if a.ksplit > 1:  # a launch the lowering split along K: only the 8-wave loop (which takes the whole K) is an alternative
+        return [c for c in out if only is None or c[0] in only]
     for tile in (1, 2, 3, 4, 6):  # 128x128, 128x64, 64x128, 64x64 (4 waves); 6 = 128x128 with two K groups (8 waves)
         if a.geglu == 1 and tile in (2, 4):
             continue
@@ -44,7 +48,7 @@ def candidates(a) -> list[tuple[int, int]]:
             continue
         for st in ((2,) if tile == 6 or a.lora_b else (2, 3, 4)):
             out.append((tile, st))
-    return out
+    return [c for c in out if only is None or c[0] in only]
 
 
 def main() -> None:
@@ -56,8 +60,10 @@ def main() -> None:
     ap.add_argument("--merge", action="store_true", help="keep the entries of an existing table for shapes this run does not see")
     ap.add_argument("--min-share", type=float, default=0.004, help="classes below this share of the step are tuned on their own replay")
     ap.add_argument("--budget-s", type=float, default=420.0)
+    ap.add_argument("--tiles", default="", help="comma-separated tile ids to try (default: all legal ones)")
     args = ap.parse_args()
 
+    only = {int(t) for t in args.tiles.split(",")} if args.tiles else None
     tuning.enabled = False  # start from the library heuristic
     dev = torch.device("cuda", 0)
     native.load()
@@ -93,12 +99,20 @@ def main() -> None:
         if not whole and own[sig] < 0.02:
             continue
         start = (int(a0.tile), int(a0.stages))
+        ks0 = int(a0.ksplit)
         results = {}
-        for tile, st in [(0, 0)] + candidates(a0):
-            if a0.ksplit > 1 and tile == 0:
-                tile, st = start  # conv launches the lowering split along K carry an explicit tile
+
+        def apply(tile, st):
             for a in items:
                 a.tile, a.stages = tile, st
+                a.ksplit = 1 if tile in (7, 8) else ks0
+                if tile == 8:
+                    native.attach_streamk(a, pipe.engine.low._sk)
+
+        for tile, st in [(0, 0)] + candidates(a0, only):
+            if ks0 > 1 and tile == 0:
+                tile, st = start  # conv launches the lowering split along K carry an explicit tile
+            apply(tile, st)
             try:
                 t = step_ms(ops, iters=3, reps=3) if whole else bench.time_ops(sub, iters=5) * 1e3
             except Exception as exc:  # noqa: BLE001 -- a refused configuration
@@ -111,11 +125,9 @@ def main() -> None:
         thresh = 0.0015 * base if whole else 0.03 * results[ref_key]
         if best != ref_key and gain > thresh:
             # confirm against the reference once more (noise guard)
-            for a in items:
-                a.tile, a.stages = ref_key if ref_key != (0, 0) else (0, 0)
+            apply(*ref_key)
             t_ref = step_ms(ops, iters=3, reps=3) if whole else bench.time_ops(sub, iters=5) * 1e3
-            for a in items:
-                a.tile, a.stages = best
+            apply(*best)
             t_best = step_ms(ops, iters=3, reps=3) if whole else bench.time_ops(sub, iters=5) * 1e3
             if t_ref - t_best > thresh * 0.5:
                 choices[sig] = [best[0], best[1]]
@@ -124,8 +136,7 @@ def main() -> None:
                 best = ref_key
         else:
             best = ref_key
-        for a in items:
-            a.tile, a.stages = best
+        apply(*best)
         row = {"class": sig, "launches": len(items), "own_ms": round(own[sig], 4), "mode": "whole-step" if whole else "class-only", "kept": list(best),
                "ms": {f"{k[0]}/{k[1]}": round(v, 4) for k, v in sorted(results.items(), key=lambda kv: kv[1])[:6]}}
         log.append(row)

@@ -22,7 +22,7 @@ def set_tile(v, st=0):
 def main():
     shapes = [("FF1", 2048, 1280, 10240, True), ("QKV", 2048, 1280, 3840, False), ("FF2", 2048, 5120, 1280, False), ("proj", 2048, 1280, 1280, False),
               ("FF1x4", 8192, 1280, 10240, True), ("QKVx4", 8192, 1280, 3840, False), ("640", 8192, 640, 640, False), ("4096^3", 4096, 4096, 4096, False)]
-    tiles = [(0, 0), (1, 2), (3, 2), (4, 2), (7, 0)]
+    tiles = [(0, 0), (1, 2), (4, 2), (7, 0), (8, 0)]
     for name, M, K, N, geglu in shapes:
         sets = []
         for _ in range(6):
@@ -35,16 +35,15 @@ def main():
             for t in tiles:
                 if geglu and t[0] in (2, 4):
                     continue
-                set_tile(*t)
                 try:
                     for x, w, o in sets:
-                        native.gemm([(x, w)], o, geglu=geglu)
+                        native.gemm([(x, w)], o, geglu=geglu, tile=t[0], stages=t[1])
                     torch.cuda.synchronize()
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
                     for _ in range(5):
                         for x, w, o in sets:
-                            native.gemm([(x, w)], o, geglu=geglu)
+                            native.gemm([(x, w)], o, geglu=geglu, tile=t[0], stages=t[1])
                     b.record()
                     torch.cuda.synchronize()
                     res[t].append(a.elapsed_time(b) / 30 * 1e3)
