@@ -141,5 +141,9 @@ template <typename T> MI_DEV Vec16<T> load16(const T* p) {
     return r;
 }
 template <typename T> MI_DEV void store16(T* p, const Vec16<T>& x) {
+#ifdef MI355X_ABL_NOSTORE  // probing builds only: the value is computed, nothing is written
+    asm volatile("" ::"v"(x.v), "v"(p));
+#else
     *reinterpret_cast<decltype(x.v)*>(p) = x.v;
+#endif
 }

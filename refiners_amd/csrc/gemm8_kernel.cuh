@@ -94,6 +94,9 @@ template <int NTHR_ALL> MI_DEV void prefetch_role(const GemmP& p, int tid_all) {
     if (acc == 0x5a5a1234 && p.pf_bytes[0] < 0) *reinterpret_cast<int*>(p.out) = acc;  // never taken: keeps the loads alive
 }
 
+#ifndef MI355X_G8_ABL
+#define MI355X_G8_ABL 0  // probing builds only (results are wrong): bit 0 = no tile epilogue (the accumulators are kept alive, nothing is stored)
+#endif
 #ifndef MI355X_G8_PRIO
 #define MI355X_G8_PRIO 1  // s_setprio 1 around every MFMA cluster (guide T5: +21..39 % on this schedule)
 #endif
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     constexpr uint32_t OOB = 0x80000000u;                  // per-lane offset beyond every descriptor's num_records: the load writes zeros
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* rowstat = reinterpret_cast<float*>(smem + 2 * BUFB);  // [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer)
+    float* colvec = rowstat + 2 * BM;                            // [2][BN]: the tile's bias (as float32) or folded-LayerNorm s | c, staged for the epilogue
 
     const int tid0 = threadIdx.x, wid = wave_id();
     const int wm = wid >> 2, wn = wid & 3;
@@ -138,7 +142,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     auto lgkm0 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     auto lgkm8 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); };
 
+    int ts_n = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr ((MI355X_G8_ABL & 4) != 0) {
+            if (bid == 0 && tid0 == 0 && p.sk_ws && ts_n < 256) reinterpret_cast<uint64_t*>(p.sk_ws)[ts_n] = wall_clock64();
+            ++ts_n;
+        }
+    };
     while (true) {
+        stamp();  // (0) segment start
         // (the thread id goes through an opaque move once per segment: nothing derived from it -- epilogue addresses, hand-over offsets -- can be
         //  hoisted out of this loop and kept in registers through the K loop, which has none to spare)
         int tid = tid0;
@@ -383,8 +395,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             adv_w();
         }
         if (p.ln_stats && owner) ln_rowstat<BM, NTHR>(p, m0, tid, rowstat);
+        if (owner && tid < BN && (p.ln_stats || p.bias)) {  // per-column vectors of the tile -> LDS (read by the epilogue: see tile_epilogue's colvec)
+            const int n = min(n0 + tid, p.N - 1);
+            if (p.ln_stats) {
+                colvec[tid] = p.ln_s[n];
+                colvec[BN + tid] = p.ln_c[n];
+            } else {
+                colvec[tid] = to_f32(reinterpret_cast<const T*>(p.bias)[n]);
+            }
+        }
         if (nk > 1) wait_vm<6>();
         else wait_vm0();
+        stamp();  // (1) first K tile landed
         fence();
         bar();
         if (wm == 1) bar();  // the second half of the workgroup runs one barrier behind the first from here on
@@ -451,6 +473,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         for (; t < nk; t += 2) trip(std::true_type{}, t);
         if (wm == 0) bar();  // (balances the extra barrier of the second half: every wave is past its last LDS read, every stage has landed)
         fence();
+        // Every LDS-DMA has landed (the last trip waited vmcnt(0) in inline asm, which the compiler's wait-count pass does not parse).  Say so in a form
+        // it does: otherwise it still believes LDS-DMA writes are pending and puts `s_waitcnt vmcnt(0)` in front of every LDS read of the epilogue
+        // (row statistics, staged column vectors) -- and vmcnt counts the previous row's STORES: 8 store round trips per tile, 8 us
+        // (profiles/r05_h_probe_g8_stamps.log).
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+        stamp();  // (2) K loop done
 
         // ---- stream-K hand-over.  Slot layout: [workgroup][wave][i][j][lane] float4 -- a wave's 64 lanes write / read 1 KB contiguous ----
         if (!owner) {
@@ -500,20 +528,26 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             __syncthreads();  // every wave has seen the flags: clear them for the next launch (the slots are free once the loads above returned)
             if (tid < bid - src) __hip_atomic_store(p.sk_flags + src + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if constexpr (!CONV) {
+        if constexpr ((MI355X_G8_ABL & 1) != 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else if constexpr (!CONV) {
             if (tr) {  // the transposed tile's blocks: 4 x 8 over (activation rows of wave column wn, weight rows of wave row wm)
                 f32x4 at[NT][MT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) at[j][i] = acc[i][j];
-                tile_epilogue<T, NT, MT, BM, false, true>(p, at, rowstat, m0, n0, wn, wm, lane, true, 0);
+                tile_epilogue<T, NT, MT, BM, false, true>(p, at, rowstat, m0, n0, wn, wm, lane, true, 0, colvec);
             } else {
-                tile_epilogue<T, MT, NT, BM, false>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0);
+                tile_epilogue<T, MT, NT, BM, false>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0, colvec);
             }
         } else {
-            tile_epilogue<T, MT, NT, BM, true>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0);
+            tile_epilogue<T, MT, NT, BM, true>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0, colvec);
         }
+        stamp();  // (3) epilogue issued
         if (more) {  // another segment follows: nobody may still be reading this tile's row statistics when the next tile's are written
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -526,7 +560,7 @@ extern int g_g8_persist;  // 1 = launches with more tiles than CUs run as one pe
 
 template <typename T, bool CONV>
 int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
-    constexpr int LDS = 2 * (256 + 256) * 128 + 256 * 8;
+    constexpr int LDS = 2 * (256 + 256) * 128 + 256 * 8 + 2 * 256 * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kfn = gemm8_kernel<T, CONV>;
     static bool attr_set[64] = {};

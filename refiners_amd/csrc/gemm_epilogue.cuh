@@ -7,6 +7,13 @@
 #pragma once
 #include "gemm_params.cuh"
 
+// probing builds (-DMI355X_EPI_LEAN): the row-major tile epilogue with every optional part compiled out (bias + store only)
+#ifdef MI355X_EPI_LEAN
+#define EPIF(x) (false)
+#else
+#define EPIF(x) (x)
+#endif
+
 namespace mi355x {
 
 // (mean, rstd) of the tile's BM rows -> rowstat[BM][2] in LDS, from the producer launch's 32-column (mean, M2) partials: TPR threads per row,
@@ -66,7 +73,9 @@ MI_DEV void ln_rowstat(const GemmP& p, int m0, int tid_all, float* rowstat) {
 // split: this workgroup's split-K index.
 // TR_ONLY: instantiate the transposed-tile path alone (the caller passes tr = true; block shapes the row-major path has no code for).
 template <typename T, int MT, int NT, int BM, bool CONV, bool TR_ONLY = false>
-MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* rowstat, int m0, int n0, int wm, int wn, int lane, bool tr, int split) {
+// colvec (LDS, or null): the tile's per-column vectors staged by the caller, [0, BN): the bias as float32 or the folded LayerNorm's s, [BN, 2 BN): its c (BN = 256);
+// a workgroup that owns its CU alone reads them from there: a global load issued behind a row's stores waits for the stores (vmcnt is in order and counts them).
+MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* rowstat, int m0, int n0, int wm, int wn, int lane, bool tr, int split, const float* colvec = nullptr) {
     constexpr int WME = 16 * MT, WNE = 16 * NT;
     const int g = lane >> 4, c16 = lane & 15;
     // ---- epilogue ----
@@ -93,14 +102,18 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];
                 if (p.ln_stats) {
-                    const float s = p.ln_s[n], c = p.ln_c[n];
+                    float s, c;  // (two separate loads, not one load through a selected pointer: that would be a FLAT load, which waits on vmcnt)
+                    if (colvec) s = colvec[n - n0], c = colvec[256 + n - n0];
+                    else s = p.ln_s[n], c = p.ln_c[n];
 #pragma unroll
                     for (int e = 0; e < RUN_T; ++e) {
                         const int row = min(wm * WME + RUN_T * g + e, BM - 1);
                         v[e] = rowstat[2 * row + 1] * (v[e] - rowstat[2 * row] * s) + c;
                     }
                 } else if (bias) {
-                    const float b = to_f32(bias[n]);
+                    float b;
+                    if (colvec) b = colvec[n - n0];
+                    else b = to_f32(bias[n]);
 #pragma unroll
                     for (int e = 0; e < RUN_T; ++e) v[e] += b;
                 }
@@ -129,7 +142,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
     const int nl = wn * WNE + RUN * g;
     const int n = n0 + nl;
     const bool full = p.vec_ok && (n + RUN <= p.N);
-    if (p.ksplit > 1) {  // split-K: raw float32 partial sums; bias / residual / conversion happen in splitk_reduce_kernel
+    if (EPIF(p.ksplit > 1)) {  // split-K: raw float32 partial sums; bias / residual / conversion happen in splitk_reduce_kernel
         float* part = p.partial + (int64_t)split * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -155,30 +168,41 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
         // rows beyond M keep going through the arithmetic when statistics are produced (the shuffles below need all lanes);
         // their stores are suppressed
         const bool mok = m < p.M;
-        if (!mok && !p.stats_out && !p.colstats) continue;
+        if (!mok && !EPIF(p.stats_out) && !EPIF(p.colstats)) continue;
         float v[RUN];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
         if (full) {
-            if (p.ln_stats) {  // y = rstd * (acc - mean * s[n]) + c[n]   (c carries the Linear's bias)
+            if (EPIF(p.ln_stats)) {  // y = rstd * (acc - mean * s[n]) + c[n]   (c carries the Linear's bias)
                 const float mean = rowstat[2 * mrow], rstd = rowstat[2 * mrow + 1];
 #pragma unroll
                 for (int c = 0; c < RUN / 4; ++c) {
-                    const f32x4 sv = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4 * c), cv = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * c);
+                    f32x4 sv, cv;
+                    if (colvec) sv = *reinterpret_cast<const f32x4*>(colvec + nl + 4 * c), cv = *reinterpret_cast<const f32x4*>(colvec + 256 + nl + 4 * c);
+                    else sv = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4 * c), cv = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * c + e] = rstd * (v[4 * c + e] - mean * sv[e]) + cv[e];
                 }
             } else if (bias) {
+                if (colvec) {
 #pragma unroll
-                for (int c = 0; c < RUN / EPC; ++c) {
-                    Vec16<T> bv = load16<T>(bias + n + c * EPC);
+                    for (int c = 0; c < RUN / 4; ++c) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(colvec + nl + 4 * c);
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
+                        for (int e = 0; e < 4; ++e) v[4 * c + e] += bv[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < RUN / EPC; ++c) {
+                        Vec16<T> bv = load16<T>(bias + n + c * EPC);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
+                    }
                 }
             }
-            if (rowbias && mok) {
+            if (EPIF(rowbias) && mok) {
                 const T* rb = rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n;
 #pragma unroll
                 for (int c = 0; c < RUN / EPC; ++c) {
@@ -187,11 +211,11 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                     for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
                 }
             }
-            if (p.gelu) {
+            if (EPIF(p.gelu)) {
 #pragma unroll
                 for (int e = 0; e < RUN; ++e) v[e] = p.gelu == 1 ? gelu_exact(v[e]) : quick_gelu(v[e]);
             }
-            if (p.geglu) {
+            if (EPIF(p.geglu)) {
                 if constexpr (NT == 4) {
                     constexpr int HR = RUN / 2;
                     const int no = (n0 + wn * WNE) / 2 + HR * g;
@@ -218,7 +242,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                     }
                 }
             } else {
-                if (res && mok) {
+                if (EPIF(res) && mok) {
                     const T* rp = res + (int64_t)m * p.ldres + n;
 #pragma unroll
                     for (int c = 0; c < RUN / EPC; ++c) {
@@ -227,7 +251,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                         for (int e = 0; e < EPC; ++e) v[c * EPC + e] += rv.get(e);
                     }
                 }
-                if (p.out_f32) {
+                if (EPIF(p.out_f32)) {
                     if (mok) {
                         float* of = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
 #pragma unroll
@@ -243,7 +267,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
                     if (mok) store16<T>(op + c * EPC, ov);
-                    if (p.stats_out || p.colstats) {
+                    if (EPIF(p.stats_out || p.colstats)) {
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) {
                             v[c * EPC + e] = ov.get(e);
@@ -251,7 +275,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                         }
                     }
                 }
-                if (p.colstats) {
+                if (EPIF(p.colstats)) {
                     // GroupNorm statistics for the consumer of this tensor: (sum, sum of squares) per column over each 32-row block = the two
                     // 16-row MMA blocks 2h, 2h + 1 of this wave (i even: remember the row, i odd: add, reduce over the 16 lanes, store)
                     if ((i & 1) == 0) {
@@ -274,7 +298,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                         }
                     }
                 }
-                if (p.stats_out) {
+                if (EPIF(p.stats_out)) {
                     // (mean, M2) of this lane's RUN columns, Chan-merged over the lane groups that share a 32-column chunk:
                     // RUN = 16 -> groups (g, g^1); RUN = 8 -> all four groups.  Lower group first on both sides: identical bits.
                     float mean = rs * (1.0f / RUN), m2 = 0.f, cn = (float)RUN;

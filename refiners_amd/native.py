@@ -293,7 +293,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     global _lib, _lib_path
     if _lib is not None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("REFINERS_AMD_LIB") or LIB_PATH)  # (REFINERS_AMD_LIB: an experiment build, tools only)
     if not p.exists():
         raise NativeError(
             f"{p} is missing: build it with `python -m refiners_amd.build_native` (or __graft_entry__.build()). "
