@@ -119,7 +119,7 @@ def main() -> None:
                 t = float("inf")
                 print(f"   {sig}: tile {tile} stages {st} refused: {exc}")
             results[(tile, st)] = t
-        ref_key = start if a0.ksplit > 1 else (0, 0)
+        ref_key = start if ks0 > 1 else (0, 0)
         best = min(results, key=results.get)
         gain = results[ref_key] - results[best]
         thresh = 0.0015 * base if whole else 0.03 * results[ref_key]

@@ -40,6 +40,9 @@ def family(kernel: str) -> str | None:
     m = re.search(r"gemm_kernelI\w+?Li\d+ELi\d+ELi\d+ELi\d+ELb([01])E", kernel)
     if m:
         return "mi355x_gemm(conv)" if m.group(1) == "1" else "mi355x_gemm"
+    m = re.search(r"gemm8_kernelI\w+?Lb([01])E", kernel)  # the 8-wave / eight-phase loop (csrc/gemm8_kernel.cuh)
+    if m:
+        return "mi355x_gemm(conv)" if m.group(1) == "1" else "mi355x_gemm"
     if "splitk_reduce_kernel" in kernel:
         return "mi355x_gemm(conv)"
     if "attn_kernel" in kernel or "attn_general_kernel" in kernel:
@@ -92,7 +95,7 @@ def step_map(rows: list[tuple], program: list[dict], max_steps: int = 4) -> list
             n = st[i][0]
             take = 1
             if what.startswith("mi355x_gemm"):
-                if "gemm_kernel" not in n:
+                if "gemm_kernel" not in n and "gemm8_kernel" not in n:
                     ok = False
                     break
                 if i + 1 < len(st) and "splitk_reduce_kernel" in st[i + 1][0] and ent.get("ksplit", 1) > 1:
@@ -187,6 +190,55 @@ def pmc_families(db: str, program: list[dict] | None = None) -> dict:
     return {"scope": scope, "families": fams, "classes": classes, "kernels": kernels}
 
 
+def traffic_micro(tag: str, prof: Path) -> None:
+    """FETCH_SIZE / WRITE_SIZE of the dominant shape classes from tools/probe_traffic.py (a few dozen dispatches instead of a whole bench run): the
+    fallback when the counter passes over the step die in the profiler.  Writes <tag>_pmc_traffic.json in the schema bench.py reads."""
+    res: dict[str, list] = {}
+    classes = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = prof / f"micro_{counter}"
+        for attempt in range(3):
+            rc = run(["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", str(d), "--", sys.executable, str(ROOT / "tools" / "probe_traffic.py")], prof / f"micro_{counter}.log")
+            if rc == 0:
+                break
+        print("traffic micro-program", counter, "rc", rc)
+        db = find_db(d)
+        if rc != 0 or not db:
+            return
+        for ln in (prof / f"micro_{counter}.log").read_text(errors="replace").splitlines():
+            if ln.startswith("TRAFFIC_PROGRAM "):
+                classes = json.loads(ln[len("TRAFFIC_PROGRAM "):])
+        con = sqlite3.connect(db)
+        per: dict[int, list] = {}
+        for did, name, start, val in con.execute("select dispatch_id, name, min(start), sum(counter_value) from pmc_events where counter_name = ? group by dispatch_id", (counter,)):
+            per[did] = [name, start, val]
+        rows = [r for r in sorted(per.values(), key=lambda r: r[1]) if "gemm_kernel" in r[0] or "gemm8_kernel" in r[0]]
+        res[counter] = rows
+    if not classes or sum(c["launches"] for c in classes) != len(res["FETCH_SIZE"]) or len(res["FETCH_SIZE"]) != len(res["WRITE_SIZE"]):
+        print("traffic micro-program: dispatch count mismatch", None if not classes else sum(c["launches"] for c in classes), {k: len(v) for k, v in res.items()})
+        return
+    out_cls, i = {}, 0
+    fam = {"mi355x_gemm": {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}, "mi355x_gemm(conv)": {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}}
+    for c in classes:
+        n = c["launches"]
+        f = sum(r[2] for r in res["FETCH_SIZE"][i : i + n]) / n * 1024 * 2  # KiB, doubled (MI355X_MICROARCH.md, HBM section)
+        w = sum(r[2] for r in res["WRITE_SIZE"][i : i + n]) / n * 1024
+        i += n
+        out_cls[c["class"]] = {"FETCH_SIZE": {"launches": n, "bytes_per_launch": f}, "WRITE_SIZE": {"launches": n, "bytes_per_launch": w}, "algorithmic_bytes": c["algorithmic_bytes"],
+                               "fetched_plus_written_over_algorithmic": (f + w) / c["algorithmic_bytes"], "launches_per_step": c["per_step"]}
+        fk = "mi355x_gemm(conv)" if c["class"].startswith("conv") else "mi355x_gemm"
+        for counter, v in (("FETCH_SIZE", f), ("WRITE_SIZE", w)):
+            fam[fk][counter][0] += v * c["per_step"]
+            fam[fk][counter][1] += c["per_step"]
+    fams = {fk: {counter: {"dispatches": tot[1], "bytes_per_launch": tot[0] / max(tot[1], 1)} for counter, tot in cs.items()} for fk, cs in fam.items()}
+    (OUT / f"{tag}_pmc_traffic.json").write_text(json.dumps({
+        "how": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python tools/probe_traffic.py (one pass per counter): the dominant shape classes of the step, "
+               "6 launches each on fresh operands, outside the step (cold operands: an upper bound for the in-place traffic)",
+        "scope": "micro-program per shape class (the counter passes over the whole step died in the profiler); families = the classes weighted by their launches per step",
+        "units": "counter values are KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)", "families": fams, "classes": out_cls}, indent=1))
+    print({k: round(v["fetched_plus_written_over_algorithmic"], 2) for k, v in out_cls.items()})
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
@@ -263,6 +315,8 @@ def main() -> None:
             cls[k] = row
         (OUT / f"{tag}_pmc_traffic.json").write_text(json.dumps({"how": how, "scope": scope, "units": "counter values are KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); families: per KERNEL dispatch (GroupNorm: per kernel, not per call); classes: per program launch (all its kernels)", "families": fams, "classes": cls}, indent=1))
         print({f: {c: round(v["bytes_per_launch"] / 1e6, 2) for c, v in cs.items()} for f, cs in fams.items()})
+    if not ("fetch" in got and "write" in got) and ("fetch" in passes or "write" in passes):
+        traffic_micro(tag, prof)
     # calibration of the MFMA-busy counter on a launch whose MFMA count is known exactly (tools/probe_mfma_cal.py)
     cal = None
     rc = run(["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace", "-d", str(prof / "cal"), "--", sys.executable, str(ROOT / "tools" / "probe_mfma_cal.py")], prof / "cal.log")
