@@ -542,10 +542,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
                     for (int j = 0; j < NT; ++j) at[j][i] = acc[i][j];
                 tile_epilogue<T, NT, MT, BM, false, true>(p, at, rowstat, m0, n0, wn, wm, lane, true, 0, colvec);
             } else {
-                tile_epilogue<T, MT, NT, BM, false>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0, colvec);
+                tile_epilogue<T, MT, NT, BM, false, false, true>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0, colvec);
             }
         } else {
-            tile_epilogue<T, MT, NT, BM, true>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0, colvec);
+            tile_epilogue<T, MT, NT, BM, true, false, true>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0, colvec);
         }
         stamp();  // (3) epilogue issued
         if (more) {  // another segment follows: nobody may still be reading this tile's row statistics when the next tile's are written
@@ -630,7 +630,7 @@ int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
 // Can this launch run on the 8-phase loop?  (No in-launch LoRA, no split-K workspace protocol, transposed column groups from a multiple of 256; every operand below
 // 2 GB: 32-bit buffer offsets with 0x80000000 as the out-of-range marker.)
 inline bool gemm8_ok(const GemmP& p) {
-    if (p.lora_b || p.ksplit > 1) return false;
+    if (p.lora_b || p.ksplit > 1 || !p.vec_ok || p.N % 16) return false;  // (the epilogue instances of this loop are the vectorised ones)
     if (p.out_t && p.nt_begin % 256) return false;  // a tile is either stored row-major or transposed
     for (int s = 0; s < p.nseg; ++s)
         if (p.seg[s].xbytes <= 0 || p.seg[s].wbytes <= 0 || p.seg[s].xbytes >= (1ll << 31) || p.seg[s].wbytes >= (1ll << 31)) return false;

@@ -7,12 +7,10 @@
 #pragma once
 #include "gemm_params.cuh"
 
-// probing builds (-DMI355X_EPI_LEAN): the row-major tile epilogue with every optional part compiled out (bias + store only)
-#ifdef MI355X_EPI_LEAN
-#define EPIF(x) (false)
-#else
-#define EPIF(x) (x)
-#endif
+// The optional parts of the row-major tile epilogue, as bits of the instance `rows<F>` that a launch runs (tile_epilogue, FAST): a part whose bit is
+// missing from F is compiled out of that instance, so a launch's rows run straight-line code for exactly its kind of epilogue.
+enum : unsigned { EPI_LN = 1, EPI_RB = 2, EPI_GELU = 4, EPI_GEGLU = 8, EPI_RES = 16, EPI_F32 = 32, EPI_ST = 64, EPI_CS = 128, EPI_ALL = 255 };
+#define EPIF(bit, x) (((F) & (bit)) != 0 && (x))
 
 namespace mi355x {
 
@@ -72,7 +70,8 @@ MI_DEV void ln_rowstat(const GemmP& p, int m0, int tid_all, float* rowstat) {
 // The tile epilogue.  wm / wn: this wave's position in the workgroup's wave grid; m0 / n0: the tile's origin; tr: transposed tile (workgroup-uniform);
 // split: this workgroup's split-K index.
 // TR_ONLY: instantiate the transposed-tile path alone (the caller passes tr = true; block shapes the row-major path has no code for).
-template <typename T, int MT, int NT, int BM, bool CONV, bool TR_ONLY = false>
+// FAST: dispatch the row loop to the instance compiled for this launch's kind of epilogue (see EPIF).
+template <typename T, int MT, int NT, int BM, bool CONV, bool TR_ONLY = false, bool FAST = false>
 // colvec (LDS, or null): the tile's per-column vectors staged by the caller, [0, BN): the bias as float32 or the folded LayerNorm's s, [BN, 2 BN): its c (BN = 256);
 // a workgroup that owns its CU alone reads them from there: a global load issued behind a row's stores waits for the stores (vmcnt is in order and counts them).
 MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* rowstat, int m0, int n0, int wm, int wn, int lane, bool tr, int split, const float* colvec = nullptr) {
@@ -142,7 +141,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
     const int nl = wn * WNE + RUN * g;
     const int n = n0 + nl;
     const bool full = p.vec_ok && (n + RUN <= p.N);
-    if (EPIF(p.ksplit > 1)) {  // split-K: raw float32 partial sums; bias / residual / conversion happen in splitk_reduce_kernel
+    if (p.ksplit > 1) {  // split-K: raw float32 partial sums; bias / residual / conversion happen in splitk_reduce_kernel
         float* part = p.partial + (int64_t)split * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -160,22 +159,27 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
         }
         return;
     }
+    auto rows = [&](auto fc) __attribute__((always_inline)) {
+    constexpr unsigned F = decltype(fc)::value;
     float cs_a[RUN], cs_b[RUN];  // GemmP::colstats: the even row of the current 32-row block
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+#if defined(MI355X_G8_ABL) && (MI355X_G8_ABL & 4)
+        if ((int)blockIdx.x == p.pf_blocks && threadIdx.x == 0 && p.sk_ws) reinterpret_cast<uint64_t*>(p.sk_ws)[128 + i] = wall_clock64();  // (probing build: row stamps)
+#endif
         const int mrow = wm * WME + 16 * i + c16;
         const int m = m0 + mrow;
         // rows beyond M keep going through the arithmetic when statistics are produced (the shuffles below need all lanes);
         // their stores are suppressed
         const bool mok = m < p.M;
-        if (!mok && !EPIF(p.stats_out) && !EPIF(p.colstats)) continue;
+        if (!mok && !EPIF(EPI_ST, p.stats_out) && !EPIF(EPI_CS, p.colstats)) continue;
         float v[RUN];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
         if (full) {
-            if (EPIF(p.ln_stats)) {  // y = rstd * (acc - mean * s[n]) + c[n]   (c carries the Linear's bias)
+            if (EPIF(EPI_LN, p.ln_stats)) {  // y = rstd * (acc - mean * s[n]) + c[n]   (c carries the Linear's bias)
                 const float mean = rowstat[2 * mrow], rstd = rowstat[2 * mrow + 1];
 #pragma unroll
                 for (int c = 0; c < RUN / 4; ++c) {
@@ -202,7 +206,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                     }
                 }
             }
-            if (EPIF(rowbias) && mok) {
+            if (EPIF(EPI_RB, rowbias) && mok) {
                 const T* rb = rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n;
 #pragma unroll
                 for (int c = 0; c < RUN / EPC; ++c) {
@@ -211,11 +215,11 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                     for (int e = 0; e < EPC; ++e) v[c * EPC + e] += bv.get(e);
                 }
             }
-            if (EPIF(p.gelu)) {
+            if (EPIF(EPI_GELU, p.gelu)) {
 #pragma unroll
                 for (int e = 0; e < RUN; ++e) v[e] = p.gelu == 1 ? gelu_exact(v[e]) : quick_gelu(v[e]);
             }
-            if (EPIF(p.geglu)) {
+            if (EPIF(EPI_GEGLU, p.geglu)) {
                 if constexpr (NT == 4) {
                     constexpr int HR = RUN / 2;
                     const int no = (n0 + wn * WNE) / 2 + HR * g;
@@ -242,7 +246,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                     }
                 }
             } else {
-                if (EPIF(res) && mok) {
+                if (EPIF(EPI_RES, res) && mok) {
                     const T* rp = res + (int64_t)m * p.ldres + n;
 #pragma unroll
                     for (int c = 0; c < RUN / EPC; ++c) {
@@ -251,7 +255,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                         for (int e = 0; e < EPC; ++e) v[c * EPC + e] += rv.get(e);
                     }
                 }
-                if (EPIF(p.out_f32)) {
+                if (EPIF(EPI_F32, p.out_f32)) {
                     if (mok) {
                         float* of = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
 #pragma unroll
@@ -267,7 +271,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
                     if (mok) store16<T>(op + c * EPC, ov);
-                    if (EPIF(p.stats_out || p.colstats)) {
+                    if (EPIF(EPI_ST, p.stats_out) || EPIF(EPI_CS, p.colstats)) {
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) {
                             v[c * EPC + e] = ov.get(e);
@@ -275,7 +279,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                         }
                     }
                 }
-                if (EPIF(p.colstats)) {
+                if (EPIF(EPI_CS, p.colstats)) {
                     // GroupNorm statistics for the consumer of this tensor: (sum, sum of squares) per column over each 32-row block = the two
                     // 16-row MMA blocks 2h, 2h + 1 of this wave (i even: remember the row, i odd: add, reduce over the 16 lanes, store)
                     if ((i & 1) == 0) {
@@ -298,7 +302,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                         }
                     }
                 }
-                if (EPIF(p.stats_out)) {
+                if (EPIF(EPI_ST, p.stats_out)) {
                     // (mean, M2) of this lane's RUN columns, Chan-merged over the lane groups that share a 32-column chunk:
                     // RUN = 16 -> groups (g, g^1); RUN = 8 -> all four groups.  Lower group first on both sides: identical bits.
                     float mean = rs * (1.0f / RUN), m2 = 0.f, cn = (float)RUN;
@@ -323,7 +327,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                     }
                 }
             }
-        } else if (mok) {
+        } else if (!FAST && mok) {  // (FAST: the caller guarantees aligned operands and N % 16 == 0 -- a lane's 16 columns are all inside N or all outside)
             // guarded scalar path (N edge tiles, unaligned outputs); geglu / LayerNorm fusion are never routed here (host checks)
 #pragma unroll
             for (int e = 0; e < RUN; ++e) {
@@ -339,6 +343,25 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                 }
             }
         }
+    }
+    };
+    if constexpr (FAST) {
+        // one instance per kind of launch the UNet issues (the others take the general one): a workgroup that owns its CU alone pays every branch and every
+        // re-loaded flag of the general row loop in full -- 1.15 us per row block of a 256 x 256 tile, 9.5 us per tile (profiles/r05_l_probe_g8_stamps.log)
+        const unsigned have = (p.ln_stats ? EPI_LN : 0u) | (rowbias ? EPI_RB : 0u) | (p.gelu ? EPI_GELU : 0u) | (p.geglu ? EPI_GEGLU : 0u) | (res ? EPI_RES : 0u) | (p.out_f32 ? EPI_F32 : 0u) |
+                              (p.stats_out ? EPI_ST : 0u) | (p.colstats ? EPI_CS : 0u);
+        switch (have) {
+            case 0u: rows(std::integral_constant<unsigned, 0u>{}); break;
+            case EPI_LN: rows(std::integral_constant<unsigned, EPI_LN>{}); break;
+            case EPI_LN | EPI_GEGLU: rows(std::integral_constant<unsigned, EPI_LN | EPI_GEGLU>{}); break;
+            case EPI_RES | EPI_ST: rows(std::integral_constant<unsigned, EPI_RES | EPI_ST>{}); break;
+            case EPI_CS: rows(std::integral_constant<unsigned, EPI_CS>{}); break;
+            case EPI_RB | EPI_CS: rows(std::integral_constant<unsigned, EPI_RB | EPI_CS>{}); break;
+            case EPI_RES | EPI_CS: rows(std::integral_constant<unsigned, EPI_RES | EPI_CS>{}); break;
+            default: rows(std::integral_constant<unsigned, EPI_ALL>{}); break;
+        }
+    } else {
+        rows(std::integral_constant<unsigned, EPI_ALL>{});
     }
     }
 }

@@ -22,6 +22,8 @@ for geglu in (False, True):
     t0 = st[0]
     rel = [(v - t0) / 100.0 for v in st[:20]]
     print(f"geglu={int(geglu)} stamps (us from start):", " ".join(f"{v:.2f}" for v in rel))
+    rows = sk.ws[:512].view(torch.int64)[128:136].cpu().tolist()
+    print("   last tile, epilogue row starts (us after the K loop's end):", " ".join(f"{(v - st[18]) / 100.0:.2f}" for v in rows), f"| end {(st[19] - st[18]) / 100.0:.2f}")
     for r in range(5):
         a, b, c, d = rel[4 * r: 4 * r + 4]
         nxt = rel[4 * r + 4] if 4 * r + 4 < len(rel) else float("nan")
