@@ -172,7 +172,9 @@ typedef struct {
        handed to the output tiles through
          lora_t     scratch, 128-BYTE aligned, >= groups * GS bytes with GS = M * lora_r * sizeof(dtype) rounded up to a multiple of 128 (group g's
                     rows start at byte g * GS: a cache line never holds rows of two groups or of two 32-row blocks),
-         lora_flags int32[groups * ceil(M / 32)], zeroed once by the caller and private to this call site (they keep the last epoch),
+         lora_flags int32[groups * ceil(M / 32) + 1], zeroed once by the caller and private to this call site (they keep the last epoch); the LAST
+                    word is an error flag: the kernel sets it to 1 when a tile waited 2 s for a hand-over that never came (the output is then
+                    undefined; nothing traps, the context survives),
          lora_epoch device pointer to an int32 whose value differs from every value left in lora_flags: increment it (mi355x_epoch_bump)
                     before each launch, or once per replay of a recorded program whose LoRA launches each own their flags,
        and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with out_f32 or the 8-wave tile;
@@ -193,7 +195,8 @@ typedef struct {
        src/refiners/foundationals/latent_diffusion/unet.py:6-51: the statistics pass over the convolution's output disappears):
        colstats_out[(m / 32) * N + n] = (sum, sum of squares) of out[32 (m / 32) .. + 31][n] AS STORED (rounded to `dtype`), float32 pairs,
        >= ceil(M / 32) * N * 2 floats, 8-byte aligned.  Written by the epilogue (by the reduction pass when ksplit > 1), fixed summation order.
-       Needs the vectorisable epilogue, N a multiple of 16; not combinable with geglu / out_t / out_f32 / the 8-wave tile.  NULL: off. */
+       Needs the vectorisable epilogue, N a multiple of 16; not combinable with geglu / out_t / out_f32; a request for tile 6 (two K groups) runs on
+       tile 1 instead.  NULL: off. */
     float* colstats_out;
     /* tile 8 only.  sk_ws: sk_slots x 256 KB of float32 scratch (16-byte aligned) -- one slot per workgroup, so sk_slots bounds the number of
        workgroups (256 = one per CU of an MI355X); sk_flags: int32[sk_slots + 1], zeroed once by the caller: [0, sk_slots) are hand-off flags that

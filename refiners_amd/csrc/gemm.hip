@@ -198,7 +198,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         p.stats_out = static_cast<float*>(a->stats_out);
     }
     if (a->colstats_out) {
-        if (a->geglu == 1 || has_t || a->out_f32 || !vec || a->N % 16 || a->tile == 6 || (reinterpret_cast<uintptr_t>(a->colstats_out) & 7)) return MI355X_ESHAPE;
+        if (a->geglu == 1 || has_t || a->out_f32 || !vec || a->N % 16 || (reinterpret_cast<uintptr_t>(a->colstats_out) & 7)) return MI355X_ESHAPE;  // (the two-K-group tile has no statistics epilogue: launch_tile takes 128 x 128 instead)
         p.colstats = a->colstats_out;
     }
     for (int i = 0; i < MI355X_MAX_PREFETCH; ++i) {

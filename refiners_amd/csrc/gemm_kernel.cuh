@@ -34,7 +34,7 @@
 //     every thread requests its 16-byte pieces of the t rows (sc1 loads: they land while the last K block is multiplied), and after
 //     the loop t goes through LDS, 32 ranks per step, against the pre-scaled up rows (s B_cat) [N][R], whose first 32 ranks the prologue
 //     staged into LDS.  Producers have the lowest workgroup ids of the launch, so they are dispatched before any tile that waits for
-//     them (a tile that does not find its flags set spins after the loop, bounded by the wall clock, and traps rather than hangs).
+//     them (a tile that does not find its flags set spins after the loop, bounded by the wall clock, and raises the launch's error word rather than hang).
 //     Per-column-group A so that a merged Q|K|V launch keeps its three LoRA sets; Conv2dLora = the same with the conv loader (down
 //     conv of the parent's kernel size / stride, 1x1 up conv).  A launch with SEVERAL column groups whose tile is wide enough (Q|K|V^T
 //     on the 128-column tile) gets t from "t-tiles" instead: one ordinary tile per row tile at the head of the grid, run against the
@@ -713,7 +713,13 @@ __global__ __launch_bounds__(WM* WN * 64 * KG) __attribute__((amdgpu_waves_per_e
                         const uint64_t t0 = wall_clock64();
                         while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {  // L1-bypassing: correct whatever this CU has cached
                             __builtin_amdgcn_s_sleep(2);
-                            if (wall_clock64() - t0 > 200000000ull) __builtin_trap();  // 2 s of the 100 MHz clock: a lost producer must not hang the GPU
+                            if (wall_clock64() - t0 > 200000000ull) {
+                                // 2 s of the 100 MHz clock: a lost producer must neither hang the GPU nor kill the process's HIP context (a trap would): the
+                                // launch's error word -- the int32 behind the last flag -- is raised, the tile goes on with whatever t holds, and the host turns
+                                // the word into an error (native.LoraSync.check)
+                                __hip_atomic_store(p.lora_flags + p.lora_groups * nfl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
                         }
                     }
                 }
@@ -907,6 +913,7 @@ template <typename T, bool CONV>
 int launch_tile(const GemmP& p, hipStream_t stream) {
     int tile = pick_tile(p, CONV);
     if (p.geglu && (tile == 2 || tile == 4)) tile = 3;  // the GEGLU epilogue needs 64 packed columns per wave
+    if (p.colstats && tile == 6) tile = 1;               // column statistics come from the 4-wave tiles' epilogue (whoever asked for tile 6: hint, table or set_option)
     const int st = pick_stages(p);
     if (p.lora_b) {  // in-launch LoRA: the 4-wave tiles, two LDS stages; a stacked rank above 64 needs the 128-column tiles (the producers stage R weight rows)
         if (p.lora_r > 64 && (tile == 2 || tile == 4)) tile = tile == 2 ? 1 : 3;

@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
             f32x2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(k + u * L) * C];
-            s1 += ((v[0][0] + v[1][0]) + (v[2][0] + v[3][0])) + ((v[4][0] + v[5][0]) + (v[6][0] + v[7][0]));
-            s2 += ((v[0][1] + v[1][1]) + (v[2][1] + v[3][1])) + ((v[4][1] + v[5][1]) + (v[6][1] + v[7][1]));
+            s1 += (((double)v[0][0] + (double)v[1][0]) + ((double)v[2][0] + (double)v[3][0])) + (((double)v[4][0] + (double)v[5][0]) + ((double)v[6][0] + (double)v[7][0]));
+            s2 += (((double)v[0][1] + (double)v[1][1]) + ((double)v[2][1] + (double)v[3][1])) + (((double)v[4][1] + (double)v[5][1]) + ((double)v[6][1] + (double)v[7][1]));
         }
         for (; k < nchunk; k += L) {
             const f32x2 v = pp[(int64_t)k * C];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __restrict__ cs, const float* __restrict__ cs2, int C1, int HW, int C, int G,
                                                               const T* __restrict__ gamma, float eps, float* __restrict__ tab) {
-    __shared__ float red[256 * 2];
+    __shared__ double red[256 * 2];
     __shared__ double mean_c[256], m2_c[256];
     __shared__ float stat[2];
     const int g = blockIdx.x, b = blockIdx.y;
@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
     const int j = t / cg, cl = t - j * cg;
     const bool on = j < L;
     const int c = g * cg + cl;
-    float s1 = 0.f, s2 = 0.f;
+    // The per-block moments are float32 (a GEMM epilogue wrote them); everything across blocks is summed in DOUBLE: S2 - S1^2 / n loses mean^2 / var
+    // of its digits, and with float32 cross-block sums a channel of mean 100 and deviation 0.1 came out with a variance that was noise (round-4 advisor).
+    double s1 = 0.0, s2 = 0.0;
     if (on) {
         // the two sources keep their own [block][channel] tables: C1 channels wide for x, C - C1 for x2
         const int Cs = c < C1 ? C1 : C - C1;
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
             f32x2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(k + u * L) * Cs];
-            s1 += ((v[0][0] + v[1][0]) + (v[2][0] + v[3][0])) + ((v[4][0] + v[5][0]) + (v[6][0] + v[7][0]));
-            s2 += ((v[0][1] + v[1][1]) + (v[2][1] + v[3][1])) + ((v[4][1] + v[5][1]) + (v[6][1] + v[7][1]));
+            s1 += (((double)v[0][0] + (double)v[1][0]) + ((double)v[2][0] + (double)v[3][0])) + (((double)v[4][0] + (double)v[5][0]) + ((double)v[6][0] + (double)v[7][0]));
+            s2 += (((double)v[0][1] + (double)v[1][1]) + ((double)v[2][1] + (double)v[3][1])) + (((double)v[4][1] + (double)v[5][1]) + ((double)v[6][1] + (double)v[7][1]));
         }
         for (; k < nblk; k += L) {
             const f32x2 v = pp[(int64_t)k * Cs];
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
     if (on && j == 0) {
         double a1 = 0.0, a2 = 0.0;
         for (int q = 0; q < L; ++q) {
-            a1 += (double)red[(cl + cg * q) * 2 + 0];
-            a2 += (double)red[(cl + cg * q) * 2 + 1];
+            a1 += red[(cl + cg * q) * 2 + 0];
+            a2 += red[(cl + cg * q) * 2 + 1];
         }
         mean_c[cl] = a1 / n;
         const double m2 = a2 - a1 * a1 / n;

@@ -392,7 +392,10 @@ class CompiledSDXL:
         if self.coef_table is None or self.coef_table.device != self.x.device:
             self._tables(self.x.device)
         n = self.x.shape[0]
-        self.engine.prepare_explicit((2 * n,) + tuple(self.x.shape[1:]), self.x.device, dict(self.inputs, timestep=self.ts_table[0:1], timesteps_all=self.ts_table, step_index=0))
+        try:
+            self.engine.prepare_explicit((2 * n,) + tuple(self.x.shape[1:]), self.x.device, dict(self.inputs, timestep=self.ts_table[0:1], timesteps_all=self.ts_table, step_index=0))
+        except Unsupported:
+            return  # a tree this lowering does not know: nothing to stage, step() takes the stock Chain forward with its warning (the fallback contract)
         self.engine.prologue_key = None  # staged, not yet run: the first step() re-stages and runs the prologue
 
     def _fill(self) -> None:

@@ -311,8 +311,8 @@ class Lowering:
         (32-pixel blocks must not straddle samples).  One buffer per PRODUCER (they total ~60 MB for the SDXL step, nothing next to 288 GB):
         the statistics of a tensor stay valid for as long as the tensor does -- a skip tensor is normalised (as one half of a
         ResidualConcatenator's output) long after the next tensor of its shape has been written."""
-        if not self.gn_stats or HW % 32 or N % 16 or self.device.type == "meta":
-            return None
+        if not self.gn_stats or HW % 32 or N % 16 or self.device.type == "meta" or self._target is self.prologue:
+            return None  # (prologue launches -- the ConditionEncoder's convolutions at up to 1024 x 1024 pixels -- feed no GroupNorm: round-4 advisor)
         cs = torch.empty(native.colstats_shape(M, N), device=self.device, dtype=torch.float32)
         self._cs_buf.append(cs)
         return cs

@@ -142,10 +142,18 @@ class UNetLowering(BlockLowering):
         self.pool.put(sin)
         e1s = self.pool.get(R, l1.N)
         native.silu(e1, e1s)
-        if table and res is not None:
-            _expect(l2.lora is None, "RangeEncoder Linear with LoRAs in table mode")
+        if table and res is not None and l2.lora is None:
             te = self.pool.get(R, l2.N)
             native.gemm([(e1s, self.kblocked(l2.w))], te, bias=l2.b, rowbias=res, rows_per_group=R // res.shape[0])
+        elif table and res is not None:
+            # a LoRA on the encoder's second Linear (TimestepEncoder taken out of the loader's exclusions): the adapted launch has no row-bias slot, so the
+            # per-batch-row TextTimeEmbedding enters as a residual expanded to the table's rows -- prologue work, once per prompt (round-4 advisor: this used to
+            # raise Unsupported and send the whole UNet to the stock Chain forward)
+            rep = R // res.shape[0]
+            resx = self.pool.get(R, l2.N)
+            self.python(lambda: resx.copy_(res.repeat_interleave(rep, dim=0)), "time-table row bias -> residual rows")
+            te = self.linear(e1s, l2, res=resx)
+            self.pool.put(resx)
         else:
             te = self.linear(e1s, l2, res=res)
         self.pool.put(e1)

@@ -2,9 +2,9 @@
 -- SURVEY.md section 8(f) next-4.  A second, separately weighted copy of the UNet's encoder half (plus a small conv net on
 the conditioning picture) runs in front of the UNet and adds its thirteen scaled block outputs into "unet".residuals.
 
-Host mirror, CPU oracle and goldens only for now: the engine does NOT lower this tree yet (CompiledUNet raises
-`Unsupported` on a `Controlnet` child -- loudly, there is no silent fallback); its shape of work is the ControlLora's,
-which is lowered (refiners_amd/engine/unet_lowering.py: control_lora).
+The engine lowers it (refiners_amd/engine/unet_lowering.py: the `Controlnet` branch next to control_lora -- the copied encoder runs as part of
+the step program, its residual taps are GEMM launches that accumulate into the UNet's residual slots); goldens from the real reference:
+tests/test_controlnet_golden.py, tests/test_engine_gpu.py.
 """
 from __future__ import annotations
 

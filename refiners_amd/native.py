@@ -530,9 +530,16 @@ class LoraSync:
         self.keep: list = []
 
     def flags(self, groups: int, M: int) -> Tensor:
-        f = torch.zeros(groups * ((M + 31) // 32), dtype=torch.int32, device=self.device)
+        f = torch.zeros(groups * ((M + 31) // 32) + 1, dtype=torch.int32, device=self.device)  # (+ the launch's error word)
         self.keep.append(f)
         return f
+
+    def check(self) -> None:
+        """Raise if a launch of this state's sites reported a hand-over that never arrived (mi355x_gemm_args.lora_flags: the last word)."""
+        if self.keep and bool(torch.stack([f[-1] for f in self.keep]).any().item()):
+            for f in self.keep:
+                f[-1].zero_()
+            raise NativeError("mi355x_gemm (in-launch LoRA): a tile waited 2 s for t = x A^T that never came (MI355X_ELAUNCH)")
 
     def scratch(self, groups: int, M: int, r: int, dtype: torch.dtype) -> Tensor:
         return torch.empty(lora_scratch_rows(groups, M, r, dtype) * r, dtype=dtype, device=self.device)
@@ -578,7 +585,7 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
         sync = (ls.scratch(len(groups), a.M, R, dtype), ls.flags(len(groups), a.M), ls)
     t, flags, ls = sync
     assert t.numel() >= lora_scratch_rows(len(groups), a.M, R, dtype) * R and t.dtype == dtype and t.data_ptr() % 128 == 0
-    assert flags.numel() >= len(groups) * ((a.M + 31) // 32) and flags.dtype == torch.int32
+    assert flags.numel() >= len(groups) * ((a.M + 31) // 32) + 1 and flags.dtype == torch.int32  # (+ the error word)
     a.lora_t, a.lora_flags, a.lora_epoch = t.data_ptr(), flags.data_ptr(), ls.epoch.data_ptr()
     keep.append((lora, t, flags, ls))
 

@@ -378,12 +378,12 @@ def colstats_case(M, K, N, dtype, *, tile=0, ksplit=1, res=True, seed=310):
     return e_out
 
 
-def conv_groupnorm_chain_case(B, Cin, Cout, H, W, dtype, *, ksplit=1, tile=0, silu=True, seed=320):
+def conv_groupnorm_chain_case(B, Cin, Cout, H, W, dtype, *, ksplit=1, tile=0, silu=True, seed=320, dc=1.5, wscale=1.0, chain_tol=None):
     """Conv2d -> GroupNorm (-> SiLU) with the statistics taken from the convolution's epilogue (two GroupNorm launches instead of three)
     against torch's conv2d + group_norm, and against the three-kernel GroupNorm on the same stored tensor."""
     x = _rand(B, Cin, H, W, dtype=dtype, seed=seed)
-    w = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=(Cin * 9) ** -0.5)
-    b = _rand(Cout, dtype=dtype, seed=seed + 2) + 1.5
+    w = _rand(Cout, Cin, 3, 3, dtype=dtype, seed=seed + 1, scale=wscale * (Cin * 9) ** -0.5)
+    b = _rand(Cout, dtype=dtype, seed=seed + 2) * wscale + dc  # (dc: the channels' common offset -- raw-moment statistics lose mean^2 / var of their digits)
     g = (1 + 0.1 * _rand(Cout, dtype=torch.float32, seed=seed + 3)).to(dtype)
     be = (0.1 * _rand(Cout, dtype=torch.float32, seed=seed + 4)).to(dtype)
     M = B * H * W
@@ -395,7 +395,7 @@ def conv_groupnorm_chain_case(B, Cin, Cout, H, W, dtype, *, ksplit=1, tile=0, si
     native.groupnorm_nhwc(y.view(B, H * W, Cout), g, be, 32, 1e-5, silu, o1.view(B, H * W, Cout), colstats=cs)
     native.groupnorm_nhwc(y.view(B, H * W, Cout), g, be, 32, 1e-5, silu, o2.view(B, H * W, Cout))
     d = (o1.float() - o2.float()).abs().max().item()
-    assert d <= (2e-2 if dtype == torch.bfloat16 else 2e-5), f"producer statistics vs statistics pass: {d:.2e}"
+    assert d <= (chain_tol if chain_tol is not None else 2e-2 if dtype == torch.bfloat16 else 2e-5), f"producer statistics vs statistics pass: {d:.2e}"
     ref = F.group_norm(y.float().view(B, H * W, Cout).permute(0, 2, 1), 32, g.float(), be.float(), 1e-5)
     if silu:
         ref = F.silu(ref)
@@ -1035,6 +1035,8 @@ def all_cases():
             (f"conv_gn_{tag}_32x32x320", lambda dt=dt: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt)),
             (f"conv_gn_{tag}_splitk_16x16x640", lambda dt=dt: conv_groupnorm_chain_case(2, 640, 640, 16, 16, dt, ksplit=3, tile=1)),
             (f"conv_gn_{tag}_24x16x960_nosilu", lambda dt=dt: conv_groupnorm_chain_case(1, 320, 960, 24, 16, dt, silu=False)),
+            # a large common offset (mean 10, deviation 0.1): the cross-block sums are double (round-4 advisor); what remains is the float32 of the per-block moments
+            (f"conv_gn_{tag}_dc_offset", lambda dt=dt: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt, dc=10.0, wscale=0.1, chain_tol=3e-2 if dt == torch.bfloat16 else 1e-3, seed=321)),
             (f"gemm_{tag}_lora1_2048x1280x1280", lambda dt=dt: gemm_lora_inlaunch_case(2048, 1280, 1280, dt)),
             (f"gemm_{tag}_lora1_rank8_tile4_edges", lambda dt=dt: gemm_lora_inlaunch_case(300, 640, 200, dt, ranks=(8,), tile=4)),
             (f"gemm_{tag}_lora1_tile2", lambda dt=dt: gemm_lora_inlaunch_case(520, 320, 384, dt, ranks=(16, 4), tile=2)),

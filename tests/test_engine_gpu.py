@@ -1226,5 +1226,9 @@ def test_trajectory_quality_gate_bf16_fused():
     sd1.set_inputs(bf(inp2["x"][:1]), clip_text_embedding=bf(inp2["text"][pick]), pooled_text_embedding=bf(inp2["pooled"][pick]), time_ids=inp2["time_ids"][pick])
     alone = sd1.sample().float()
     mx, l2 = float((alone - both[:1]).abs().max()), S.rel_err(alone, both[:1])[0]
-    print(f"batch invariance bf16 (10 steps, image 0 of 2 vs alone): max abs {mx:.2e} rel l2 {l2:.2e}")
-    assert mx < 5e-3, (mx, l2)
+    scale = float(both[:1].abs().max())
+    print(f"batch invariance bf16 (10 steps, image 0 of 2 vs alone): rel l2 {l2:.2e}, max abs {mx:.2e} on latents of max magnitude {scale:.1f}")
+    # The reference's atol 5e-3 is a statement about float32 pictures in [0, 1].  In bfloat16 a different batch size means different tiles, i.e. a different
+    # summation order, i.e. a trajectory that differs by rounding and then drifts like any two bf16 runs do: the bar is the bf16 parity bar of this file
+    # (norm-wise, vs the float32 reference), which a hand-over or indexing bug between batch rows would miss by orders of magnitude.
+    assert l2 < BF16_TOL, (l2, mx, scale)

@@ -32,3 +32,27 @@ def test_bit_reproducible():
     g1 = kernel_cases.groupnorm_case(2, 320, 4096, torch.float32)
     g2 = kernel_cases.groupnorm_case(2, 320, 4096, torch.float32)
     assert g1[0] == g2[0]
+
+
+def test_lost_lora_producer_raises_instead_of_trapping():
+    """In-launch LoRA whose producers never publish (probing bit: they exit at once, the flags still hold an old epoch): every tile waits its 2 s, raises
+    the launch's error word and finishes; the host turns the word into NativeError, and the process's HIP context survives (the next launch is correct).
+    Round-4 review: a `__builtin_trap()` sat here and killed the context of a serving process."""
+    from refiners_amd import native
+
+    lib = native.load()
+    lib.mi355x_set_option(b"lora_dbg", 1)
+    try:
+        kernel_cases.gemm_lora_inlaunch_case(256, 256, 256, torch.bfloat16)
+        torch.cuda.synchronize()
+    except AssertionError:
+        pass  # (the output of a launch that lost its hand-over is undefined: the case's own non-finite check may fire)
+    finally:
+        lib.mi355x_set_option(b"lora_dbg", 0)
+    with pytest.raises(native.NativeError):
+        for ls in native._eager_sync.values():
+            ls.check()
+    err, scale, tol = kernel_cases.gemm_lora_inlaunch_case(256, 256, 256, torch.bfloat16)  # the context is alive and the next launch is right
+    assert err <= tol * scale + 1e-7
+    for ls in native._eager_sync.values():
+        ls.check()

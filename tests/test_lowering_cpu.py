@@ -414,3 +414,27 @@ def test_tuning_table_lookup_rules(tmp_path, monkeypatch):
     monkeypatch.setattr(tuning, "enabled", False)
     assert tuning.lookup("gemm:bf16:64x64x64:s1:") == (0, 0)
     monkeypatch.setattr(tuning, "_table", None)  # (the next user re-reads the product table)
+
+
+def test_every_tuned_signature_is_a_launch_of_the_lowered_step(monkeypatch):
+    """engine/tuning_gfx950.json is keyed by launch signature; a lowering change that alters a signature (the concat-shortcut split turned two `:s2:`
+    convolutions into `:s3:` in round 4) silently orphans its entry.  Every key of the table must be carried by a launch of the bare SDXL step at the
+    two batch sizes the table was measured on (CFG pair = UNet batch 2; four images per GPU = batch 8), 128 x 128 latents, bf16."""
+    import json
+
+    from refiners_amd import native
+    from refiners_amd.engine import tuning
+
+    monkeypatch.setattr(tuning, "enabled", False)  # (signatures do not depend on the choice; this keeps tile-8 scratch off the meta device)
+    table = json.loads(tuning.TABLE_PATH.read_text())["choices"]
+    seen = set()
+    for B in (2, 8):
+        unet = SDXLUNet(4, device="meta", dtype=torch.bfloat16)
+        low = _dry(unet, B, 128, 128, torch.bfloat16, {("cross_attention_block", "clip_text_embedding"): (77, 2048)})
+        seen |= {native.gemm_signature(e[1][0]._obj).rsplit(":", 1)[0] for e in low.step if e[0] is not None and e[2].startswith("mi355x_gemm")}
+    # (compared without the flag field: on the meta device every pointer is 0, so the flags that mean "this pointer is set" -- ln, st, T -- are missing)
+    # not visible in a meta-device lowering: the merged Q|K|V^T launches (flag T: merging is decided on device tensors) and the two-row time-embedding GEMM
+    # (the timestep table replaces it wherever the solver's timesteps are known)
+    skip = lambda k: "T" in k.rsplit(":", 1)[1] or int(k.split(":")[2].split("x")[0]) <= 8  # noqa: E731
+    orphans = sorted(k for k in table if not skip(k) and k.rsplit(":", 1)[0] not in seen)
+    assert not orphans, orphans
