@@ -27,6 +27,12 @@ extern "C" int mi355x_set_option(const char* name, int value);
 extern "C" int mi355x_set_option(const char* name, int value) {
     // debugging / A-B switches; not part of the stable contract
     if (!name) return MI355X_EARG;
+    if (name[0] == 'g' && name[1] == 'n') {  // "gnwgs" / "gnunroll" (norm.hip)
+        extern int g_gn_wgs, g_gn_unroll;
+        if (name[2] == 'w') g_gn_wgs = value;
+        else g_gn_unroll = value;
+        return MI355X_OK;
+    }
     if (name[0] == 'g' && name[1] == '8') {  // "g8persist"
         g_g8_persist = value;
         return MI355X_OK;

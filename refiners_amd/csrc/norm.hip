@@ -10,6 +10,9 @@
 #include "common.cuh"
 #include "../../include/mi355x_refiners.h"
 
+int g_gn_wgs = 2048;  // workgroups a GroupNorm pass aims for (512 until round 5: profiles/r05_r_probe_gn_apply.log, -5 ... -15 % at 4 images per GPU, nil at a CFG pair); (mi355x_set_option "gnwgs", before any workspace is sized: mi355x_groupnorm_ws_floats follows it)
+int g_gn_unroll = 4;  // loads in flight per thread of the apply pass: 4 or 8 ("gnunroll")
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
 
 // One workgroup per pixel chunk of one sample (the chunks of gn_partial): a thread keeps the (scale, shift) of its 8 / 4 channels in registers
 // and streams its pixels with four loads in flight -- per element one FMA (+ SiLU), no per-element table reads.
-template <typename T>
+template <typename T, int U>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx1, const T* __restrict__ x2, int64_t ldx2, int C1, T* __restrict__ out, int64_t ldo,
                                                         int HW, int C, int ppc, const float* __restrict__ tab,
                                                         const T* __restrict__ beta, int silu) {
@@ -344,10 +347,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             store16<T>(ov + (int64_t)px * ldo, o);
         };
         int px = p0 + pl;
-        for (; px + 3 * PL < p1; px += 4 * PL) {
-            Vec16<T> t0 = load16<T>(xv + (int64_t)px * ldx), t1 = load16<T>(xv + (int64_t)(px + PL) * ldx), t2 = load16<T>(xv + (int64_t)(px + 2 * PL) * ldx),
-                     t3 = load16<T>(xv + (int64_t)(px + 3 * PL) * ldx);
-            emit(t0, px), emit(t1, px + PL), emit(t2, px + 2 * PL), emit(t3, px + 3 * PL);
+        for (; px + (U - 1) * PL < p1; px += U * PL) {  // U independent 16-byte loads in flight per thread
+            Vec16<T> t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = load16<T>(xv + (int64_t)(px + u * PL) * ldx);
+#pragma unroll
+            for (int u = 0; u < U; ++u) emit(t[u], px + u * PL);
         }
         for (; px < p1; px += PL) emit(load16<T>(xv + (int64_t)px * ldx), px);
     }
@@ -356,7 +361,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 inline int gn_ppc(int B, int HW, int C, int es) {
     const int nv = C * es / 16;
     const int pl = nv >= 256 ? 1 : 256 / nv;
-    int64_t target = ((int64_t)B * HW + 511) / 512;  // ~512 workgroups in total
+    const int wgs = g_gn_wgs < 512 ? 512 : g_gn_wgs;
+    int64_t target = ((int64_t)B * HW + wgs - 1) / wgs;  // ~wgs workgroups in total
     int ppc = (int)(target < pl ? pl : target);
     ppc = ((ppc + pl - 1) / pl) * pl;
     if (ppc < 4 * pl) ppc = 4 * pl;
@@ -401,8 +407,12 @@ int run_groupnorm(const mi355x_groupnorm_args* a, hipStream_t st) {
         hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(a->G, a->B), dim3(256), 0, st, x, a->ldx, x2, a->ldx2, C1, a->HW, a->C, a->G,
                            nchunk, part, static_cast<const T*>(a->gamma), a->eps, tab);
     }
-    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, x2, a->ldx2, C1, static_cast<T*>(a->out), a->ldo, a->HW,
-                       a->C, ppc, tab, static_cast<const T*>(a->beta), a->silu);
+    if (g_gn_unroll == 8)
+        hipLaunchKernelGGL((gn_apply_kernel<T, 8>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, x2, a->ldx2, C1, static_cast<T*>(a->out), a->ldo, a->HW, a->C, ppc, tab,
+                           static_cast<const T*>(a->beta), a->silu);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<T, 4>), dim3(nchunk, a->B), dim3(256), 0, st, x, a->ldx, x2, a->ldx2, C1, static_cast<T*>(a->out), a->ldo, a->HW, a->C, ppc, tab,
+                           static_cast<const T*>(a->beta), a->silu);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
 
