@@ -117,8 +117,11 @@ typedef struct {
                                workgroup one barrier apart): the large-grid shapes;  8: the same loop as a persistent "stream-K" launch -- one
                                workgroup per CU, each taking an equal share of (output tiles x K tiles), partial tiles summed in a fixed order
                                through sk_ws -- for launches whose 256x256 tiles do not fill a whole number of rounds (needs sk_ws / sk_flags;
-                               falls back to 7 without them).  7 / 8 do not combine with in-launch LoRA, out_t, ksplit or operands of 2 GB and
-                               more: such launches run on the library's own choice among 1..4 */
+                               falls back to 7 without them).  In-launch LoRA on this loop: ONE column group of a plain one-segment GEMM without out_t,
+                               as whole tiles (8 with LoRA runs as 7) -- t = x A^T comes from "t-tiles" at the head of the grid (the same loop with
+                               the stacked down rows in the weight slot), every tile adds (t)(s B)^T after its K loop.  7 / 8 do not combine with
+                               other in-launch LoRA forms (several groups, out_t, conv), a column group transposed from a column that is not a
+                               multiple of 256, ksplit, or operands of 2 GB and more: such launches run on the library's own choice among 1..4 */
     int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
                                partial sums into `ws`, a second launch adds them in a fixed order (deterministic) and
                                applies the epilogue.  Not combinable with geglu. */
@@ -177,7 +180,7 @@ typedef struct {
                     undefined; nothing traps, the context survives),
          lora_epoch device pointer to an int32 whose value differs from every value left in lora_flags: increment it (mi355x_epoch_bump)
                     before each launch, or once per replay of a recorded program whose LoRA launches each own their flags,
-       and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with out_f32 or the 8-wave tile;
+       and multiplied against lora_b in the tiles' epilogue.  lora_b == NULL: off.  Not combinable with out_f32 or tile 6;
        with ksplit the first split carries the LoRA term.
        With ln_stats (x un-normalised): lora_a carries gamma like w does (A' = A . diag(gamma)) and the caller adds
          lora_ls[g][r] = sum_k A'_g[r][k],   lora_lc[g][r] = sum_k beta[k] A_g[r][k]        (float32, [groups][lora_r]). */

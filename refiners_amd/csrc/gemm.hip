@@ -61,6 +61,16 @@ extern "C" int mi355x_set_option(const char* name, int value) {
     return MI355X_EARG;
 }
 
+static int g_stat_g8 = 0, g_stat_g8_lora = 0;
+extern "C" int mi355x_get_stat(const char* name);
+extern "C" int mi355x_get_stat(const char* name) {
+    // launches since the library was loaded (tests: did the configuration asked for really run?); like mi355x_set_option not part of the stable contract
+    //   "g8" = launches on the 8-wave loop (tile configurations 7 / 8), "g8lora" = those of them with the in-launch LoRA
+    if (!name) return MI355X_EARG;
+    if (name[0] == 'g' && name[1] == '8') return name[2] == 'l' ? g_stat_g8_lora : g_stat_g8;
+    return MI355X_EARG;
+}
+
 namespace {
 __global__ void epoch_bump_kernel(int* e) {
     const int v = *e + 1;
@@ -229,7 +239,9 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tile_req = g_tile ? g_tile : a->tile;
-    if ((tile_req == 7 || tile_req == 8) && gemm8_ok(p)) {  // the 256 x 256 tile on the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
+    if ((tile_req == 7 || tile_req == 8) && gemm8_ok(p, a->conv != 0)) {  // the 256 x 256 tile on the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
+        ++g_stat_g8;
+        if (p.lora_b) ++g_stat_g8_lora;
         const bool sk = tile_req == 8 && a->sk_ws && a->sk_flags && a->sk_slots > 0 && (reinterpret_cast<uintptr_t>(a->sk_ws) & 15) == 0;
         p.sk_ws = static_cast<float*>(a->sk_ws);
         p.sk_flags = a->sk_flags;

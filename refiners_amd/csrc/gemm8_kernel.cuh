@@ -101,7 +101,7 @@ template <int NTHR_ALL> MI_DEV void prefetch_role(const GemmP& p, int tid_all) {
 #define MI355X_G8_PRIO 1  // s_setprio 1 around every MFMA cluster (guide T5: +21..39 % on this schedule)
 #endif
 
-template <typename T, bool CONV>
+template <typename T, bool CONV, bool LORA>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     constexpr int BM = 256, BN = 256, NTHR = 512, MT = 8, NT = 4;
     constexpr int XB = BM * 128, BUFB = (BM + BN) * 128;  // bytes: X tile, one LDS buffer (X tile + W tile)
@@ -116,7 +116,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         prefetch_role<NTHR>(p, tid0);
         return;
     }
-    const int bid = (int)blockIdx.x - p.pf_blocks;
+    int bid = (int)blockIdx.x - p.pf_blocks;
+    // In-launch LoRA (one column group, GemmP::lora_*; fluxion/adapters/lora.py:383-397): the first lp_blocks workgroups are T-TILES -- ordinary tiles of row tile
+    // `bid` whose W slot holds the stacked down rows (rank r in LDS-row order, everything beyond the rank reads as zero), so the same K loop leaves
+    // t = x A^T in their accumulators; their epilogue applies the folded LayerNorm's correction, rounds t to the storage type like the reference's
+    // intermediate tensor, stores it write-through and raises the flags of the tile's eight 32-row blocks.  Every output tile adds T(t) (s B)^T after its K loop
+    // (32 MFMAs per wave and 32 ranks, t and the up rows read straight into fragment layout: no LDS) once its rows' flags carry the launch's epoch.
+    // t-tiles have the lowest ids: dispatched first, they run their K loop beside the tiles that will want t when THEY leave theirs.
+    bool ttile = false;
+    if (LORA && p.lp_blocks > 0) {
+        if (bid < p.lp_blocks) {
+            if (bid >= p.tiles_m) return;  // (padding up to a multiple of 8 keeps tile b on XCD b % 8)
+            ttile = true;
+        } else {
+            bid -= p.lp_blocks;
+        }
+    }
     // ---- this workgroup's span of the launch's work.  The unit of work is one K tile of one output tile; an output tile is sk_nk consecutive units.
     //   sk_mode 0: whole tiles: workgroup b takes tiles b, b + sk_g, ... in the XCD-aware rasterisation of plan_grid (sk_g = tiles: one each);
     //   sk_mode 1 ("stream-K"): sk_g persistent workgroups split the tiles x sk_nk units evenly (+-1) and contiguously, workgroup b taking span b.
@@ -185,7 +200,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             more = tile_next < p.grid0;
         }
         int tm, tn;
-        if (p.sk_mode == 1) {  // tiles in row-major (sk_order 0) or column-major order along the unit axis
+        if (LORA && ttile) {
+            if (tile != bid) break;  // (a t-tile is one tile)
+            tm = bid, tn = 0, more = false;
+        } else if (p.sk_mode == 1) {  // tiles in row-major (sk_order 0) or column-major order along the unit axis
             if (p.sk_order == 0) {
                 tm = tile / p.tiles_n;
                 tn = tile - tm * p.tiles_n;
@@ -203,32 +221,32 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         // loop does not know; acc[i][j] then is the (weight rows 16 i.., activation rows 16 j..) block, and the epilogue gets its transpose.
         const bool tr = !CONV && n0 >= p.nt_begin;
         const int xs_lim = tr ? p.N : p.M, ws_lim = tr ? p.M : p.N, xs_0 = tr ? n0 : m0, ws_0 = tr ? m0 : n0;
-        int xrow[2][2];  // source row of the X slot's LDS row (or -1): an activation row m (transposed tile: a weight row n)
-        int wrow[2][2];  // source row of the W slot's LDS row (or -1): a weight row n (transposed tile: an activation row m)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int rx = xs_0 + 128 * s + 64 * h + 8 * wid + lr8;
-                xrow[h][s] = rx < xs_lim ? rx : -1;
-                // LDS row R of the W slot holds source row (R - rl) + 16 a + 4 j + b, rl = R % 64 = 16 j + 4 a + b (gemm_kernel.cuh header: every lane
-                // then owns 16 consecutive output columns)
-                const int R = 64 * (2 * s + (wid >> 2)) + 32 * h + 8 * (wid & 3) + lr8;
-                const int rl = R & 63, j = rl >> 4, a = (rl >> 2) & 3, b = rl & 3;
-                const int rw = ws_0 + (R - rl) + 16 * a + 4 * j + b;
-                wrow[h][s] = rw < ws_lim ? rw : -1;
-            }
-        int xb[2][2], xyx[2][2];  // conv: image index, (oy | ox << 16) of the output pixel
+        // Source rows of the two slots' LDS rows, as one lane constant each (the per-(h, s) part is a compile-time offset):
+        //   X slot: row 128 s + 64 h + xlane of the tile;   W slot: LDS row R = 64 (2 s + (wid >> 2)) + 32 h + q, q = 8 (wid & 3) + (lane >> 3), holds source
+        //   row (R - rl) + 16 a + 4 j + b with rl = R % 64 = 16 j + 4 a + b (gemm_kernel.cuh header: every lane then owns 16 consecutive output columns)
+        //   = 128 s + 8 h + wlane.  Rows beyond the operand get row -1 (offset 2^32 - ld + coff: beyond every descriptor, the load writes zeros).
+        const int wq = 8 * (wid & 3) + lr8;
+        const int xlane = 8 * wid + lr8, wlane = 64 * (wid >> 2) + 16 * ((wq >> 2) & 3) + 4 * (wq >> 4) + (wq & 3);
+        const int ws_lim_eff = LORA && ttile ? p.lora_r : ws_lim;  // (t-tile: virtual column = rank)
+        auto xrow = [&](int h, int s2) __attribute__((always_inline)) {
+            const int r = xs_0 + 128 * s2 + 64 * h + xlane;
+            return r < xs_lim ? r : -1;
+        };
+        auto wrow = [&](int h, int s2) __attribute__((always_inline)) {
+            const int r = ws_0 + 128 * s2 + 8 * h + wlane;
+            return r < ws_lim_eff ? r : -1;
+        };
+        int xb[2][2], xyx[2][2];  // conv: image index (-1: a row beyond M), (oy | ox << 16) of the output pixel
         if constexpr (CONV) {
             const int ohw = p.OH * p.OW;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int m = xrow[h][s] < 0 ? 0 : xrow[h][s];
-                    const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW;
-                    xb[h][s] = b;
-                    xyx[h][s] = oy | ((rem - oy * p.OW) << 16);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int mr = xrow(h, s2), m = mr < 0 ? 0 : mr;
+                    const int bi = m / ohw, rem = m - bi * ohw, oy = rem / p.OW;
+                    xb[h][s2] = mr < 0 ? -1 : bi;
+                    xyx[h][s2] = oy | ((rem - oy * p.OW) << 16);
                 }
         }
 
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int iy = (xyx[h][s] & 0xffff) * c_st + dy, ix = (xyx[h][s] >> 16) * c_st + dx;
-                    const bool ok = xrow[h][s] >= 0 && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
+                    const bool ok = xb[h][s] >= 0 && iy >= 0 && iy < HH && ix >= 0 && ix < WW;
                     const int pix = (xb[h][s] * c_H + (iy >> c_up)) * c_W + (ix >> c_up);
                     xvo[h][s] = ok ? (uint32_t)pix * c_ld + coff : OOB;
                 }
@@ -288,21 +306,26 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) xvo[h][s2] = (uint32_t)xrow[h][s2] * ld + coff;  // (row -1: 2^32 - ld + coff, beyond every descriptor)
+                    for (int s2 = 0; s2 < 2; ++s2) xvo[h][s2] = (uint32_t)xrow(h, s2) * ld + coff;
             }
         };
         auto enter_w = [&](int s, int kb) __attribute__((always_inline)) {
             const SegP& sp = p.seg[s];
             w_nkb = sp.nkb;
-            const bool kbl = tr ? sp.xkb : sp.wkb;
+            bool kbl = tr ? sp.xkb : sp.wkb;
             wrs = tr ? make_rsrc(sp.x, sp.xbytes) : make_rsrc(sp.w, sp.wbytes);
             w_step = kbl ? (uint32_t)ws_lim * 128u : 128u;
+            uint32_t ld = kbl ? 128u : (uint32_t)(tr ? sp.ldxb : sp.ldwb);
+            if (LORA && ttile) {  // the stacked down rows, K-blocked: [K blocks][lora_r][128 B] (the LoRAs adapt K segment 0: the only one of such a launch)
+                wrs = make_rsrc(p.lora_a[0], (int64_t)sp.nkb * p.lora_r * 128);
+                w_step = (uint32_t)p.lora_r * 128u;
+                ld = 128u;
+            }
             w_so = (uint32_t)kb * w_step;
-            const uint32_t ld = kbl ? 128u : (uint32_t)(tr ? sp.ldxb : sp.ldwb);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) wvo[h][s2] = (uint32_t)wrow[h][s2] * ld + coff;
+                for (int s2 = 0; s2 < 2; ++s2) wvo[h][s2] = (uint32_t)wrow(h, s2) * ld + coff;
         };
         auto adv_x = [&]() __attribute__((always_inline)) {  // one K tile forward (called behind the stage of X half 1)
             ++x_kb;
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             adv_w();
         }
         if (p.ln_stats && owner) ln_rowstat<BM, NTHR>(p, m0, tid, rowstat);
-        if (owner && tid < BN && (p.ln_stats || p.bias)) {  // per-column vectors of the tile -> LDS (read by the epilogue: see tile_epilogue's colvec)
+        if (owner && !(LORA && ttile) && tid < BN && (p.ln_stats || p.bias)) {  // per-column vectors of the tile -> LDS (read by the epilogue: see tile_epilogue's colvec)
             const int n = min(n0 + tid, p.N - 1);
             if (p.ln_stats) {
                 colvec[tid] = p.ln_s[n];
@@ -528,6 +551,103 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             __syncthreads();  // every wave has seen the flags: clear them for the next launch (the slots are free once the loads above returned)
             if (tid < bid - src) __hip_atomic_store(p.sk_flags + src + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // (everything below derives its per-lane addresses from a copy of the lane id made opaque HERE: computed any earlier -- the compiler hoists such
+        //  arithmetic above the K loop -- it would sit in registers the K loop does not have)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int ge = lane_e >> 4, ce = lane_e & 15;
+        // (and the LoRA roles read their parameters through a pointer to the kernel arguments made opaque here, for the same reason: as fields of `p` they
+        //  are scalar loads the compiler issues at kernel entry and carries -- spilt -- through the K loop)
+        const __attribute__((address_space(4))) GemmP* pe = (const __attribute__((address_space(4))) GemmP*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pe));
+        if (LORA) {
+            // ---- LoRA tail of an output tile: acc += T(t) (s B)^T, 32 ranks per step ----
+            const int nfl = (pe->M + 31) / 32, lora_tag = *pe->lora_epoch;
+            if (!ttile) {  // this wave's four row blocks: lanes 0..3 poll one flag each (relaxed agent-scope loads bypass the CU's L1), bounded by the wall clock
+                const int fb = (m0 + 128 * wm) / 32 + (lane_e & 3);
+                const int* fp = pe->lora_flags + (fb < nfl ? fb : nfl - 1);
+                const uint64_t t0 = wall_clock64();
+                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lora_tag) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > 200000000ull) {  // 2 s: raise the launch's error word (native.LoraSync.check) and go on
+                        __hip_atomic_store(pe->lora_flags + pe->lora_groups * nfl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");  // (no load of t may be moved above the poll: relaxed atomics order nothing for the compiler)
+            constexpr int KS32 = 32 / DT<T>::KSTEP;  // MMA steps per 32 ranks (bf16: 1, f32: 2)
+            const int rb = pe->lora_r * (int)sizeof(T);  // bytes per row of t / of the up rows
+            // the W slot's row order (gemm_kernel.cuh header): MMA row ce of block j is output column 64 wn + 16 (ce >> 2) + 4 j + (ce & 3)
+            const int ncol = n0 + 64 * wn + 16 * (ce >> 2) + (ce & 3);
+            const int nc32 = ttile ? 0 : pe->lora_r / 32;  // (a t-tile passes through here with no steps: its accumulators then have ONE consumer after the K loop, this loop --
+            // with the t-tile's own epilogue as a second one beside it the register allocator gave up on keeping them in place: 1400 spills)
+            for (int c = 0; c < nc32; ++c) {
+                frag_t tfr[MT][KS32], bfr[NT][KS32];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int m = min(m0 + 128 * wm + 16 * i + ce, pe->M - 1);
+#pragma unroll
+                    for (int ks = 0; ks < KS32; ++ks)
+                        tfr[i][ks] = *reinterpret_cast<const frag_t*>(pe->lora_t + (int64_t)m * rb + c * 32 * (int)sizeof(T) + (4 * ks + ge) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = min(ncol + 4 * j, pe->N - 1);
+#pragma unroll
+                    for (int ks = 0; ks < KS32; ++ks) bfr[j][ks] = *reinterpret_cast<const frag_t*>(pe->lora_b + (int64_t)n * rb + c * 32 * (int)sizeof(T) + (4 * ks + ge) * 16);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) mma_step<T>(acc[i][j], bfr[j][ks], tfr[i][ks]);
+            }
+        }
+        if (LORA && ttile) {
+            // ---- t-tile epilogue: lane_e (ge, ce) of wave (wm, wn) holds, for rows 128 wm + 16 i + ce, the virtual columns 64 wn + 16 ge + (4 j + r): ranks ----
+            const int r0 = 64 * wn + 16 * ge;
+            const int lora_tag = *pe->lora_epoch;
+            if (r0 < pe->lora_r) {
+                char* tg = pe->lora_t;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int mrow = 128 * wm + 16 * i + ce, m = m0 + mrow;
+                    if (m >= pe->M) continue;
+                    float v[16];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
+                    if (pe->ln_stats) {  // what is published is t / rstd = (x A'^T - mean sA) + cA / rstd: the tiles' LayerNorm epilogue scales the product back
+                        const float mean = rowstat[2 * mrow], inv = 1.0f / rowstat[2 * mrow + 1];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const f32x4 sa = *reinterpret_cast<const f32x4*>(pe->lora_ls + r0 + 4 * c), ca = *reinterpret_cast<const f32x4*>(pe->lora_lc + r0 + 4 * c);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[4 * c + e] = (v[4 * c + e] - mean * sa[e]) + ca[e] * inv;
+                        }
+                    }
+                    char* dst = tg + ((int64_t)m * pe->lora_r + r0) * (int)sizeof(T);
+                    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) st_agent8(dst + 8 * c, __builtin_bit_cast(uint64_t, f32x2{v[2 * c], v[2 * c + 1]}));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const bf16x4 b4 = {(bf16_t)v[4 * c], (bf16_t)v[4 * c + 1], (bf16_t)v[4 * c + 2], (bf16_t)v[4 * c + 3]};
+                            st_agent8(dst + 8 * c, __builtin_bit_cast(uint64_t, b4));
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
+            __syncthreads();
+            const int nfl = (pe->M + 31) / 32;
+            if (tid < 8 && m0 / 32 + tid < nfl) __hip_atomic_store(pe->lora_flags + m0 / 32 + tid, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         if constexpr ((MI355X_G8_ABL & 1) != 0) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -540,12 +660,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) at[j][i] = acc[i][j];
-                tile_epilogue<T, NT, MT, BM, false, true>(p, at, rowstat, m0, n0, wn, wm, lane, true, 0, colvec);
+                tile_epilogue<T, NT, MT, BM, false, true>(p, at, rowstat, m0, n0, wn, wm, lane_e, true, 0, colvec);
             } else {
-                tile_epilogue<T, MT, NT, BM, false, false, true>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0, colvec);
+                tile_epilogue<T, MT, NT, BM, false, false, true>(p, acc, rowstat, m0, n0, wm, wn, lane_e, false, 0, colvec);
             }
         } else {
-            tile_epilogue<T, MT, NT, BM, true, false, true>(p, acc, rowstat, m0, n0, wm, wn, lane, false, 0, colvec);
+            tile_epilogue<T, MT, NT, BM, true, false, true>(p, acc, rowstat, m0, n0, wm, wn, lane_e, false, 0, colvec);
         }
         stamp();  // (3) epilogue issued
         if (more) {  // another segment follows: nobody may still be reading this tile's row statistics when the next tile's are written
@@ -558,11 +678,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
 extern int g_sk_g;        // probing: number of stream-K / persistent workgroups (0 = one per CU)
 extern int g_g8_persist;  // 1 = launches with more tiles than CUs run as one persistent workgroup per CU
 
-template <typename T, bool CONV>
-int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
+template <typename T, bool CONV, bool LORA>
+int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
     constexpr int LDS = 2 * (256 + 256) * 128 + 256 * 8 + 2 * 256 * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kfn = gemm8_kernel<T, CONV>;
+    auto kfn = gemm8_kernel<T, CONV, LORA>;
     static bool attr_set[64] = {};
     static int n_cu[64] = {};
     int dev = 0;
@@ -575,8 +695,8 @@ int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
     GemmP q = p;
     plan_grid(q, 256, 256, CONV, 2);
     q.lora_dbg = 0;
-    q.lora_tt = 0;
-    q.lp_blocks = 0;
+    q.lora_tt = 1;
+    q.lp_blocks = q.lora_b && !q.lora_reuse ? (q.tiles_m + 7) / 8 * 8 : 0;  // t-tiles (none when the caller says t and the flags of this epoch are already there)
     q.ksplit = 1;
     q.sk_nk = 0;
     for (int s = 0; s < q.nseg; ++s) q.sk_nk += q.seg[s].nkb;
@@ -584,7 +704,7 @@ int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
     q.sk_g = q.grid0;  // one tile per workgroup
     int ncu = dev >= 0 && dev < 64 && n_cu[dev] > 0 ? n_cu[dev] : 256;
     if (g_sk_g > 0) ncu = g_sk_g;
-    if (streamk && q.sk_ws && q.sk_flags && q.grid0 % ncu != 0) {
+    if (streamk && !q.lora_b && q.sk_ws && q.sk_flags && q.grid0 % ncu != 0) {
         // "stream-K": one persistent workgroup per CU (256 on MI355X; the decomposition -- hence the summation order -- depends on this number only),
         // fewer when there is less than two K tiles of work for each
         int G = ncu;
@@ -621,16 +741,25 @@ int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
             }
         }
     }
-    if (q.sk_mode == 0 && g_g8_persist && q.grid0 > ncu && ncu % 8 == 0) q.sk_g = ncu;  // several whole tiles per workgroup: b, b + ncu, ... (the same XCD each time)
-    const int grid = q.pf_blocks + q.sk_g;
+    if (q.sk_mode == 0 && g_g8_persist && q.grid0 > ncu && ncu % 8 == 0 && !q.lora_b) q.sk_g = ncu;  // several whole tiles per workgroup: b, b + ncu, ... (the same XCD each time)
+    const int grid = q.pf_blocks + q.lp_blocks + q.sk_g;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, stream, q);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
 
+template <typename T, bool CONV>
+int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
+    if constexpr (!CONV) {
+        if (p.lora_b) return launch_gemm8_impl<T, false, true>(p, stream, streamk);  // (its own instance: the LoRA roles cost the plain one registers it does not have)
+    }
+    return launch_gemm8_impl<T, CONV, false>(p, stream, streamk);
+}
+
 // Can this launch run on the 8-phase loop?  (No in-launch LoRA, no split-K workspace protocol, transposed column groups from a multiple of 256; every operand below
 // 2 GB: 32-bit buffer offsets with 0x80000000 as the out-of-range marker.)
-inline bool gemm8_ok(const GemmP& p) {
-    if (p.lora_b || p.ksplit > 1 || !p.vec_ok || p.N % 16) return false;  // (the epilogue instances of this loop are the vectorised ones)
+inline bool gemm8_ok(const GemmP& p, bool conv = false) {
+    if (p.ksplit > 1 || !p.vec_ok || p.N % 16) return false;  // (the epilogue instances of this loop are the vectorised ones)
+    if (p.lora_b && (conv || p.lora_groups != 1 || p.nseg != 1 || p.out_t || p.lora_r % 32 || p.lora_r > 256 || !p.lora_t || !p.lora_flags || !p.lora_epoch)) return false;  // in-launch LoRA here: one column group of a plain GEMM
     if (p.out_t && p.nt_begin % 256) return false;  // a tile is either stored row-major or transposed
     for (int s = 0; s < p.nseg; ++s)
         if (p.seg[s].xbytes <= 0 || p.seg[s].wbytes <= 0 || p.seg[s].xbytes >= (1ll << 31) || p.seg[s].wbytes >= (1ll << 31)) return false;

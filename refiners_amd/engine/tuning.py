@@ -16,6 +16,7 @@ from typing import Optional
 TABLE_PATH = Path(__file__).resolve().parent / "tuning_gfx950.json"
 _table: Optional[dict] = None
 enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
+lora_g8 = os.environ.get("REFINERS_AMD_LORA_G8", "1") != "0"  # A/B: 0 = LoRA launches never inherit the 8-wave loop from their un-adapted shape class (round-4 behaviour)
 
 
 def table_path() -> Path:
@@ -40,7 +41,12 @@ def lookup(signature: str, stages: int = 0) -> tuple[int, int]:
         got = table().get(signature)
         if got is None and signature.endswith("lora"):  # the LoRA producers leave the tiles' K loop untouched: same choice as the un-adapted launch
             got = table().get(signature[: -len("lora")])
-            if got is not None and (got[0] > 4 or got[1] != 2):  # the LoRA kernels exist for the 4-wave tiles with two LDS stages
+            if got is not None and got[0] in (7, 8):
+                # the 8-wave loop takes the LoRAs of a plain one-segment GEMM with one column group (whole tiles: no stream-K); a launch it cannot
+                # take -- several groups, a transposed group, a convolution -- gets the 128 x 128 tile of the 4-wave kernel
+                kind, _, _, seg, flags = signature.split(":")
+                got = (7, 0) if lora_g8 and kind == "gemm" and seg == "s1" and "T" not in flags else (1, 2)
+            elif got is not None and (got[0] > 4 or got[1] != 2):  # the 4-wave LoRA kernels exist for tiles 1 .. 4 with two LDS stages
                 got = (got[0] if got[0] <= 4 else 1, 2)
         if got is not None:
             return int(got[0]), int(got[1])

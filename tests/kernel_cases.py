@@ -791,6 +791,18 @@ def with_lora_source(bits, fn):
         lib.mi355x_set_option(b"lora_dbg", 0)
 
 
+def on_g8_lora(fn, launches=1):
+    """Run a case and require that at least `launches` of its launches took the in-launch LoRA on the 8-wave loop (csrc/gemm8_kernel.cuh: t-tiles at the head of
+    the grid, the up-projection as every tile's tail) rather than falling back to the 4-wave kernel: mi355x_get_stat("g8lora")."""
+    lib = native.load()
+    lib.mi355x_get_stat.argtypes = [__import__("ctypes").c_char_p]
+    n0 = lib.mi355x_get_stat(b"g8lora")
+    e = fn()
+    n1 = lib.mi355x_get_stat(b"g8lora")
+    assert n1 - n0 >= launches, f"expected {launches} LoRA launches on the 8-wave loop, saw {n1 - n0}"
+    return e
+
+
 def gemm_qkv_lora_case(M, K, Cc, dtype, tile=0, seed=270):
     """Q | K | V^T from one launch with a different LoRA set per column group."""
     x = _rand(M, K, dtype=dtype, seed=seed)
@@ -871,7 +883,7 @@ def conv_lora_inlaunch_case(B, Cin, Cout, H, W, dtype, *, ranks=(16, 16), stride
     return _cmp(out, ref.permute(0, 2, 3, 1).reshape(B * OH * OW, Cout), dtype)
 
 
-def gemm_lora_repeat_case(M, K, N, dtype, seed=295, rounds=12):
+def gemm_lora_repeat_case(M, K, N, dtype, seed=295, rounds=12, tiles=(1, 4, 2, 3)):
     """The hand-off under reuse: the SAME scratch / flags / epoch word driven through several launches with different inputs (what a
     replayed program does), every word of every result checked -- a stale t (flag seen early, L1-resident line) would show here."""
     w = _rand(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5)
@@ -884,7 +896,7 @@ def gemm_lora_repeat_case(M, K, N, dtype, seed=295, rounds=12):
         x = _rand(M, K, dtype=dtype, seed=seed + 50 + rnd)
         out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
         sync.bump()
-        native.gemm([(x, wk)], out, lora=([(0, a_kb)], bs), lora_sync=(t, flags, sync), tile=(1, 4, 2, 3)[rnd % 4])
+        native.gemm([(x, wk)], out, lora=([(0, a_kb)], bs), lora_sync=(t, flags, sync), tile=tiles[rnd % len(tiles)])
         e = _cmp(out, x.float() @ (w.float() + delta).t(), dtype)
         worst = (max(worst[0], e[0]), max(worst[1], e[1]), e[2])
     return worst
@@ -1116,6 +1128,22 @@ def all_cases():
                 (f"conv_{tag}_tile{tile}_odd_taps", lambda dt=dt, tile=tile: conv_tile_case(1, 64, 320, 40, 24, dt, tile, 0, seed=221)),
                 (f"conv_gn_{tag}_tile{tile}", lambda dt=dt, tile=tile: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt, tile=tile)),
             ]
+        # the in-launch LoRA on the 8-wave loop (one column group of a plain GEMM; everything else keeps the 4-wave kernel's producers)
+        cases += [
+            (f"gemm_{tag}_tile7_lora1_2048x1280x1280", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, tile=7), 2)),
+            (f"gemm_{tag}_tile7_lora1_rank8_edges", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(300, 640, 208, dt, ranks=(8,), tile=7), 2)),
+            (f"gemm_{tag}_tile7_lora1_rank64", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(520, 640, 384, dt, ranks=(32, 16, 8), tile=7), 2)),
+            (f"gemm_{tag}_tile7_lora1_rank128", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, ranks=(128,), tile=7), 2)),
+            (f"gemm_{tag}_tile7_lora1_geglu", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(512, 640, 2560, dt, geglu=True, tile=7))),
+            (f"gemm_{tag}_tile7_lora1_ff1_geglu_more_tiles_than_cus", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 10240, dt, geglu=True, tile=7))),
+            (f"gemm_{tag}_tile7_lora1_ff2_2048x1280x5120", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 5120, 1280, dt, tile=7), 2)),
+            (f"gemm_{tag}_tile7_lora1_short_k", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(1000, 64, 528, dt, tile=7), 2)),
+            (f"gemm_{tag}_tile7_ln_lora_1024x1280", lambda dt=dt: on_g8_lora(lambda: gemm_ln_lora_case(1024, 1280, 1280, dt, tile=7))),
+            (f"gemm_{tag}_tile7_ln_lora_edges", lambda dt=dt: on_g8_lora(lambda: gemm_ln_lora_case(300, 640, 384, dt, tile=7))),
+            (f"gemm_{tag}_tile7_lora1_repeat_shared_scratch", lambda dt=dt: on_g8_lora(lambda: gemm_lora_repeat_case(1024, 640, 1280, dt, tiles=(7, 1, 7, 3)), 6)),
+            (f"gemm_{tag}_tile7_lora1_transposed_keeps_4wave", lambda dt=dt: gemm_lora_inlaunch_case(154, 2048, 640, dt, transposed=True, tile=7)),
+            (f"gemm_{tag}_tile7_qkv_lora_keeps_4wave", lambda dt=dt: gemm_qkv_lora_case(512, 640, 640, dt, tile=7)),
+        ]
         cases += [
             (f"conv_{tag}_tile7_s2_ups_shortcut", lambda dt=dt: conv_forced_tile_case(dt, 7)),
             (f"conv_{tag}_tile8_s2_ups_shortcut", lambda dt=dt: conv_forced_tile_case(dt, 8)),

@@ -15,6 +15,16 @@ def test_tile_table_fallbacks(monkeypatch):
     assert tuning.lookup("gemm:bf16:8x8x8:s1:lora") == (1, 2)    # 8-wave tile -> 128x128, two stages
     assert tuning.lookup("gemm:bf16:8x8x8:s1:lnlora") == (3, 2)  # deeper ring -> two stages
     assert tuning.lookup("gemm:bf16:9x9x9:s1:lora") == (2, 2)    # its own measured entry wins
+    # the 8-wave loop (7 = whole tiles, 8 = stream-K) takes the LoRAs of a plain one-segment GEMM with one column group, as whole tiles
+    monkeypatch.setattr(tuning, "_table", {"gemm:bf16:8x8x8:s1:gegluln": (7, 0), "gemm:bf16:8x8x8:s1:st": (8, 0), "gemm:bf16:8x24x8:s1:T16ln": (7, 0),
+                                           "conv:bf16:8x8x72:s1:": (8, 0), "gemm:bf16:8x8x16:s2:": (7, 0)})
+    assert tuning.lookup("gemm:bf16:8x8x8:s1:geglulnlora") == (7, 0)
+    assert tuning.lookup("gemm:bf16:8x8x8:s1:stlora") == (7, 0)
+    assert tuning.lookup("gemm:bf16:8x24x8:s1:T16lnlora") == (1, 2)  # a transposed column group (Q | K | V^T: three LoRA groups): the 4-wave kernel
+    assert tuning.lookup("conv:bf16:8x8x72:s1:lora") == (1, 2)
+    assert tuning.lookup("gemm:bf16:8x8x16:s2:lora") == (1, 2)
+    monkeypatch.setattr(tuning, "lora_g8", False)
+    assert tuning.lookup("gemm:bf16:8x8x8:s1:stlora") == (1, 2)
     monkeypatch.setattr(tuning, "enabled", False)
     assert tuning.lookup("gemm:bf16:8x8x8:s1:") == (0, 0)
 
@@ -24,7 +34,7 @@ def test_the_shipped_table_only_names_tiles_the_library_has():
     for sig, (tile, stages) in doc["choices"].items():
         assert tile in (0, 1, 2, 3, 4, 6, 7, 8) and stages in (0, 2, 3, 4), (sig, tile, stages)  # (7 / 8: the 8-wave loop, whole tiles / stream-K)
         if sig.endswith("lora"):
-            assert tile in (1, 2, 3, 4) and stages == 2, sig
+            assert (tile in (1, 2, 3, 4) and stages == 2) or (tile == 7 and sig.startswith("gemm") and ":s1:" in sig and "T" not in sig.split(":")[-1]), sig
 
 
 def test_bench_quotes_the_latest_counter_pass_deterministically(tmp_path, monkeypatch):

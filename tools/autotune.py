@@ -37,6 +37,8 @@ def candidates(a, only=None) -> list[tuple[int, int]]:
     out = []
     if not a.lora_b and not (a.out_t and a.nt_begin % 256):  # the 8-wave / eight-phase loop: 7 = whole 256 x 256 tiles, 8 = stream-K
         out += [(7, 0), (8, 0)]
+    elif a.lora_b and not a.conv and a.lora_groups == 1 and a.nseg == 1 and not a.out_t:  # its in-launch LoRA: one column group of a plain GEMM, whole tiles
+        out += [(7, 0)]
     if a.ksplit > 1:  # a launch the lowering split along K: only the 8-wave loop (which takes the whole K) is an alternative
         return [c for c in out if only is None or c[0] in only]
     for tile in (1, 2, 3, 4, 6):  # 128x128, 128x64, 64x128, 64x64 (4 waves); 6 = 128x128 with two K groups (8 waves)

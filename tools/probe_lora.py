@@ -90,6 +90,14 @@ def case(M, K, N, *, geglu=False, ln=False, qkv=False, tile=0, ranks=(16, 16), o
     lib = native.load()
     res = {}
     res["plain"] = graph_time(plain)
+    if only == ("g8",):  # the 8-wave loop against the 4-wave kernel: un-adapted / adapted / adapted with nobody waiting
+        res["bump+plain"] = graph_time(bump_plain)
+        res["full"] = graph_time(full)
+        res["nowait"] = graph_time(nowait)
+        fl = 2.0 * M * K * N
+        print(f"M={M} K={K} N={N} geglu={int(geglu)} ln={int(ln)} tile={tile} R={R}: " + "  ".join(f"{k} {v:7.2f} us" for k, v in res.items())
+              + f"   | plain {fl / res['plain'] / 1e6:.0f} TF, (full - bump) / plain = {(res['full'] - (res['bump+plain'] - res['plain'])) / res['plain']:.3f}", flush=True)
+        return res
     if only is None:
         res["bump+plain"] = graph_time(bump_plain)
         res["full"] = graph_time(full)
@@ -120,6 +128,19 @@ def main():
     native.load()
     if "--bisect" in sys.argv:
         case(2048, 1280, 1280, tile=1, only=("plain", "as-plain"))
+        return
+    if "--g8" in sys.argv:  # round 5: the in-launch LoRA on the 8-wave loop (tile 7) beside the 4-wave kernel's (tile 1 / the heuristic), CFG-pair and 4-image sizes
+        for M in (2048, 4096):
+            for tile in (1, 7):
+                case(M, 1280, 1280, tile=tile, only=("g8",))
+                case(M, 1280, 10240, geglu=True, ln=True, tile=tile, only=("g8",))
+                case(M, 5120, 1280, tile=tile, only=("g8",))
+                case(M, 1280, 1280, ln=True, tile=tile, only=("g8",))
+        for M in (8192, 16384):
+            for tile in (1, 7):
+                case(M, 640, 640, tile=tile, only=("g8",))
+                case(M, 640, 5120, geglu=True, ln=True, tile=tile, only=("g8",))
+                case(M, 2560, 640, tile=tile, only=("g8",))
         return
     if "--ablate" in sys.argv:
         case(2048, 1280, 1280, tile=1)
