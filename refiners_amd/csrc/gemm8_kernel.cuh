@@ -560,6 +560,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         //  are scalar loads the compiler issues at kernel entry and carries -- spilt -- through the K loop)
         const __attribute__((address_space(4))) GemmP* pe = (const __attribute__((address_space(4))) GemmP*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(pe));
+#ifdef MI355X_G8_EPI_ARGS_AT_ENTRY  // (A/B build: the epilogue reads the by-value kernel argument like the K loop does: ~60 scalar-spill reloads per 16-row block)
+        const GemmP& pq = p;
+#else
+        const GemmP& pq = *(const GemmP*)pe;  // (the epilogue's view of the arguments: loaded HERE, after the K loop, into scalar registers the loop no longer needs)
+#endif
         if (LORA) {
             // ---- LoRA tail of an output tile: acc += T(t) (s B)^T, 32 ranks per step ----
             const int nfl = (pe->M + 31) / 32, lora_tag = *pe->lora_epoch;
@@ -660,12 +665,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) at[j][i] = acc[i][j];
-                tile_epilogue<T, NT, MT, BM, false, true>(p, at, rowstat, m0, n0, wn, wm, lane_e, true, 0, colvec);
+                tile_epilogue<T, NT, MT, BM, false, true>(pq, at, rowstat, m0, n0, wn, wm, lane_e, true, 0, colvec);
             } else {
-                tile_epilogue<T, MT, NT, BM, false, false, true>(p, acc, rowstat, m0, n0, wm, wn, lane_e, false, 0, colvec);
+                tile_epilogue<T, MT, NT, BM, false, false, true>(pq, acc, rowstat, m0, n0, wm, wn, lane_e, false, 0, colvec);
             }
         } else {
-            tile_epilogue<T, MT, NT, BM, true, false, true>(p, acc, rowstat, m0, n0, wm, wn, lane_e, false, 0, colvec);
+            tile_epilogue<T, MT, NT, BM, true, false, true>(pq, acc, rowstat, m0, n0, wm, wn, lane_e, false, 0, colvec);
         }
         stamp();  // (3) epilogue issued
         if (more) {  // another segment follows: nobody may still be reading this tile's row statistics when the next tile's are written

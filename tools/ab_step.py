@@ -23,7 +23,7 @@ from refiners_amd.engine import tuning  # noqa: E402
 from refiners_amd.engine.compiled import CompiledSDXL  # noqa: E402
 
 KEYS = ("REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH", "REFINERS_AMD_TIME_BATCH", "REFINERS_AMD_ATTN_PIPE",
-        "REFINERS_AMD_GN_STATS", "REFINERS_AMD_TIME_TABLE", "REFINERS_AMD_CAT_FUSE", "REFINERS_AMD_TUNING_TABLE", "REFINERS_AMD_PF_BLOCKS")
+        "REFINERS_AMD_GN_STATS", "REFINERS_AMD_TIME_TABLE", "REFINERS_AMD_CAT_FUSE", "REFINERS_AMD_TUNING_TABLE", "REFINERS_AMD_PF_BLOCKS", "REFINERS_AMD_LORA_G8")
 
 
 def main() -> None:
@@ -52,6 +52,7 @@ def main() -> None:
         native.attention_pipeline_from_env()
         tuning.enabled = os.environ.get("REFINERS_AMD_TUNING", "1") != "0"
         tuning._table = None
+        tuning.lora_g8 = os.environ.get("REFINERS_AMD_LORA_G8", "1") != "0"
         libtag = None
         if "%" in name:  # "name%prio=...": lowered against csrc/variants/libmi355x_refiners_prio.so (refiners_amd.build_native.build_variant)
             name_, libtag = name.split("%", 1)

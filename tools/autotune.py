@@ -63,6 +63,7 @@ def main() -> None:
     ap.add_argument("--min-share", type=float, default=0.004, help="classes below this share of the step are tuned on their own replay")
     ap.add_argument("--budget-s", type=float, default=420.0)
     ap.add_argument("--tiles", default="", help="comma-separated tile ids to try (default: all legal ones)")
+    ap.add_argument("--only-class", default="", help="tune only the classes whose signature contains this (e.g. lora)")
     args = ap.parse_args()
 
     only = {int(t) for t in args.tiles.split(",")} if args.tiles else None
@@ -94,6 +95,8 @@ def main() -> None:
         if time.time() - t_start > args.budget_s:
             print("time budget reached, stopping", flush=True)
             break
+        if args.only_class and args.only_class not in sig:
+            continue
         items = classes[sig]
         a0 = items[0]
         whole = own[sig] / base >= args.min_share
