@@ -107,8 +107,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     constexpr int XB = BM * 128, BUFB = (BM + BN) * 128;  // bytes: X tile, one LDS buffer (X tile + W tile)
     constexpr uint32_t OOB = 0x80000000u;                  // per-lane offset beyond every descriptor's num_records: the load writes zeros
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* rowstat = reinterpret_cast<float*>(smem + 2 * BUFB);  // [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer)
-    float* colvec = rowstat + 2 * BM;                            // [2][BN]: the tile's bias (as float32) or folded-LayerNorm s | c, staged for the epilogue
+    // per-tile vectors of the epilogue, TWO sets used alternately by consecutive segments of a persistent workgroup: the waves that finish a tile's epilogue first
+    // go on to the next tile's prologue (which writes the other set) without waiting for the rest -- they meet again at the prologue's own barrier
+    float* const epi_lds = reinterpret_cast<float*>(smem + 2 * BUFB);
+    constexpr int EPI_SET = 2 * BM + 2 * BN;  // floats: rowstat [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer) | colvec [2][BN]: bias (as float32) or folded-LayerNorm s | c
+    int epi_par = 0;
 
     const int tid0 = threadIdx.x, wid = wave_id();
     const int wm = wid >> 2, wn = wid & 3;
@@ -170,6 +173,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         //  hoisted out of this loop and kept in registers through the K loop, which has none to spare)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
+        float* rowstat = epi_lds + epi_par * EPI_SET;
+        float* colvec = rowstat + 2 * BM;
+        epi_par ^= 1;
         const int lane = tid & 63, g = lane >> 4, c16 = lane & 15;
         // ---- loader geometry.  Half tile (h), load (s): 128 rows x 8 chunks = 1024 pieces of 16 B = 2 loads x 512 threads; piece s * 512 + tid is
         // (local row lr = s * 64 + 8 wid + (lane >> 3), physical chunk lane & 7).  X: LDS row = 128 s + 64 h + (lr & 63);  W: LDS row = 64 (lr >> 5)
@@ -673,10 +679,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             tile_epilogue<T, MT, NT, BM, true, false, true>(pq, acc, rowstat, m0, n0, wm, wn, lane_e, false, 0, colvec);
         }
         stamp();  // (3) epilogue issued
-        if (more) {  // another segment follows: nobody may still be reading this tile's row statistics when the next tile's are written
+        // (no barrier between segments: the next prologue writes the OTHER set of epilogue vectors, and the stage buffers it fills were last read before
+        //  the barrier that closed the K loop; the set this epilogue reads is rewritten two segments on, behind the next prologue's barrier)
+#ifdef MI355X_G8_END_BARRIER  // (A/B build: the round-5 first version, every wave waits for the tile's last epilogue row before the next tile's first load)
+        if (more) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+#endif
     }
 }
 
@@ -685,7 +695,7 @@ extern int g_g8_persist;  // 1 = launches with more tiles than CUs run as one pe
 
 template <typename T, bool CONV, bool LORA>
 int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
-    constexpr int LDS = 2 * (256 + 256) * 128 + 256 * 8 + 2 * 256 * 4;
+    constexpr int LDS = 2 * (256 + 256) * 128 + 2 * (256 * 8 + 2 * 256 * 4);  // two stage buffers + two sets of epilogue vectors
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kfn = gemm8_kernel<T, CONV, LORA>;
     static bool attr_set[64] = {};
