@@ -27,7 +27,15 @@
 // Loader: buffer_load_dwordx4 ... lds (LDS-DMA through a buffer descriptor): per-lane 32-bit offset that is constant over the K loop, the
 // running K offset in the instruction's SCALAR offset, the descriptor per segment -- no vector ALU work per load -- and out-of-range lanes
 // (conv padding, rows beyond M / N) are given offset 0x80000000, for which the hardware writes zeros to LDS (no zero page, no select).
-// Not in this loop (the host keeps such launches on gemm_kernel.cuh): in-launch LoRA, operands of 2 GB and more.
+// In-launch LoRA (its own kernel instance, LORA = true: the plain instance's register allocation is untouched): ONE column group of a plain one-segment GEMM
+// without a transposed part.  t = x A^T comes from "t-tiles" -- the first tiles_m workgroups of the grid run this same loop on their row tile with the stacked
+// down rows in the W slot and publish t (LayerNorm correction folded in, rounded to the storage type, write-through stores, one flag per 32 rows) --, and every
+// output tile adds T(t) (s B)^T after its K loop: fragments of t and of the up rows straight from memory (a wave's 16 rows x 64 B are 1 KB contiguous), 32 MFMAs
+// per 32 ranks.  Register notes that shaped the code: (a) the accumulators must have ONE consumer after the K loop -- with the t-tile epilogue and the tail as
+// alternatives the allocator gave up on keeping them in place (1 400 spills), so t-tiles pass through the tail with zero steps; (b) everything after the K loop
+// reads the launch arguments through a pointer to the kernel-argument segment made opaque AFTER the loop: as fields of the by-value argument they are loaded at
+// kernel entry, spilt over the loop and re-loaded one v_readlane per use (3 181 of them; 59 per 16-row block of the epilogue).
+// Not in this loop (the host keeps such launches on gemm_kernel.cuh): other LoRA forms (several column groups, a transposed group, convolutions), operands of 2 GB and more.
 #pragma once
 #include <vector>
 
@@ -711,7 +719,7 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
     plan_grid(q, 256, 256, CONV, 2);
     q.lora_dbg = 0;
     q.lora_tt = 1;
-    q.lp_blocks = q.lora_b && !q.lora_reuse ? (q.tiles_m + 7) / 8 * 8 : 0;  // t-tiles (none when the caller says t and the flags of this epoch are already there)
+    q.lp_blocks = q.lora_b ? (q.tiles_m + 7) / 8 * 8 : 0;  // t-tiles: one per row tile, padded to a multiple of 8 (tile b stays on XCD b % 8)
     q.ksplit = 1;
     q.sk_nk = 0;
     for (int s = 0; s < q.nseg; ++s) q.sk_nk += q.seg[s].nkb;

@@ -69,7 +69,6 @@ struct GemmP {
     int* lora_flags;       // [groups][ceil(M / 32)]: == *lora_epoch once those 32 rows of t are complete
     const int* lora_epoch;
     int lp_blocks;         // producer workgroups at the head of the grid (ceil(M / 32) * groups rounded up to a multiple of 8)
-    int lora_reuse;        // 1 = t and the flags of this epoch were written by an earlier launch of the same program (a column split of one Linear): no producers / t-tiles
     int lora_tt;           // 1 = no producers: the lp_blocks workgroups at the head of the grid are t-TILES (one per row tile; see gemm_kernel)
     int64_t lora_gs;       // bytes from one group's t to the next: M * lora_r * sizeof(T) rounded up to 128 (a 128-byte line never holds two groups' rows)
     int lora_dbg;          // probing only (mi355x_set_option "lora_dbg", tools/probe_lora.py; timing, not results): 1 = producers exit at once (valid only
