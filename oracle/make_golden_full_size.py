@@ -4,7 +4,8 @@ tests/support.py::FULL_SIZE and commit the results, so that the GPU tests at ful
     python oracle/make_golden_full_size.py [name ...]        # ~2-5 min per recipe on 8 cores, ~25 GB RAM
 
 Writes tests/golden/full_size_oracle.safetensors: one float32 x_next per recipe (1 x 4 x 128 x 128), the recipe as JSON in the file's metadata
-(tests/support.py::full_size_oracle ignores an entry whose recipe no longer matches and computes the step on the spot instead).  The oracle
+(tests/support.py::full_size_oracle ignores an entry whose recipe no longer matches, or a file whose `sources` digest -- sha256 over oracle/*.py and
+refiners_amd/synth.py -- differs from the tree's, and computes the step on the spot instead).  The oracle
 itself is pinned against the reference's own outputs by tests/test_oracle_golden.py (tests/golden/sdxl_*.safetensors, oracle/make_golden.py)."""
 from __future__ import annotations
 
@@ -36,7 +37,7 @@ def main() -> None:
             tensors[name] = S.compute_full_size_oracle(name).float().contiguous()
         meta[name] = json.dumps(S.FULL_SIZE[name])
         print(name, tuple(tensors[name].shape), f"abs mean {float(tensors[name].abs().mean()):.4f}", f"{time.time() - t0:.0f} s", flush=True)
-        save_file(tensors, str(path), metadata={**meta, "torch": torch.__version__})
+        save_file(tensors, str(path), metadata={**meta, "torch": torch.__version__, "sources": S.oracle_sources_digest()})
 
 
 if __name__ == "__main__":

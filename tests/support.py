@@ -99,6 +99,21 @@ def compute_full_size_oracle(name: str) -> torch.Tensor:
                            loras=specs["loras"] or None, ip=specs["ip"])
 
 
+def oracle_sources_digest() -> str:
+    """sha256 over the sources a FULL_SIZE tensor depends on besides its recipe: the CPU oracle (oracle/*.py without the fixture writers) and the synthetic
+    weights / inputs (refiners_amd/synth.py).  Stored in the fixture's metadata; an edit to any of them makes full_size_oracle() recompute instead of
+    serving a stale reference (round-4 advisor)."""
+    import hashlib
+
+    root = GOLD.parent.parent
+    files = sorted(p for p in (root / "oracle").glob("*.py") if not p.name.startswith("make_golden")) + [root / "refiners_amd" / "synth.py"]
+    h = hashlib.sha256()
+    for p in files:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
 def full_size_oracle(name: str) -> torch.Tensor:
     from safetensors import safe_open
 
@@ -106,6 +121,6 @@ def full_size_oracle(name: str) -> torch.Tensor:
     if path.exists():
         with safe_open(str(path), framework="pt") as f:
             meta = f.metadata() or {}
-            if name in f.keys() and json.loads(meta.get(name, "null")) == FULL_SIZE[name]:
+            if name in f.keys() and json.loads(meta.get(name, "null")) == FULL_SIZE[name] and meta.get("sources") == oracle_sources_digest():
                 return f.get_tensor(name)
     return compute_full_size_oracle(name)

@@ -39,3 +39,19 @@ def test_sd1_oracle_matches_reference():
     l2, mx = S.rel_err(y, gold["unet_out"])
     assert l2 < TOL and mx < TOL, (l2, mx)
     assert torch.equal(gold["unet_out"], gold["unet_out_again"])  # the reference itself is bit-reproducible
+
+
+def test_full_size_fixture_is_current():
+    """tests/golden/full_size_oracle.safetensors holds the oracle's steps at the benchmarked geometry (the GPU tests compare the engine with them).  An entry is only
+    served when its recipe AND the digest of the sources it was computed from (oracle/*.py, refiners_amd/synth.py) match the tree: a stale file would otherwise cost every
+    GPU run minutes of host arithmetic -- or, before the digest existed, silently keep a reference the edited oracle no longer produces (round-4 advisor)."""
+    import json
+
+    from safetensors import safe_open
+
+    with safe_open(str(S.GOLD / "full_size_oracle.safetensors"), framework="pt") as f:
+        meta = f.metadata() or {}
+        assert meta.get("sources") == S.oracle_sources_digest(), "re-run `python oracle/make_golden_full_size.py` (oracle or synth sources changed)"
+        for name, recipe in S.FULL_SIZE.items():
+            assert name in f.keys() and json.loads(meta.get(name, "null")) == recipe, name
+            assert tuple(f.get_slice(name).get_shape()) == (1, 4, 128, 128)
