@@ -137,7 +137,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     bool ttile = false;
     if (LORA && p.lp_blocks > 0) {
         if (bid < p.lp_blocks) {
-            if (bid >= p.tiles_m) return;  // (padding up to a multiple of 8 keeps tile b on XCD b % 8)
+            if (bid >= p.tiles_m || (p.lora_dbg & 1)) return;  // (padding up to a multiple of 8 keeps tile b on XCD b % 8; lora_dbg bit 0, probing / tests: the t-tiles exit
+                                                               //  at once -- a LOST hand-over: every tile waits its 2 s and raises the launch's error word)
             ttile = true;
         } else {
             bid -= p.lp_blocks;
@@ -699,6 +700,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
 }
 
 extern int g_sk_g;        // probing: number of stream-K / persistent workgroups (0 = one per CU)
+extern int g_lora_dbg;    // probing bits of the in-launch LoRA (gemm.hip; bit 0 = the hand-over's producers exit at once)
 extern int g_g8_persist;  // 1 = launches with more tiles than CUs run as one persistent workgroup per CU
 
 template <typename T, bool CONV, bool LORA>
@@ -717,7 +719,7 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
     }
     GemmP q = p;
     plan_grid(q, 256, 256, CONV, 2);
-    q.lora_dbg = 0;
+    q.lora_dbg = g_lora_dbg & 1;  // (mi355x_set_option "lora_dbg"; the other probing bits belong to the 4-wave kernel's producers)
     q.lora_tt = 1;
     q.lp_blocks = q.lora_b ? (q.tiles_m + 7) / 8 * 8 : 0;  // t-tiles: one per row tile, padded to a multiple of 8 (tile b stays on XCD b % 8)
     q.ksplit = 1;

@@ -34,16 +34,17 @@ def test_bit_reproducible():
     assert g1[0] == g2[0]
 
 
-def test_lost_lora_producer_raises_instead_of_trapping():
+@pytest.mark.parametrize("tile", [0, 7])
+def test_lost_lora_producer_raises_instead_of_trapping(tile):
     """In-launch LoRA whose producers never publish (probing bit: they exit at once, the flags still hold an old epoch): every tile waits its 2 s, raises
     the launch's error word and finishes; the host turns the word into NativeError, and the process's HIP context survives (the next launch is correct).
-    Round-4 review: a `__builtin_trap()` sat here and killed the context of a serving process."""
+    Round-4 review: a `__builtin_trap()` sat here and killed the context of a serving process.  tile 7: the same on the 8-wave loop, whose hand-over comes from t-tiles."""
     from refiners_amd import native
 
     lib = native.load()
     lib.mi355x_set_option(b"lora_dbg", 1)
     try:
-        kernel_cases.gemm_lora_inlaunch_case(256, 256, 256, torch.bfloat16)
+        kernel_cases.gemm_lora_inlaunch_case(256, 256, 256, torch.bfloat16, tile=tile)
         torch.cuda.synchronize()
     except AssertionError:
         pass  # (the output of a launch that lost its hand-over is undefined: the case's own non-finite check may fire)
@@ -52,7 +53,7 @@ def test_lost_lora_producer_raises_instead_of_trapping():
     with pytest.raises(native.NativeError):
         for ls in native._eager_sync.values():
             ls.check()
-    err, scale, tol = kernel_cases.gemm_lora_inlaunch_case(256, 256, 256, torch.bfloat16)  # the context is alive and the next launch is right
+    err, scale, tol = kernel_cases.gemm_lora_inlaunch_case(256, 256, 256, torch.bfloat16, tile=tile)  # the context is alive and the next launch is right
     assert err <= tol * scale + 1e-7
     for ls in native._eager_sync.values():
         ls.check()
