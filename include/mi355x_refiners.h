@@ -117,7 +117,9 @@ typedef struct {
                                workgroup one barrier apart): the large-grid shapes;  8: the same loop as a persistent "stream-K" launch -- one
                                workgroup per CU, each taking an equal share of (output tiles x K tiles), partial tiles summed in a fixed order
                                through sk_ws -- for launches whose 256x256 tiles do not fill a whole number of rounds (needs sk_ws / sk_flags;
-                               falls back to 7 without them).  In-launch LoRA on this loop: ONE column group of a plain one-segment GEMM without out_t,
+                               falls back to 7 without them);  9: the same loop on 192x256 tiles (wave tile 96x64), whole tiles only and no transposed
+                               part: for launches whose 256-row tiles leave CUs idle in their only round (M = 8192, N = 1280: 160 tiles / 215).
+                               In-launch LoRA on this loop: ONE column group of a plain one-segment GEMM without out_t,
                                as whole tiles (8 with LoRA runs as 7) -- t = x A^T comes from "t-tiles" at the head of the grid (the same loop with
                                the stacked down rows in the weight slot), every tile adds (t)(s B)^T after its K loop.  7 / 8 do not combine with
                                other in-launch LoRA forms (several groups, out_t, conv), a column group transposed from a column that is not a

@@ -61,13 +61,14 @@ extern "C" int mi355x_set_option(const char* name, int value) {
     return MI355X_EARG;
 }
 
-static int g_stat_g8 = 0, g_stat_g8_lora = 0;
+static int g_stat_g8 = 0, g_stat_g8_lora = 0, g_stat_g9 = 0;
 extern "C" int mi355x_get_stat(const char* name);
 extern "C" int mi355x_get_stat(const char* name) {
     // launches since the library was loaded (tests: did the configuration asked for really run?); like mi355x_set_option not part of the stable contract
-    //   "g8" = launches on the 8-wave loop (tile configurations 7 / 8), "g8lora" = those of them with the in-launch LoRA
+    //   "g8" = launches on the 8-wave loop (tile configurations 7 / 8 / 9), "g8lora" = those of them with the in-launch LoRA, "g9" = those on 192-row tiles
     if (!name) return MI355X_EARG;
     if (name[0] == 'g' && name[1] == '8') return name[2] == 'l' ? g_stat_g8_lora : g_stat_g8;
+    if (name[0] == 'g' && name[1] == '9') return g_stat_g9;
     return MI355X_EARG;
 }
 
@@ -239,15 +240,17 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tile_req = g_tile ? g_tile : a->tile;
-    if ((tile_req == 7 || tile_req == 8) && gemm8_ok(p, a->conv != 0)) {  // the 256 x 256 tile on the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
+    const int g8_mt = tile_req == 9 ? 6 : 8;  // tile 9: the same loop on 192 x 256 tiles (whole tiles only)
+    if ((tile_req == 7 || tile_req == 8 || tile_req == 9) && gemm8_ok(p, a->conv != 0, g8_mt)) {  // the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
         ++g_stat_g8;
         if (p.lora_b) ++g_stat_g8_lora;
+        if (g8_mt == 6) ++g_stat_g9;
         const bool sk = tile_req == 8 && a->sk_ws && a->sk_flags && a->sk_slots > 0 && (reinterpret_cast<uintptr_t>(a->sk_ws) & 15) == 0;
         p.sk_ws = static_cast<float*>(a->sk_ws);
         p.sk_flags = a->sk_flags;
         p.sk_cap = a->sk_slots;
-        if (a->conv) return a->dtype == MI355X_F32 ? launch_conv8_f32(p, st, sk) : launch_conv8_bf16(p, st, sk);
-        return a->dtype == MI355X_F32 ? launch_gemm8_f32(p, st, sk) : launch_gemm8_bf16(p, st, sk);
+        if (a->conv) return a->dtype == MI355X_F32 ? launch_conv8_f32(p, st, sk, g8_mt) : launch_conv8_bf16(p, st, sk, g8_mt);
+        return a->dtype == MI355X_F32 ? launch_gemm8_f32(p, st, sk, g8_mt) : launch_gemm8_bf16(p, st, sk, g8_mt);
     }
     if (a->conv) return a->dtype == MI355X_F32 ? launch_conv_f32(p, st) : launch_conv_bf16(p, st);
     if (a->dtype == MI355X_F32) return launch_tile<float, false>(p, st);

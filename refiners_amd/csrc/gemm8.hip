@@ -3,8 +3,8 @@
 #include "gemm8_kernel.cuh"
 
 namespace mi355x {
-int launch_gemm8_f32(const GemmP& p, hipStream_t stream, bool streamk) { return launch_gemm8<float, false>(p, stream, streamk); }
-int launch_gemm8_bf16(const GemmP& p, hipStream_t stream, bool streamk) { return launch_gemm8<bf16_t, false>(p, stream, streamk); }
-int launch_conv8_f32(const GemmP& p, hipStream_t stream, bool streamk) { return launch_gemm8<float, true>(p, stream, streamk); }
-int launch_conv8_bf16(const GemmP& p, hipStream_t stream, bool streamk) { return launch_gemm8<bf16_t, true>(p, stream, streamk); }
+int launch_gemm8_f32(const GemmP& p, hipStream_t stream, bool streamk, int mt) { return launch_gemm8<float, false>(p, stream, streamk, mt); }
+int launch_gemm8_bf16(const GemmP& p, hipStream_t stream, bool streamk, int mt) { return launch_gemm8<bf16_t, false>(p, stream, streamk, mt); }
+int launch_conv8_f32(const GemmP& p, hipStream_t stream, bool streamk, int mt) { return launch_gemm8<float, true>(p, stream, streamk, mt); }
+int launch_conv8_bf16(const GemmP& p, hipStream_t stream, bool streamk, int mt) { return launch_gemm8<bf16_t, true>(p, stream, streamk, mt); }
 }  // namespace mi355x

@@ -109,17 +109,22 @@ template <int NTHR_ALL> MI_DEV void prefetch_role(const GemmP& p, int tid_all) {
 #define MI355X_G8_PRIO 1  // s_setprio 1 around every MFMA cluster (guide T5: +21..39 % on this schedule)
 #endif
 
-template <typename T, bool CONV, bool LORA>
+template <typename T, bool CONV, bool LORA, int MT>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
-    constexpr int BM = 256, BN = 256, NTHR = 512, MT = 8, NT = 4;
+    // MT = 16-row blocks per wave: 8 = the 256 x 256 tile of the header; 6 = a 192 x 256 tile (wave tile 96 x 64, 12 MFMAs per phase) for launches whose 256-row tiles
+    // leave CUs idle in their only dispatch round (M = 8192, N = 1280: 160 tiles of 256 rows on 256 CUs, 215 of 192 rows).  Everything row-related below is written in
+    // WR = rows per wave row (128 / 96) and QR = rows of one X half tile per wave row (64 / 48); the W side does not change.
+    static_assert(MT == 8 || MT == 6, "wave tile rows");
+    constexpr int BM = 32 * MT, BN = 256, NTHR = 512, NT = 4, WR = 16 * MT, QR = 8 * MT, XW = QR / 8;  // XW = waves that stage an X half tile (8 rows each)
     constexpr int XB = BM * 128, BUFB = (BM + BN) * 128;  // bytes: X tile, one LDS buffer (X tile + W tile)
     constexpr uint32_t OOB = 0x80000000u;                  // per-lane offset beyond every descriptor's num_records: the load writes zeros
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // per-tile vectors of the epilogue, TWO sets used alternately by consecutive segments of a persistent workgroup: the waves that finish a tile's epilogue first
     // go on to the next tile's prologue (which writes the other set) without waiting for the rest -- they meet again at the prologue's own barrier
     float* const epi_lds = reinterpret_cast<float*>(smem + 2 * BUFB);
-    constexpr int EPI_SET = 2 * BM + 2 * BN;  // floats: rowstat [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer) | colvec [2][BN]: bias (as float32) or folded-LayerNorm s | c
+    constexpr int EPI_SET = 2 * 256 + 2 * BN;  // floats: rowstat [BM][2] (mean, rstd) of the tile's rows (LayerNorm consumer) | colvec [2][BN]: bias (as float32) or folded-LayerNorm s | c
     int epi_par = 0;
+    char* const spare = smem + 2 * BUFB + 2 * EPI_SET * 4;  // 2 KB nobody reads: where the two waves without X rows (MT = 6) let their zero-filling loads land
 
     const int tid0 = threadIdx.x, wid = wave_id();
     const int wm = wid >> 2, wn = wid & 3;
@@ -167,7 +172,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     auto bar = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_barrier(); };
     auto lgkm0 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    auto lgkm8 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); };
+    auto lgkm8 = [&]() __attribute__((always_inline)) {  // the X reads of the phase (MT: issued behind the four W reads) may stay outstanding, the W reads may not
+        if constexpr (MT == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    };
 
     int ts_n = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         float* rowstat = epi_lds + epi_par * EPI_SET;
-        float* colvec = rowstat + 2 * BM;
+        float* colvec = rowstat + 2 * 256;
         epi_par ^= 1;
         const int lane = tid & 63, g = lane >> 4, c16 = lane & 15;
         // ---- loader geometry.  Half tile (h), load (s): 128 rows x 8 chunks = 1024 pieces of 16 B = 2 loads x 512 threads; piece s * 512 + tid is
@@ -244,8 +252,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         const int xlane = 8 * wid + lr8, wlane = 64 * (wid >> 2) + 16 * ((wq >> 2) & 3) + 4 * (wq >> 4) + (wq & 3);
         const int ws_lim_eff = LORA && ttile ? p.lora_r : ws_lim;  // (t-tile: virtual column = rank)
         auto xrow = [&](int h, int s2) __attribute__((always_inline)) {
-            const int r = xs_0 + 128 * s2 + 64 * h + xlane;
-            return r < xs_lim ? r : -1;
+            const int r = xs_0 + WR * s2 + QR * h + xlane;
+            return r < xs_lim && (MT == 8 || wid < XW) ? r : -1;  // (MT = 6: waves 6 and 7 stage nothing real -- zeros into a spare LDS area)
         };
         auto wrow = [&](int h, int s2) __attribute__((always_inline)) {
             const int r = ws_0 + 128 * s2 + 8 * h + wlane;
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         };
         auto stage_x = [&](int h, int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) blds16(xrs, smem + buf * BUFB + (128 * s + 64 * h + 8 * wid) * 128, xvo[h][s], x_so);
+            for (int s = 0; s < 2; ++s) blds16(xrs, MT == 8 || wid < XW ? smem + buf * BUFB + (WR * s + QR * h + 8 * wid) * 128 : spare + (wid - XW) * 1024, xvo[h][s], x_so);
         };
         auto stage_w = [&](int h, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -378,12 +386,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         };
 
         // ---- fragments ----
-        frag_t xf[4][2];     // X quadrant rows: [16-row block][K half]
+        frag_t xf[MT / 2][2];  // X quadrant rows: [16-row block][K half]
         frag_t wf[2][2][2];  // W halves: [h][16-row block][K half]
         auto read_x = [&](int h, int buf) __attribute__((always_inline)) {
-            const char* xs = smem + buf * BUFB + (128 * wm + 64 * h) * 128;
+            const char* xs = smem + buf * BUFB + (WR * wm + QR * h) * 128;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT / 2; ++i)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) xf[i][kk] = lds_read_frag(xs, i * 2048 + fo[kk]);
         };
@@ -399,9 +407,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MT / 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) mma_step<T>(acc[4 * hx + i][2 * hw + j], wf[hw][j][kk], xf[i][kk]);
+                    for (int j = 0; j < 2; ++j) mma_step<T>(acc[(MT / 2) * hx + i][2 * hw + j], wf[hw][j][kk], xf[i][kk]);
         };
         // the compute half of a phase: barrier | the fragments have arrived | 16 MFMA at raised priority | barrier
         auto compute = [&](auto hxc, auto hwc, bool reads) __attribute__((always_inline)) {
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             stage_w(1, 1);
             adv_w();
         }
-        if (p.ln_stats && owner) ln_rowstat<BM, NTHR>(p, m0, tid, rowstat);
+        if (p.ln_stats && owner) ln_rowstat<256, NTHR>(p, m0, tid, rowstat);  // (256 rows whatever the tile: two threads per row; a 192-row tile's last 64 are the next tile's, unused)
         if (owner && !(LORA && ttile) && tid < BN && (p.ln_stats || p.bias)) {  // per-column vectors of the tile -> LDS (read by the epilogue: see tile_epilogue's colvec)
             const int n = min(n0 + tid, p.N - 1);
             if (p.ln_stats) {
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             // ---- LoRA tail of an output tile: acc += T(t) (s B)^T, 32 ranks per step ----
             const int nfl = (pe->M + 31) / 32, lora_tag = *pe->lora_epoch;
             if (!ttile) {  // this wave's four row blocks: lanes 0..3 poll one flag each (relaxed agent-scope loads bypass the CU's L1), bounded by the wall clock
-                const int fb = (m0 + 128 * wm) / 32 + (lane_e & 3);
+                const int fb = (m0 + WR * wm) / 32 + min(lane_e & 3, WR / 32 - 1);
                 const int* fp = pe->lora_flags + (fb < nfl ? fb : nfl - 1);
                 const uint64_t t0 = wall_clock64();
                 while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lora_tag) {
@@ -606,7 +614,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
                 frag_t tfr[MT][KS32], bfr[NT][KS32];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int m = min(m0 + 128 * wm + 16 * i + ce, pe->M - 1);
+                    const int m = min(m0 + WR * wm + 16 * i + ce, pe->M - 1);
 #pragma unroll
                     for (int ks = 0; ks < KS32; ++ks)
                         tfr[i][ks] = *reinterpret_cast<const frag_t*>(pe->lora_t + (int64_t)m * rb + c * 32 * (int)sizeof(T) + (4 * ks + ge) * 16);
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
                 char* tg = pe->lora_t;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int mrow = 128 * wm + 16 * i + ce, m = m0 + mrow;
+                    const int mrow = WR * wm + 16 * i + ce, m = m0 + mrow;
                     if (m >= pe->M) continue;
                     float v[16];
 #pragma unroll
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
             __syncthreads();
             const int nfl = (pe->M + 31) / 32;
-            if (tid < 8 && m0 / 32 + tid < nfl) __hip_atomic_store(pe->lora_flags + m0 / 32 + tid, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < BM / 32 && m0 / 32 + tid < nfl) __hip_atomic_store(pe->lora_flags + m0 / 32 + tid, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         if constexpr ((MI355X_G8_ABL & 1) != 0) {
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
         } else if constexpr (!CONV) {
-            if (tr) {  // the transposed tile's blocks: 4 x 8 over (activation rows of wave column wn, weight rows of wave row wm)
+            if (MT == 8 && tr) {  // the transposed tile's blocks: 4 x 8 over (activation rows of wave column wn, weight rows of wave row wm)  (256-row tiles only: gemm8_ok)
                 f32x4 at[NT][MT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -703,11 +711,11 @@ extern int g_sk_g;        // probing: number of stream-K / persistent workgroups
 extern int g_lora_dbg;    // probing bits of the in-launch LoRA (gemm.hip; bit 0 = the hand-over's producers exit at once)
 extern int g_g8_persist;  // 1 = launches with more tiles than CUs run as one persistent workgroup per CU
 
-template <typename T, bool CONV, bool LORA>
+template <typename T, bool CONV, bool LORA, int MT>
 int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
-    constexpr int LDS = 2 * (256 + 256) * 128 + 2 * (256 * 8 + 2 * 256 * 4);  // two stage buffers + two sets of epilogue vectors
+    constexpr int LDS = 2 * (32 * MT + 256) * 128 + 2 * (256 * 8 + 2 * 256 * 4) + 2048;  // two stage buffers + two sets of epilogue vectors + the spare landing area
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kfn = gemm8_kernel<T, CONV, LORA>;
+    auto kfn = gemm8_kernel<T, CONV, LORA, MT>;
     static bool attr_set[64] = {};
     static int n_cu[64] = {};
     int dev = 0;
@@ -718,7 +726,7 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
         attr_set[dev] = true;
     }
     GemmP q = p;
-    plan_grid(q, 256, 256, CONV, 2);
+    plan_grid(q, 32 * MT, 256, CONV, 2);
     q.lora_dbg = g_lora_dbg & 1;  // (mi355x_set_option "lora_dbg"; the other probing bits belong to the 4-wave kernel's producers)
     q.lora_tt = 1;
     q.lp_blocks = q.lora_b ? (q.tiles_m + 7) / 8 * 8 : 0;  // t-tiles: one per row tile, padded to a multiple of 8 (tile b stays on XCD b % 8)
@@ -773,16 +781,19 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
 }
 
 template <typename T, bool CONV>
-int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk) {
+int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk, int mt) {  // mt: 8 = 256-row tiles (tile ids 7 / 8), 6 = 192-row tiles (tile id 9)
     if constexpr (!CONV) {
-        if (p.lora_b) return launch_gemm8_impl<T, false, true>(p, stream, streamk);  // (its own instance: the LoRA roles cost the plain one registers it does not have)
+        if (p.lora_b) {  // (its own instance: the LoRA roles cost the plain one registers it does not have)
+            return mt == 6 ? launch_gemm8_impl<T, false, true, 6>(p, stream, false) : launch_gemm8_impl<T, false, true, 8>(p, stream, streamk);
+        }
     }
-    return launch_gemm8_impl<T, CONV, false>(p, stream, streamk);
+    return mt == 6 ? launch_gemm8_impl<T, CONV, false, 6>(p, stream, false) : launch_gemm8_impl<T, CONV, false, 8>(p, stream, streamk);
 }
 
 // Can this launch run on the 8-phase loop?  (No in-launch LoRA, no split-K workspace protocol, transposed column groups from a multiple of 256; every operand below
 // 2 GB: 32-bit buffer offsets with 0x80000000 as the out-of-range marker.)
-inline bool gemm8_ok(const GemmP& p, bool conv = false) {
+inline bool gemm8_ok(const GemmP& p, bool conv = false, int mt = 8) {
+    if (mt == 6 && p.out_t) return false;  // (the 192-row tile has no transposed form)
     if (p.ksplit > 1 || !p.vec_ok || p.N % 16) return false;  // (the epilogue instances of this loop are the vectorised ones)
     if (p.lora_b && (conv || p.lora_groups != 1 || p.nseg != 1 || p.out_t || p.lora_r % 32 || p.lora_r > 256 || !p.lora_t || !p.lora_flags || !p.lora_epoch)) return false;  // in-launch LoRA here: one column group of a plain GEMM
     if (p.out_t && p.nt_begin % 256) return false;  // a tile is either stored row-major or transposed
@@ -791,9 +802,9 @@ inline bool gemm8_ok(const GemmP& p, bool conv = false) {
     return true;
 }
 
-int launch_gemm8_f32(const GemmP& p, hipStream_t stream, bool streamk);
-int launch_gemm8_bf16(const GemmP& p, hipStream_t stream, bool streamk);
-int launch_conv8_f32(const GemmP& p, hipStream_t stream, bool streamk);
-int launch_conv8_bf16(const GemmP& p, hipStream_t stream, bool streamk);
+int launch_gemm8_f32(const GemmP& p, hipStream_t stream, bool streamk, int mt);
+int launch_gemm8_bf16(const GemmP& p, hipStream_t stream, bool streamk, int mt);
+int launch_conv8_f32(const GemmP& p, hipStream_t stream, bool streamk, int mt);
+int launch_conv8_bf16(const GemmP& p, hipStream_t stream, bool streamk, int mt);
 
 }  // namespace mi355x

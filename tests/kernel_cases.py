@@ -803,6 +803,28 @@ def on_g8_lora(fn, launches=1):
     return e
 
 
+def on_g8(fn, launches=1):
+    """Run a case and require that at least `launches` of its launches ran on the 8-wave loop (any of its tile ids) instead of falling back: mi355x_get_stat("g8")."""
+    lib = native.load()
+    lib.mi355x_get_stat.argtypes = [__import__("ctypes").c_char_p]
+    n0 = lib.mi355x_get_stat(b"g8")
+    e = fn()
+    n1 = lib.mi355x_get_stat(b"g8")
+    assert n1 - n0 >= launches, f"expected {launches} launches on the 8-wave loop, saw {n1 - n0}"
+    return e
+
+
+def on_tile9(fn, launches=1):
+    """Run a case and require that at least `launches` of its launches ran the 8-wave loop on 192-row tiles (mi355x_get_stat("g9")) instead of falling back."""
+    lib = native.load()
+    lib.mi355x_get_stat.argtypes = [__import__("ctypes").c_char_p]
+    n0 = lib.mi355x_get_stat(b"g9")
+    e = fn()
+    n1 = lib.mi355x_get_stat(b"g9")
+    assert n1 - n0 >= launches, f"expected {launches} launches on 192-row tiles, saw {n1 - n0}"
+    return e
+
+
 def gemm_qkv_lora_case(M, K, Cc, dtype, tile=0, seed=270):
     """Q | K | V^T from one launch with a different LoRA set per column group."""
     x = _rand(M, K, dtype=dtype, seed=seed)
@@ -1109,25 +1131,53 @@ def all_cases():
         kt = 128 // (4 if dt == torch.float32 else 2)  # elements per K tile
         for tile in (7, 8):
             for nkt in (1, 2, 3, 4, 5, 8):
-                cases.append((f"gemm_{tag}_tile{tile}_{nkt}ktiles", lambda dt=dt, tile=tile, nkt=nkt, kt=kt: gemm_tile_case(300, nkt * kt, 520, dt, tile, 0, seed=400 + nkt)))
+                cases.append((f"gemm_{tag}_tile{tile}_{nkt}ktiles", lambda dt=dt, tile=tile, nkt=nkt, kt=kt: on_g8(lambda: gemm_tile_case(300, nkt * kt, 528, dt, tile, 0, seed=400 + nkt), 2)))  # (N % 16 == 0: the loop's entry condition)
             cases += [
-                (f"gemm_{tag}_tile{tile}_2048x1280x1280_prefetch", lambda dt=dt, tile=tile: gemm_tile_case(2048, 1280, 1280, dt, tile, 0, prefetch=True)),
-                (f"gemm_{tag}_tile{tile}_many_tiles", lambda dt=dt, tile=tile: gemm_tile_case(4352, 256, 4608, dt, tile, 0, seed=410)),  # 17 x 18 = 306 tiles: more than CUs
-                (f"gemm_{tag}_tile{tile}_long_k_few_tiles", lambda dt=dt, tile=tile: gemm_tile_case(512, 5120, 768, dt, tile, 0, seed=411)),
-                (f"gemm_{tag}_tile{tile}_two_segments", lambda dt=dt, tile=tile: gemm_multiseg_case(600, 640, 320 + 64, 520, dt, tile)),
-                (f"gemm_{tag}_tile{tile}_geglu", lambda dt=dt, tile=tile: gemm_geglu_case(1024, 640, 2560, dt, tile=tile)),
-                (f"gemm_{tag}_tile{tile}_qkv", lambda dt=dt, tile=tile: gemm_qkv_case(1000, 640, 640, dt, tile=tile, bias=True, pad=32, seed=431)),
-                (f"gemm_{tag}_tile{tile}_qkv_2048x1280", lambda dt=dt, tile=tile: gemm_qkv_case(2048, 1280, 1280, dt, tile=tile)),
-                (f"gemm_{tag}_tile{tile}_t_only_ragged", lambda dt=dt, tile=tile: gemm_t_only_case(77 * 2, 2048, 640, dt, tile=tile)),
-                (f"gemm_{tag}_tile{tile}_ln_chain", lambda dt=dt, tile=tile: gemm_ln_chain_case(1000, 640, 640, dt, tile1=tile, tile2=tile)),
-                (f"gemm_{tag}_tile{tile}_ln_chain_geglu", lambda dt=dt, tile=tile: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile1=1, tile2=tile)),
-                (f"gemm_{tag}_tile{tile}_ln_chain_transposed", lambda dt=dt, tile=tile: gemm_ln_chain_case(1024, 1280, 1280, dt, transposed=True, tile1=tile, tile2=tile)),
-                (f"colstats_{tag}_tile{tile}", lambda dt=dt, tile=tile: colstats_case(600, 384, 640, dt, tile=tile)),
-                (f"colstats_{tag}_tile{tile}_edge_rows", lambda dt=dt, tile=tile: colstats_case(96, 256, 320, dt, tile=tile)),
-                (f"conv_{tag}_tile{tile}", lambda dt=dt, tile=tile: conv_tile_case(2, 320, 384, 16, 24, dt, tile, 0)),
-                (f"conv_{tag}_tile{tile}_odd_taps", lambda dt=dt, tile=tile: conv_tile_case(1, 64, 320, 40, 24, dt, tile, 0, seed=221)),
-                (f"conv_gn_{tag}_tile{tile}", lambda dt=dt, tile=tile: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt, tile=tile)),
+                (f"gemm_{tag}_tile{tile}_2048x1280x1280_prefetch", lambda dt=dt, tile=tile: on_g8(lambda: gemm_tile_case(2048, 1280, 1280, dt, tile, 0, prefetch=True))),
+                (f"gemm_{tag}_tile{tile}_many_tiles", lambda dt=dt, tile=tile: on_g8(lambda: gemm_tile_case(4352, 256, 4608, dt, tile, 0, seed=410))),  # 17 x 18 = 306 tiles: more than CUs
+                (f"gemm_{tag}_tile{tile}_long_k_few_tiles", lambda dt=dt, tile=tile: on_g8(lambda: gemm_tile_case(512, 5120, 768, dt, tile, 0, seed=411))),
+                (f"gemm_{tag}_tile{tile}_two_segments", lambda dt=dt, tile=tile: on_g8(lambda: gemm_multiseg_case(600, 640, 320 + 64, 528, dt, tile))),
+                (f"gemm_{tag}_tile{tile}_geglu", lambda dt=dt, tile=tile: on_g8(lambda: gemm_geglu_case(1024, 640, 2560, dt, tile=tile))),
+                (f"gemm_{tag}_tile{tile}_qkv", lambda dt=dt, tile=tile: on_g8(lambda: gemm_qkv_case(1000, 640, 640, dt, tile=tile, bias=True, pad=32, seed=431))),
+                (f"gemm_{tag}_tile{tile}_qkv_2048x1280", lambda dt=dt, tile=tile: on_g8(lambda: gemm_qkv_case(2048, 1280, 1280, dt, tile=tile))),
+                (f"gemm_{tag}_tile{tile}_t_only_ragged", lambda dt=dt, tile=tile: on_g8(lambda: gemm_t_only_case(77 * 2, 2048, 640, dt, tile=tile))),
+                (f"gemm_{tag}_tile{tile}_ln_chain", lambda dt=dt, tile=tile: on_g8(lambda: gemm_ln_chain_case(1000, 640, 640, dt, tile1=tile, tile2=tile))),
+                (f"gemm_{tag}_tile{tile}_ln_chain_geglu", lambda dt=dt, tile=tile: on_g8(lambda: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile1=1, tile2=tile))),
+                (f"gemm_{tag}_tile{tile}_ln_chain_transposed", lambda dt=dt, tile=tile: on_g8(lambda: gemm_ln_chain_case(1024, 1280, 1280, dt, transposed=True, tile1=tile, tile2=tile))),
+                (f"colstats_{tag}_tile{tile}", lambda dt=dt, tile=tile: on_g8(lambda: colstats_case(600, 384, 640, dt, tile=tile))),
+                (f"colstats_{tag}_tile{tile}_edge_rows", lambda dt=dt, tile=tile: on_g8(lambda: colstats_case(96, 256, 320, dt, tile=tile))),
+                (f"conv_{tag}_tile{tile}", lambda dt=dt, tile=tile: on_g8(lambda: conv_tile_case(2, 320, 384, 16, 24, dt, tile, 0))),
+                (f"conv_{tag}_tile{tile}_odd_taps", lambda dt=dt, tile=tile: on_g8(lambda: conv_tile_case(1, 64, 320, 40, 24, dt, tile, 0, seed=221))),
+                (f"conv_gn_{tag}_tile{tile}", lambda dt=dt, tile=tile: on_g8(lambda: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt, tile=tile))),
             ]
+        # tile 9: the 8-wave loop on 192 x 256 tiles (wave tile 96 x 64; two of the eight waves stage no activation rows): K tile counts around the peel points, ragged
+        # M (not a multiple of 192, of 96, of 32) and N, more tiles than CUs (persistent), every epilogue kind, K-blocked operands, two K segments, convolutions, LoRA
+        for nkt in (1, 2, 3, 4, 5, 8):
+            cases.append((f"gemm_{tag}_tile9_{nkt}ktiles", lambda dt=dt, nkt=nkt, kt=kt: on_tile9(lambda: gemm_tile_case(300, nkt * kt, 528, dt, 9, 0, seed=500 + nkt), 2)))
+        cases += [
+            (f"gemm_{tag}_tile9_2048x1280x1280_prefetch", lambda dt=dt: gemm_tile_case(2048, 1280, 1280, dt, 9, 0, prefetch=True)),
+            (f"gemm_{tag}_tile9_8192x256x1280_one_round", lambda dt=dt: on_tile9(lambda: gemm_tile_case(8192, 256, 1280, dt, 9, 0, seed=509))),  # 43 x 5 = 215 tiles
+            (f"gemm_{tag}_tile9_many_tiles", lambda dt=dt: gemm_tile_case(4352, 256, 4608, dt, 9, 0, seed=510)),  # 23 x 18 = 414 tiles: more than CUs
+            (f"gemm_{tag}_tile9_ragged_rows", lambda dt=dt: gemm_tile_case(193 + 96 + 17, 320, 272, dt, 9, 0, seed=512)),
+            (f"gemm_{tag}_tile9_long_k_few_tiles", lambda dt=dt: gemm_tile_case(512, 5120, 768, dt, 9, 0, seed=511)),
+            (f"gemm_{tag}_tile9_two_segments", lambda dt=dt: on_tile9(lambda: gemm_multiseg_case(600, 640, 320 + 64, 528, dt, 9))),
+            (f"gemm_{tag}_tile9_geglu", lambda dt=dt: on_tile9(lambda: gemm_geglu_case(1024, 640, 2560, dt, tile=9))),
+            (f"gemm_{tag}_tile9_ln_chain", lambda dt=dt: gemm_ln_chain_case(1000, 640, 640, dt, tile1=9, tile2=9)),
+            (f"gemm_{tag}_tile9_ln_chain_geglu", lambda dt=dt: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile1=1, tile2=9)),
+            (f"gemm_{tag}_tile9_qkv_falls_back", lambda dt=dt: gemm_qkv_case(1000, 640, 640, dt, tile=9, bias=True, pad=32, seed=531)),  # (a transposed part: not on this tile)
+            (f"colstats_{tag}_tile9", lambda dt=dt: on_tile9(lambda: colstats_case(600, 384, 640, dt, tile=9))),
+            (f"colstats_{tag}_tile9_edge_rows", lambda dt=dt: colstats_case(96, 256, 320, dt, tile=9)),
+            (f"conv_{tag}_tile9", lambda dt=dt: on_tile9(lambda: conv_tile_case(2, 320, 384, 16, 24, dt, 9, 0))),
+            (f"conv_{tag}_tile9_odd_taps", lambda dt=dt: conv_tile_case(1, 64, 320, 40, 24, dt, 9, 0, seed=521)),
+            (f"conv_gn_{tag}_tile9", lambda dt=dt: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt, tile=9)),
+            (f"conv_{tag}_tile9_s2_ups_shortcut", lambda dt=dt: conv_forced_tile_case(dt, 9)),
+            (f"gemm_{tag}_tile9_lora1_2048x1280x1280", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, tile=9), 2)),
+            (f"gemm_{tag}_tile9_lora1_rank8_edges", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(300, 640, 208, dt, ranks=(8,), tile=9), 2)),
+            (f"gemm_{tag}_tile9_lora1_rank128", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, ranks=(128,), tile=9), 2)),
+            (f"gemm_{tag}_tile9_lora1_geglu", lambda dt=dt: on_tile9(lambda: on_g8_lora(lambda: gemm_lora_inlaunch_case(512, 640, 2560, dt, geglu=True, tile=9)))),
+            (f"gemm_{tag}_tile9_ln_lora_edges", lambda dt=dt: on_g8_lora(lambda: gemm_ln_lora_case(300, 640, 384, dt, tile=9))),
+            (f"gemm_{tag}_tile9_lora1_repeat_shared_scratch", lambda dt=dt: on_g8_lora(lambda: gemm_lora_repeat_case(1024, 640, 1280, dt, tiles=(9, 1, 7, 9)), 9)),
+        ]
         # the in-launch LoRA on the 8-wave loop (one column group of a plain GEMM; everything else keeps the 4-wave kernel's producers)
         cases += [
             (f"gemm_{tag}_tile7_lora1_2048x1280x1280", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, tile=7), 2)),

@@ -20,6 +20,8 @@ def test_tile_table_fallbacks(monkeypatch):
                                            "conv:bf16:8x8x72:s1:": (8, 0), "gemm:bf16:8x8x16:s2:": (7, 0)})
     assert tuning.lookup("gemm:bf16:8x8x8:s1:geglulnlora") == (7, 0)
     assert tuning.lookup("gemm:bf16:8x8x8:s1:stlora") == (7, 0)
+    monkeypatch.setitem(tuning._table, "gemm:bf16:8x8x8:s1:ln", (9, 0))
+    assert tuning.lookup("gemm:bf16:8x8x8:s1:lnlora") == (9, 0)  # (the 192-row tile of the same loop has the LoRA instance too)
     assert tuning.lookup("gemm:bf16:8x24x8:s1:T16lnlora") == (1, 2)  # a transposed column group (Q | K | V^T: three LoRA groups): the 4-wave kernel
     assert tuning.lookup("conv:bf16:8x8x72:s1:lora") == (1, 2)
     assert tuning.lookup("gemm:bf16:8x8x16:s2:lora") == (1, 2)
@@ -32,9 +34,10 @@ def test_tile_table_fallbacks(monkeypatch):
 def test_the_shipped_table_only_names_tiles_the_library_has():
     doc = json.loads(tuning.TABLE_PATH.read_text())
     for sig, (tile, stages) in doc["choices"].items():
-        assert tile in (0, 1, 2, 3, 4, 6, 7, 8) and stages in (0, 2, 3, 4), (sig, tile, stages)  # (7 / 8: the 8-wave loop, whole tiles / stream-K)
+        assert tile in (0, 1, 2, 3, 4, 6, 7, 8, 9) and stages in (0, 2, 3, 4), (sig, tile, stages)  # (7 / 8 / 9: the 8-wave loop, whole 256-row tiles / stream-K / whole 192-row tiles)
+        assert not (tile == 9 and "T" in sig.rsplit(":", 1)[1]), sig  # (the 192-row tile has no transposed form)
         if sig.endswith("lora"):
-            assert (tile in (1, 2, 3, 4) and stages == 2) or (tile == 7 and sig.startswith("gemm") and ":s1:" in sig and "T" not in sig.split(":")[-1]), sig
+            assert (tile in (1, 2, 3, 4) and stages == 2) or (tile in (7, 9) and sig.startswith("gemm") and ":s1:" in sig and "T" not in sig.split(":")[-1]), sig
 
 
 def test_bench_quotes_the_latest_counter_pass_deterministically(tmp_path, monkeypatch):

@@ -35,10 +35,10 @@ def step_ms(ops, iters: int = 4, reps: int = 3) -> float:
 
 def candidates(a, only=None) -> list[tuple[int, int]]:
     out = []
-    if not a.lora_b and not (a.out_t and a.nt_begin % 256):  # the 8-wave / eight-phase loop: 7 = whole 256 x 256 tiles, 8 = stream-K
-        out += [(7, 0), (8, 0)]
+    if not a.lora_b and not (a.out_t and a.nt_begin % 256):  # the 8-wave / eight-phase loop: 7 = whole 256 x 256 tiles, 8 = stream-K, 9 = whole 192 x 256 tiles
+        out += [(7, 0), (8, 0)] + ([] if a.out_t else [(9, 0)])
     elif a.lora_b and not a.conv and a.lora_groups == 1 and a.nseg == 1 and not a.out_t:  # its in-launch LoRA: one column group of a plain GEMM, whole tiles
-        out += [(7, 0)]
+        out += [(7, 0), (9, 0)]
     if a.ksplit > 1:  # a launch the lowering split along K: only the 8-wave loop (which takes the whole K) is an alternative
         return [c for c in out if only is None or c[0] in only]
     for tile in (1, 2, 3, 4, 6):  # 128x128, 128x64, 64x128, 64x64 (4 waves); 6 = 128x128 with two K groups (8 waves)
@@ -110,7 +110,7 @@ def main() -> None:
         def apply(tile, st):
             for a in items:
                 a.tile, a.stages = tile, st
-                a.ksplit = 1 if tile in (7, 8) else ks0
+                a.ksplit = 1 if tile in (7, 8, 9) else ks0
                 if tile == 8:
                     native.attach_streamk(a, pipe.engine.low._sk)
 

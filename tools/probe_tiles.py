@@ -21,8 +21,11 @@ def set_tile(v, st=0):
 
 def main():
     shapes = [("FF1", 2048, 1280, 10240, True), ("QKV", 2048, 1280, 3840, False), ("FF2", 2048, 5120, 1280, False), ("proj", 2048, 1280, 1280, False),
-              ("FF1x4", 8192, 1280, 10240, True), ("QKVx4", 8192, 1280, 3840, False), ("640", 8192, 640, 640, False), ("4096^3", 4096, 4096, 4096, False)]
-    tiles = [(0, 0), (1, 2), (4, 2), (7, 0), (8, 0)]
+              ("FF1x4", 8192, 1280, 10240, True), ("QKVx4", 8192, 1280, 3840, False), ("640", 8192, 640, 640, False), ("4096^3", 4096, 4096, 4096, False),
+              ("projx4", 8192, 1280, 1280, False), ("FF2x4", 8192, 5120, 1280, False), ("640x4", 32768, 640, 640, False)]  # (N = 1280 at 4 images: 160 tiles of 256 rows, 215 of 192)
+    if "--n1280" in sys.argv:
+        shapes = shapes[-3:] + [s_ for s_ in shapes if s_[0] in ("FF1x4", "4096^3")]
+    tiles = [(0, 0), (1, 2), (4, 2), (7, 0), (8, 0), (9, 0)]
     for name, M, K, N, geglu in shapes:
         sets = []
         for _ in range(6):
