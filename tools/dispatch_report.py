@@ -30,6 +30,7 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "refiners_amd" / "csrc"
 TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 6: (128, 128)}
 CUS, LDS_CU, VGPR_SIMD = 256, 160 * 1024, 512
+G8_TILES = {7: (256, 256), 8: (256, 256), 9: (192, 256)}  # 8 = stream-K over the same tiles (every CU gets an equal share of (tiles x K tiles): balance 1 by construction)
 
 
 def kernel_resources(cache: Path) -> dict:
@@ -88,6 +89,14 @@ def analyse(cls: str, res: dict) -> dict | None:
         stages = 2
         if conv and tile not in (1, 3):
             tile = 3
+    if tile in G8_TILES:  # the 8-wave loop (csrc/gemm8_kernel.cuh): one workgroup per CU by construction (256 registers x 8 waves, 117-141 KB of LDS); its in-launch LoRA has t-tiles
+        BM, BN = G8_TILES[tile]
+        tiles = -(-M // BM) * -(-N // BN)
+        head, kind = (-(-(-(-M // BM)) // 8) * 8, "t-tiles") if lora else (0, "")
+        rounds = (tiles + head) / CUS
+        return {"class": cls, "tile": f"{BM}x{BN}" + ("*" if tuned else "") + (" stream-K" if tile == 8 else ""), "stages": 2, "vgpr": 256 if tile != 9 else 224, "lds_kb": round((2 * (BM + BN) * 128 + 10240) / 1024, 1),
+                "per_cu": 1, "tiles": tiles, "head": head, "head_kind": kind, "slots": CUS, "rounds": round(rounds, 3), "tiles_per_cu": tiles / CUS,
+                "balance": 1.0 if tile == 8 else tiles / CUS / math.ceil(tiles / CUS)}
     BM, BN = TILES[tile]
     KG = 2 if tile == 6 else 1
     key = f"{dt},{BM},{BN},{int(conv)},{stages},{KG},{int(lora)}"
