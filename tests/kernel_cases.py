@@ -7,6 +7,7 @@ Used by tests/test_kernels_gpu.py (pytest -m gpu) and tools/probe.py (first-cont
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import torch
@@ -791,38 +792,35 @@ def with_lora_source(bits, fn):
         lib.mi355x_set_option(b"lora_dbg", 0)
 
 
+def _launch_stat(name: bytes) -> int:
+    """mi355x_get_stat: launches since the library was loaded ("g8" = on the 8-wave loop, any tile id; "g8lora" = those with its in-launch LoRA; "g9" = those on 192-row tiles)."""
+    lib = native.load()
+    lib.mi355x_get_stat.argtypes = [ctypes.c_char_p]
+    return int(lib.mi355x_get_stat(name))
+
+
+def _on_path(stat: bytes, what: str, fn, launches: int):
+    n0 = _launch_stat(stat)
+    e = fn()
+    n1 = _launch_stat(stat)
+    assert n1 - n0 >= launches, f"expected {launches} launches {what}, saw {n1 - n0} (the launch fell back to another kernel)"
+    return e
+
+
 def on_g8_lora(fn, launches=1):
     """Run a case and require that at least `launches` of its launches took the in-launch LoRA on the 8-wave loop (csrc/gemm8_kernel.cuh: t-tiles at the head of
-    the grid, the up-projection as every tile's tail) rather than falling back to the 4-wave kernel: mi355x_get_stat("g8lora")."""
-    lib = native.load()
-    lib.mi355x_get_stat.argtypes = [__import__("ctypes").c_char_p]
-    n0 = lib.mi355x_get_stat(b"g8lora")
-    e = fn()
-    n1 = lib.mi355x_get_stat(b"g8lora")
-    assert n1 - n0 >= launches, f"expected {launches} LoRA launches on the 8-wave loop, saw {n1 - n0}"
-    return e
+    the grid, the up-projection as every tile's tail) rather than falling back to the 4-wave kernel."""
+    return _on_path(b"g8lora", "with the in-launch LoRA of the 8-wave loop", fn, launches)
 
 
 def on_g8(fn, launches=1):
-    """Run a case and require that at least `launches` of its launches ran on the 8-wave loop (any of its tile ids) instead of falling back: mi355x_get_stat("g8")."""
-    lib = native.load()
-    lib.mi355x_get_stat.argtypes = [__import__("ctypes").c_char_p]
-    n0 = lib.mi355x_get_stat(b"g8")
-    e = fn()
-    n1 = lib.mi355x_get_stat(b"g8")
-    assert n1 - n0 >= launches, f"expected {launches} launches on the 8-wave loop, saw {n1 - n0}"
-    return e
+    """... ran on the 8-wave loop (any of its tile ids) instead of falling back."""
+    return _on_path(b"g8", "on the 8-wave loop", fn, launches)
 
 
 def on_tile9(fn, launches=1):
-    """Run a case and require that at least `launches` of its launches ran the 8-wave loop on 192-row tiles (mi355x_get_stat("g9")) instead of falling back."""
-    lib = native.load()
-    lib.mi355x_get_stat.argtypes = [__import__("ctypes").c_char_p]
-    n0 = lib.mi355x_get_stat(b"g9")
-    e = fn()
-    n1 = lib.mi355x_get_stat(b"g9")
-    assert n1 - n0 >= launches, f"expected {launches} launches on 192-row tiles, saw {n1 - n0}"
-    return e
+    """... ran the 8-wave loop on 192-row tiles."""
+    return _on_path(b"g9", "on 192-row tiles of the 8-wave loop", fn, launches)
 
 
 def gemm_qkv_lora_case(M, K, Cc, dtype, tile=0, seed=270):
