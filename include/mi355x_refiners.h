@@ -121,7 +121,7 @@ typedef struct {
                                part: for launches whose 256-row tiles leave CUs idle in their only round (M = 8192, N = 1280: 160 tiles / 215).
                                In-launch LoRA on this loop: ONE column group of a plain one-segment GEMM without out_t,
                                as whole tiles (8 with LoRA runs as 7) -- t = x A^T comes from "t-tiles" at the head of the grid (the same loop with
-                               the stacked down rows in the weight slot), every tile adds (t)(s B)^T after its K loop.  7 / 8 do not combine with
+                               the stacked down rows in the weight slot), every tile adds (t)(s B)^T after its K loop.  7 / 8 / 9 do not combine with
                                other in-launch LoRA forms (several groups, out_t, conv), a column group transposed from a column that is not a
                                multiple of 256, ksplit, or operands of 2 GB and more: such launches run on the library's own choice among 1..4 */
     int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
