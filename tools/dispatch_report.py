@@ -89,7 +89,7 @@ def analyse(cls: str, res: dict) -> dict | None:
         stages = 2
         if conv and tile not in (1, 3):
             tile = 3
-    if tile in G8_TILES:  # the 8-wave loop (csrc/gemm8_kernel.cuh): one workgroup per CU by construction (256 registers x 8 waves, 117-141 KB of LDS); its in-launch LoRA has t-tiles
+    if tile in G8_TILES:  # the 8-wave loop (csrc/gemm8_kernel.cuh): one workgroup per CU by construction (256 registers x 8 waves, 122-138 KB of LDS); its in-launch LoRA has t-tiles
         BM, BN = G8_TILES[tile]
         tiles = -(-M // BM) * -(-N // BN)
         head, kind = (-(-(-(-M // BM)) // 8) * 8, "t-tiles") if lora else (0, "")
