@@ -241,7 +241,18 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tile_req = g_tile ? g_tile : a->tile;
     const int g8_mt = tile_req == 9 ? 6 : 8;  // tile 9: the same loop on 192 x 256 tiles (whole tiles only)
-    if ((tile_req == 7 || tile_req == 8 || tile_req == 9) && gemm8_ok(p, a->conv != 0, g8_mt)) {  // the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
+    const bool want_g8 = tile_req == 7 || tile_req == 8 || tile_req == 9;
+    if (want_g8 && p.ksplit > 1) {
+        // a caller that split K for want of tiles AND asks for the 8-wave loop (native._fill_split: the measured table replaced a heuristic split): the loop needs
+        // no split (whole tiles or stream-K) -- take it unsplit where it can run, otherwise keep the split on the 128 x 128 tile of the 4-wave kernel
+        GemmP q = p;
+        q.ksplit = 1;
+        q.kb_per_split = 0;
+        q.partial = nullptr;
+        if (gemm8_ok(q, a->conv != 0, g8_mt)) p = q;
+        else p.tile_hint = 1;
+    }
+    if (want_g8 && gemm8_ok(p, a->conv != 0, g8_mt)) {  // the 8-wave / eight-phase loop (gemm8_kernel.cuh); otherwise the heuristic decides
         ++g_stat_g8;
         if (p.lora_b) ++g_stat_g8_lora;
         if (g8_mt == 6) ++g_stat_g9;

@@ -166,7 +166,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ x2, int64_t ldx2, int C1, int HW, int C, int G,
                                                            int nchunk, const float* __restrict__ part,
                                                            const T* __restrict__ gamma, float eps, float* __restrict__ tab) {
-    __shared__ float red[256 * 2];
+    __shared__ double red[256 * 2];  // (double all the way: the partials are pivoted sums over up to HW / 4 pixels each, and S2 - S1^2 / n below is a difference of large numbers)
     __shared__ float mean_c[256], m2_c[256];
     __shared__ float stat[2];
     const int g = blockIdx.x, b = blockIdx.y;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
     const bool on = j < L;
     const int c = g * cg + cl;
     const float n = (float)HW;
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
     if (on) {
         const f32x2* pp = reinterpret_cast<const f32x2*>(part) + ((int64_t)b * nchunk * C + c);
         int k = j;
@@ -198,14 +198,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const T* __restrict__ 
     red[t * 2 + 1] = s2;
     __syncthreads();
     if (on && j == 0) {
-        float a1 = 0.f, a2 = 0.f;
+        double a1 = 0.0, a2 = 0.0;
         for (int q = 0; q < L; ++q) {
             a1 += red[(cl + cg * q) * 2 + 0];
             a2 += red[(cl + cg * q) * 2 + 1];
         }
         const float piv = to_f32(c < C1 ? x[(int64_t)b * HW * ldx + c] : x2[(int64_t)b * HW * ldx2 + (c - C1)]);
-        mean_c[cl] = piv + a1 / n;
-        m2_c[cl] = fmaxf(a2 - a1 * a1 / n, 0.f);
+        mean_c[cl] = piv + (float)(a1 / (double)n);
+        m2_c[cl] = fmaxf((float)(a2 - a1 * a1 / (double)n), 0.f);
     }
     __syncthreads();
     if (t == 0) {
@@ -429,10 +429,12 @@ extern "C" int mi355x_layernorm(const mi355x_layernorm_args* a, void* stream) {
 }
 
 extern "C" int64_t mi355x_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C) {
-    // worst case over both dtypes: the smaller ppc (more chunks) wins, so take the max of the two
+    // worst case over both dtypes AND over every value of the "gnwgs" option (a probing switch that may be flipped after workspaces were sized:
+    // round-5 advisor): the smallest pixels-per-chunk gn_ppc can return is 4 pixel lanes' worth, whatever the workgroup target
     int64_t best = 0;
     for (int es = 2; es <= 4; es += 2) {
-        const int ppc = gn_ppc(B, HW, C, es);
+        const int nv = C * es / 16;
+        const int ppc = 4 * (nv >= 256 ? 1 : 256 / (nv > 0 ? nv : 1));
         const int64_t nchunk = (HW + ppc - 1) / ppc;
         const int64_t need = (int64_t)B * nchunk * C * 2 + (int64_t)B * C * 2;
         if (need > best) best = need;

@@ -60,8 +60,11 @@ def _weights_version(unet: Any, cache: Optional[dict] = None, epoch: Any = None)
 class Program:
     """A lowered launch list replayed directly the first time and as ONE HIP graph afterwards (every buffer is static)."""
 
-    def __init__(self, ops: list, use_graph: bool, weight_prefetch: Optional[bool] = None) -> None:
-        self.ops, self.use_graph = ops, use_graph
+    def __init__(self, ops: list, use_graph: bool, weight_prefetch: Optional[bool] = None, low: Any = None) -> None:
+        # `low`: the Lowering the launches came from.  Given, every run ends with a look at its hand-over error words (in-launch LoRA, stream-K):
+        # these programs -- text / image encoders, SAM -- run once per prompt or picture and their callers read the result next, so the host
+        # round trip costs nothing that is not paid anyway
+        self.ops, self.use_graph, self.low = ops, use_graph, low
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         if weight_prefetch is None:
             weight_prefetch = os.environ.get("REFINERS_AMD_WEIGHT_PREFETCH", "1") != "0"
@@ -70,14 +73,18 @@ class Program:
     def run(self) -> None:
         if self.use_graph and self.graph is not None:
             self.graph.replay()
-            return
-        native.replay(self.ops)  # also the warm-up: first-launch work (function attributes) must not be captured
-        if self.use_graph:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                native.replay(self.ops)
-            self.graph = g
+        else:
+            native.replay(self.ops)  # also the warm-up: first-launch work (function attributes) must not be captured
+            if self.use_graph:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    native.replay(self.ops)
+                self.graph = g
+        if self.low is not None:
+            bad = self.low.handover_pending()
+            if bad and bool((bad[0] if len(bad) == 1 else torch.stack(bad).any()).item()):
+                self.low.handover_raise()
 
 
 class CompiledUNet:
@@ -88,6 +95,7 @@ class CompiledUNet:
         self.lora_mode = lora_mode  # see Lowering.__init__
         self.weight_prefetch = os.environ.get("REFINERS_AMD_WEIGHT_PREFETCH", "1") != "0"
         self.cache = PackCache()
+        self.io_override: Optional[tuple[Tensor, Tensor]] = None  # (x, out) buffers owned by the caller instead of fresh ones (see _build)
         self.low: Optional[UNetLowering] = None
         self.io: Optional[UNetIO] = None
         self.key: Any = None
@@ -132,11 +140,12 @@ class CompiledUNet:
         dtype = self.unet.dtype
         assert dtype in (torch.float32, torch.bfloat16), f"the MI355X path computes in float32 or bfloat16, not {dtype}"
         B, _, H, W = x_shape
-        io = UNetIO(
-            x=torch.empty(tuple(x_shape), device=dev, dtype=dtype),
-            timestep=torch.empty(B, device=dev, dtype=torch.float32),
-            out=torch.empty(B, self._out_channels(), H, W, device=dev, dtype=dtype),
-        )
+        xbuf, obuf = self.io_override if self.io_override is not None else (None, None)  # CompiledSDXL's split CFG pair: halves of ONE 2n-row buffer
+        if xbuf is None:
+            xbuf = torch.empty(tuple(x_shape), device=dev, dtype=dtype)
+            obuf = torch.empty(B, self._out_channels(), H, W, device=dev, dtype=dtype)
+        assert tuple(xbuf.shape) == tuple(x_shape) and tuple(obuf.shape) == (B, self._out_channels(), H, W) and xbuf.is_contiguous() and obuf.is_contiguous() and xbuf.dtype == obuf.dtype == dtype
+        io = UNetIO(x=xbuf, timestep=torch.empty(B, device=dev, dtype=torch.float32), out=obuf)
         if got["pooled"] is not None:
             io.pooled = torch.empty(B, got["pooled"].shape[1], device=dev, dtype=dtype)
             io.time_ids = torch.empty(B, got["time_ids"].shape[1], device=dev, dtype=torch.float32)
@@ -254,6 +263,21 @@ class CompiledUNet:
     def run_prologue(self) -> None:
         assert self.low is not None
         native.replay(self.low.prologue)
+        self.check_handovers()  # once per prompt: a host round trip here is nothing next to the prologue's ~290 launches
+
+    CHECK_EVERY = 16  # replays of the step program between two looks at the hand-over error words (one stacked .any() + one host sync)
+
+    def check_handovers(self, every: int = 1) -> None:
+        """The in-launch LoRA hand-over and the stream-K collect are bounded waits: a tile that gives up after 2 s raises an error word in device
+        memory and goes on with undefined operands (a trap would kill the process's HIP context).  Nothing on the device can raise into Python, so
+        the engine looks at those words at its host sync points -- after the prologue, every CHECK_EVERY-th step replay (`every`), at the end of a
+        sampling run -- and turns a raised word into NativeError (round-5 advisor: until round 6 only the tests looked)."""
+        self._replays = getattr(self, "_replays", 0) + 1
+        if self.low is None or self._replays % max(every, 1):
+            return
+        bad = self.low.handover_pending()
+        if bad and bool((bad[0] if len(bad) == 1 else torch.stack(bad).any()).item()):
+            self.low.handover_raise()
 
     def run_step(self) -> None:
         """Replay the per-step program (directly the first time, as a HIP graph afterwards)."""
@@ -279,6 +303,7 @@ class CompiledUNet:
             return self.unet(x)  # the stock child loop: reads the same context store, resets it itself (chain.py:245-257)
         if changed:
             self.run_prologue()
+        self.check_handovers(self.CHECK_EVERY)  # (looks at what the PREVIOUS replays left: no wait for this one)
         self.run_step()
         assert self.io is not None
         self.unet._reset_context()  # what Chain.forward does after running its children (chain.py:256)
@@ -298,11 +323,21 @@ class CompiledSDXL:
     tree's context store is not touched per step (the reference spends ~19 000 Python calls per step on it)."""
 
     def __init__(self, unet: Any, num_inference_steps: int = 50, condition_scale: float = 5.0, use_graph: bool = True, lora_mode: str = "fused",
-                 solver: Any = None) -> None:
+                 solver: Any = None, cfg_split: Optional[bool] = None) -> None:
         from ..latent_diffusion.sampling import DDIM
 
         self.unet = unet
         self.engine = CompiledUNet(unet, use_graph=False, lora_mode=lora_mode)
+        # cfg_split: the two halves of the classifier-free-guidance pair never meet before the guidance kernel (model.py:128-159 runs them as one
+        # batch only because that is one module call), so they are lowered as TWO batch-n programs and replayed on two streams -- two branches of
+        # the one captured HIP graph.  At one image per GPU every launch of the pair is short of workgroups (M = 2048 rows: 160 tiles on 256 CUs)
+        # and a third of the step is fill / epilogue / launch boundary; two independent launch sequences fill each other's gaps.
+        # None = REFINERS_AMD_CFG_SPLIT (default: see _split_wanted).  Self-Attention Guidance keeps the single program (its tap reads both halves).
+        self.cfg_split = cfg_split if cfg_split is not None else {"0": False, "1": True}.get(os.environ.get("REFINERS_AMD_CFG_SPLIT", ""), None)
+        self.engine_c: Optional[CompiledUNet] = None  # split mode: the conditional half (self.engine then runs the negative half)
+        self.pair_x: Optional[Tensor] = None  # split mode: [2n, C, H, W] model input / UNet output, halves owned by the two engines
+        self.pair_out: Optional[Tensor] = None
+        self.side_stream: Optional[torch.cuda.Stream] = None
         self.use_graph = use_graph
         self.coef_table: Optional[Tensor] = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -385,6 +420,116 @@ class CompiledSDXL:
         if self.coef_table is None or self.coef_table.device != x.device:
             self._tables(x.device)
 
+    # -- the CFG pair as two programs on two streams -----------------------------------------------------------------------------
+    # default policy: never.  Measured at one image per GPU (profiles/r06_a_ab_cfg_split.log, r06_b_ab_cfg_split_lead.log): 26.1 ms against 25.2-25.4 ms for the
+    # single program, with the tuning table's choices carried over to the halved shapes and with one half running 3 / 5 / 40 launches ahead of the other --
+    # two identical launch sequences pair equal kernels, and a launch that leaves CUs idle leaves them idle in both.  Kept as an option (and as the
+    # two-concurrent-programs test of the engine): `cfg_split=True` / REFINERS_AMD_CFG_SPLIT=1.
+    SPLIT_MAX_IMAGES = 0
+
+    def _split_wanted(self, n: int) -> bool:
+        if self._sag_adapter() is not None or self.x is None or self.x.device.type != "cuda":
+            return False
+        return self.cfg_split if self.cfg_split is not None else n <= self.SPLIT_MAX_IMAGES
+
+    def _split_got(self, got: dict[str, Any], n: int) -> tuple[dict[str, Any], dict[str, Any]]:
+        """[negative ; conditional] stacks -> (negative rows, conditional rows).  The views are made once per set_inputs: a fresh view per step
+        would look like a new prompt to the engines (_ident keys on id()) and re-run their prologues every step."""
+        cached = getattr(self, "_pair_halves", None)
+        if cached is None or cached[0] is not self.inputs:
+            def cut(t: Any, h: int) -> Any:
+                if t is None or t.shape[0] != 2 * n:  # ONE control picture / feature set for the whole batch broadcasts into both halves
+                    return t
+                return t[h * n : (h + 1) * n]
+
+            sides = []
+            for h in (0, 1):
+                sides.append({"pooled": cut(got["pooled"], h), "time_ids": cut(got["time_ids"], h), "tokens": {k: cut(v, h) for k, v in got["tokens"].items()},
+                              "conditions": {k: cut(v, h) for k, v in got["conditions"].items()},
+                              "t2i": {k: tuple(cut(f, h) for f in feats) for k, feats in got.get("t2i", {}).items()}})
+            cached = (self.inputs, sides)
+            self._pair_halves = cached
+        rest = {"timestep": got["timestep"], "timesteps_all": got.get("timesteps_all"), "step_index": got.get("step_index", 0)}
+        return {**rest, **cached[1][0]}, {**rest, **cached[1][1]}
+
+    def _prepare_pair(self, got: dict[str, Any], n: int) -> tuple[bool, bool]:
+        """Both halves lowered / staged; (negative prologue must run, conditional prologue must run).  Raises Unsupported like prepare_explicit."""
+        x = self.x
+        assert x is not None
+        eu = self.engine
+        if self.engine_c is None:
+            self.engine_c = CompiledUNet(self.unet, use_graph=False, lora_mode=eu.lora_mode)
+            self.engine_c.cache = eu.cache  # one set of packed weights for both programs
+        ec = self.engine_c
+        shape2 = (2 * n,) + tuple(x.shape[1:])
+        if self.pair_x is None or tuple(self.pair_x.shape) != shape2 or self.pair_x.device != x.device or self.pair_x.dtype != self.unet.dtype:
+            self.pair_x = torch.empty(shape2, device=x.device, dtype=self.unet.dtype)
+            self.pair_out = torch.empty((2 * n, eu._out_channels()) + tuple(x.shape[2:]), device=x.device, dtype=self.unet.dtype)
+            eu.key = ec.key = None  # the programs hold the old buffers' addresses
+        assert self.pair_out is not None
+        eu.io_override, ec.io_override = (self.pair_x[:n], self.pair_out[:n]), (self.pair_x[n:], self.pair_out[n:])
+        gu, gc = self._split_got(got, n)
+        shape1 = (n,) + tuple(x.shape[1:])
+        cu = eu.prepare_explicit(shape1, x.device, gu)
+        cc = ec.prepare_explicit(shape1, x.device, gc)
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=x.device)
+        return cu, cc
+
+    def _replay_pair(self) -> None:
+        """The conditional half on the side stream beside the negative half on the current one (under capture: two branches of the graph)."""
+        cur, side = torch.cuda.current_stream(), self.side_stream
+        assert side is not None and self.engine.low is not None and self.engine_c is not None and self.engine_c.low is not None
+        lead = int(os.environ.get("REFINERS_AMD_CFG_SPLIT_LEAD", "0"))  # launches the current stream's half runs ahead of the other (probing: two identical sequences in lockstep pair equal kernels)
+        ops = self.engine.low.step
+        if lead > 0:
+            native.replay(ops[:lead])
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            native.replay(self.engine_c.low.step)
+        native.replay(ops[lead:] if lead > 0 else ops)
+        cur.wait_stream(side)
+
+    def _split_step(self, step: int, got: dict[str, Any], n: int) -> Tensor:
+        from types import SimpleNamespace
+
+        try:
+            cu, cc = self._prepare_pair(got, n)
+        except Unsupported:
+            return self._stock_step(step, got)
+        eu, ec = self.engine, self.engine_c
+        assert ec is not None and self.x is not None
+        if cu:
+            eu.run_prologue()
+        if cc:
+            ec.run_prologue()
+        eu.check_handovers(eu.CHECK_EVERY)
+        ec.check_handovers(ec.CHECK_EVERY)
+        self.coef.copy_(self.coef_table[step])
+        io = SimpleNamespace(x=self.pair_x, out=self.pair_out)
+        gkey = ("pair", eu.key, ec.key)
+        if self.linear:
+            return self._linear_step(step, io, None, eu, None, gkey, run=self._replay_pair)
+        if not self.use_graph:
+            self._fill(io)
+            self._replay_pair()
+            native.cfg_ddim_step(self.x, io.out, self.coef)
+            return self.x
+        if self.graph is None or self.graph_key != gkey:
+            keep = self.x.clone()
+            self._fill(io)
+            self._replay_pair()  # warm-up outside capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._fill(io)
+                self._replay_pair()
+                native.cfg_ddim_step(self.x, io.out, self.coef)
+            self.x.copy_(keep)
+            self.graph, self.graph_key = g, gkey
+        self.graph.replay()
+        return self.x
+
     def lower_now(self) -> None:
         """Build the launch programs for the staged inputs without running anything (refiners_amd.parallel.broadcast_packs lowers on every
         rank but lets only the source compute the packed weights: the prologue must not run before they have arrived)."""
@@ -392,14 +537,22 @@ class CompiledSDXL:
         if self.coef_table is None or self.coef_table.device != self.x.device:
             self._tables(self.x.device)
         n = self.x.shape[0]
+        if self._split_wanted(n):
+            try:
+                self._prepare_pair(dict(self.inputs, timestep=self.ts_table[0:1], timesteps_all=self.ts_table, step_index=0), n)
+            except Unsupported:
+                return
+            self.engine.prologue_key = None
+            self.engine_c.prologue_key = None  # type: ignore[union-attr]
+            return
         try:
             self.engine.prepare_explicit((2 * n,) + tuple(self.x.shape[1:]), self.x.device, dict(self.inputs, timestep=self.ts_table[0:1], timesteps_all=self.ts_table, step_index=0))
         except Unsupported:
             return  # a tree this lowering does not know: nothing to stage, step() takes the stock Chain forward with its warning (the fallback contract)
         self.engine.prologue_key = None  # staged, not yet run: the first step() re-stages and runs the prologue
 
-    def _fill(self) -> None:
-        io = self.engine.io
+    def _fill(self, io: Any = None) -> None:
+        io = io if io is not None else self.engine.io
         n = self.x.shape[0]  # type: ignore[union-attr]
         io.x[:n].copy_(self.x)  # type: ignore[union-attr]
         io.x[n:].copy_(self.x)  # type: ignore[union-attr]
@@ -412,6 +565,9 @@ class CompiledSDXL:
         eng = self.engine
         got = dict(self.inputs, timestep=self.ts_table[step : step + 1], timesteps_all=self.ts_table, step_index=step)
         n = self.x.shape[0]
+        if self._split_wanted(n):
+            return self._split_step(step, got, n)
+        eng.io_override = None
         shape2 = (2 * n,) + tuple(self.x.shape[1:])
         try:
             changed = eng.prepare_explicit(shape2, self.x.device, got)
@@ -419,6 +575,7 @@ class CompiledSDXL:
             return self._stock_step(step, got)
         if changed:
             eng.run_prologue()
+        eng.check_handovers(eng.CHECK_EVERY)
         io, low = eng.io, eng.low
         assert io is not None and low is not None
         self.coef.copy_(self.coef_table[step])
@@ -551,10 +708,12 @@ class CompiledSDXL:
 
         return tail
 
-    def _linear_step(self, step: int, io: Any, low: Any, eng: Any, tail: Any = None, gkey: Any = None) -> Tensor:
+    def _linear_step(self, step: int, io: Any, low: Any, eng: Any, tail: Any = None, gkey: Any = None, run: Any = None) -> Tensor:
         """Euler / DPM-Solver++ / LCM: the UNet program (then the Self-Attention Guidance pass, `tail`) then ONE kernel (guidance, update,
-        history, next model input)."""
+        history, next model input).  `run`: what replays the UNet (default: `low.step` on the current stream; the split CFG pair passes its own)."""
         gkey = gkey if gkey is not None else eng.key
+        if run is None:
+            run = lambda: native.replay(low.step)  # noqa: E731
         if tail is None:
             tail = lambda: None  # noqa: E731
         assert self.x is not None and self.hist is not None
@@ -567,24 +726,24 @@ class CompiledSDXL:
             sdt = getattr(self.solver, "dtype", self.x.dtype)
             noise = torch.randn(tuple(self.x.shape), generator=getattr(self, "generator", None), device=sdev, dtype=sdt)
             self.hist.copy_(noise)
-        if not self.primed or self.primed_key != eng.key:  # first step of a trajectory, or the engine re-lowered into new buffers
-            self._fill()  # cat(x, x) ...
+        if not self.primed or self.primed_key != gkey:  # first step of a trajectory, or the engine re-lowered into new buffers
+            self._fill(io)  # cat(x, x) ...
             s0 = float(self.solver.input_scale(step))
             if s0 != 1.0:
                 io.x.mul_(s0)  # ... through Solver.scale_model_input for THIS step; later steps get it from the kernel
-            self.primed, self.primed_key = True, eng.key
+            self.primed, self.primed_key = True, gkey
         if not self.use_graph:
-            native.replay(low.step)
+            run()
             tail()
             native.cfg_linear_step(self.x, io.out, self.hist, io.x, self.coef)
             return self.x
         if self.graph is None or self.graph_key != gkey:
-            native.replay(low.step)  # warm-up outside capture; reads io.x only
+            run()  # warm-up outside capture; reads io.x only
             tail()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                native.replay(low.step)
+                run()
                 tail()
                 native.cfg_linear_step(self.x, io.out, self.hist, io.x, self.coef)
             self.graph, self.graph_key = g, gkey
@@ -603,4 +762,7 @@ class CompiledSDXL:
             f"sample(first_step={first_step}) but solver.first_inference_step={first}: build the solver with first_inference_step={first_step}")
         for s in range(first_step, self.solver.num_inference_steps):
             self.step(s)
+        for eng in (self.engine, self.engine_c, self.engine2):  # the trajectory's last replays (the in-loop look runs every CHECK_EVERY-th step)
+            if eng is not None:
+                eng.check_handovers()
         return self.x  # type: ignore[return-value]

@@ -88,6 +88,11 @@ class _FusedBlock(fl.Chain):
             native.replay(rt["low"].prologue)
             rt["side_id"] = side_id
         native.replay(rt["low"].step)
+        rt["calls"] = rt.get("calls", 0) + 1
+        if fresh or rt["calls"] % 16 == 0:  # a lost in-launch hand-over raises an error word on the device: look at it now and then (CompiledUNet.check_handovers)
+            bad = rt["low"].handover_pending()
+            if bad and bool((bad[0] if len(bad) == 1 else torch.stack(bad).any()).item()):
+                rt["low"].handover_raise()
         return rt["out"].clone()
 
 

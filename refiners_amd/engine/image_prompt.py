@@ -212,7 +212,7 @@ class CompiledImagePrompt:
                 self.tokens = torch.empty(2 * B * nt, ct, device=dev, dtype=dtype)
                 low.lower_image_projection(self.image_proj, self.both, self.tokens)
             self.cache.sweep()
-            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
+            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph, low=low)
             self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.x.copy_(image)
         self.program.run()
@@ -248,7 +248,7 @@ class CompiledImagePromptPlus:
             self.tokens = torch.empty(2 * B * nt, od, device=dev, dtype=dtype)
             low.lower_perceiver(self.resampler, feats, 2 * B, L, self.tokens)
             self.cache.sweep()
-            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
+            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph, low=low)
             self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.x[B:].copy_(image)
         self.program.run()

@@ -306,6 +306,21 @@ class Lowering:
             self._bumped.add(id(self._target))
         return self.pool.get(native.lora_scratch_rows(groups, M, R, self.dtype), R), self._lsync.flags(groups, M), self._lsync
 
+    def handover_pending(self) -> list:
+        """Device-side "an in-launch hand-over was lost" indicators of this lowering's programs (0-d bool tensors; no host synchronisation): the in-launch
+        LoRA's error words (a tile gave up waiting for t = x A^T) and the stream-K scratch's (a partial tile never arrived).  See CompiledUNet.check_handovers."""
+        out = []
+        for st in (self._lsync, self._sk):
+            bad = st.pending() if st is not None else None
+            if bad is not None:
+                out.append(bad)
+        return out
+
+    def handover_raise(self) -> None:
+        for st in (self._lsync, self._sk):
+            if st is not None:
+                st.check()
+
     def colstats_for(self, M: int, N: int, HW: int) -> Any:
         """The buffer for the column statistics of an [M, N] image tensor about to be produced, or None when its consumer could not use them
         (32-pixel blocks must not straddle samples).  One buffer per PRODUCER (they total ~60 MB for the SDXL step, nothing next to 288 GB):
@@ -485,7 +500,7 @@ class Lowering:
             sy = self.lora_sync(1, M_out, spec.lora.R)
         cs = self.colstats_for(M_out, spec.cout, OH * OW)  # most convolution outputs of a UNet are normalised next (ResidualBlock, unet.py:6-51)
         native.conv_gemm(segs, out, a.B, OH, OW, bias=b, rowbias=rowbias, rows_per_group=OH * OW, res=res, tile=tile, ksplit=ksplit, ws=ws, lora=lo, lora_sync=sy,
-                         colstats_out=cs)
+                         colstats_out=cs, table_may_replace_split=True)
         if sy is not None:
             self.pool.put(sy[0])
         self.pool.put(t)

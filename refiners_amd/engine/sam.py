@@ -301,7 +301,7 @@ class CompiledSAMViT:
             self.cache.sweep()
             self.low, self.key = low, key
             # the torch fallback of an attention (un-merged LoRA, odd shapes) allocates: not capturable
-            self.program = Program(low.step, self.use_graph and not low.stats["fallback_nodes"])
+            self.program = Program(low.step, self.use_graph and not low.stats["fallback_nodes"], low=low)
             self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.x.copy_(image)
         self.program.run()

@@ -217,7 +217,7 @@ class CompiledDoubleTextEncoder:
             low = TextLowering(dev, dtype, self.cache, self.lora_mode)
             low.lower_double(self.enc, self.tok_l, self.tok_g, self.eot, B, L, self.emb, self.pooled)
             self.cache.sweep()
-            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
+            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph, low=low)
             self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.tok_l.copy_(tok_l.reshape(-1))
         self.tok_g.copy_(tok_g.reshape(-1))
@@ -254,7 +254,7 @@ class CompiledTextEncoder:
             low = TextLowering(dev, dtype, self.cache, self.lora_mode)
             low.lower_encoder(self.enc, self.tok, B, L, self.out)
             self.cache.sweep()
-            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph)
+            self.low, self.key, self.program = low, key, Program(low.step, self.use_graph, low=low)
             self.stats = dict(low.stats, step_ops=launches(low.step), pool_bytes=low.step_pool.bytes())
         self.tok.copy_(tok.reshape(-1))
         self.program.run()

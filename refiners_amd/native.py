@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from pathlib import Path
 from typing import Any, Optional, Sequence
 
@@ -522,23 +523,67 @@ def pack_conv_weight(w: Tensor) -> Tensor:
 class LoraSync:
     """Device-side state of mi355x_gemm's in-launch LoRA (include/mi355x_refiners.h: lora_t / lora_flags / lora_epoch): the epoch word that
     a recorded program bumps once per replay (`bump_op()` goes to the head of the program), per-site flag arrays (zeroed, never shared
-    between launches of one replay) and scratch for t = x A^T, which consecutive launches may share (stream order)."""
+    between launches of one replay) and scratch for t = x A^T, which consecutive launches may share (stream order).
+
+    The flag arrays of all sites are cut from a few large int32 chunks, so that the sites' error words (the int32 behind each site's last
+    flag, raised by a tile whose hand-over never arrived) can be consulted with ONE gather per chunk: `pending()` is what the engines poll
+    at their host sync points (CompiledUNet.check_handovers)."""
+
+    CHUNK = 1 << 20  # int32 words per chunk (4 MB): the SDXL step's 722 sites need ~0.1 M
 
     def __init__(self, device: torch.device) -> None:
         self.device = device
         self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
-        self.keep: list = []
+        self.chunks: list[Tensor] = []
+        self.err_pos: list[list[int]] = []   # per chunk: positions of the sites' error words
+        self._err_idx: list[Optional[Tensor]] = []  # the same as device index tensors (built on first use, dropped when a site is added)
+        self.cursor = 0
 
     def flags(self, groups: int, M: int) -> Tensor:
-        f = torch.zeros(groups * ((M + 31) // 32) + 1, dtype=torch.int32, device=self.device)  # (+ the launch's error word)
-        self.keep.append(f)
+        n = groups * ((M + 31) // 32) + 1  # (+ the launch's error word)
+        if not self.chunks or self.cursor + n > self.chunks[-1].numel():
+            self.chunks.append(torch.zeros(max(self.CHUNK, n), dtype=torch.int32, device=self.device))
+            self.err_pos.append([])
+            self._err_idx.append(None)
+            self.cursor = 0
+        f = self.chunks[-1][self.cursor : self.cursor + n]
+        self.err_pos[-1].append(self.cursor + n - 1)
+        self._err_idx[-1] = None
+        self.cursor += (n + 3) // 4 * 4  # sites start on 16-byte boundaries
         return f
+
+    def reset(self) -> None:
+        """Forget every site (eager calls: one launch at a time, fresh flags and a fresh error word per call)."""
+        if self.chunks:
+            self.chunks, self.err_pos, self._err_idx = self.chunks[:1], [[]], [None]
+            self.chunks[0].zero_()
+        self.cursor = 0
+
+    def pending(self) -> Optional[Tensor]:
+        """A 0-d bool tensor on the device: some site's error word is raised (None: no site yet).  No host synchronisation."""
+        parts = []
+        for i, (chunk, pos) in enumerate(zip(self.chunks, self.err_pos)):
+            if not pos:
+                continue
+            if self._err_idx[i] is None:
+                self._err_idx[i] = torch.tensor(pos, dtype=torch.int64, device=self.device)
+            parts.append(chunk[self._err_idx[i]].any())
+        if not parts:
+            return None
+        return parts[0] if len(parts) == 1 else torch.stack(parts).any()
+
+    def clear_errors(self) -> None:
+        for i, (chunk, pos) in enumerate(zip(self.chunks, self.err_pos)):
+            if pos:
+                if self._err_idx[i] is None:
+                    self._err_idx[i] = torch.tensor(pos, dtype=torch.int64, device=self.device)
+                chunk[self._err_idx[i]] = 0
 
     def check(self) -> None:
         """Raise if a launch of this state's sites reported a hand-over that never arrived (mi355x_gemm_args.lora_flags: the last word)."""
-        if self.keep and bool(torch.stack([f[-1] for f in self.keep]).any().item()):
-            for f in self.keep:
-                f[-1].zero_()
+        bad = self.pending()
+        if bad is not None and bool(bad.item()):
+            self.clear_errors()
             raise NativeError("mi355x_gemm (in-launch LoRA): a tile waited 2 s for t = x A^T that never came (MI355X_ELAUNCH)")
 
     def scratch(self, groups: int, M: int, r: int, dtype: torch.dtype) -> Tensor:
@@ -580,7 +625,7 @@ def _lora_fill(a: GemmArgs, lora: tuple, ln_given: bool, dtype: torch.dtype, K: 
         dev = lb.device
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         ls = _eager_sync.setdefault(idx, LoraSync(dev))
-        ls.keep.clear()
+        ls.reset()
         ls.bump()
         sync = (ls.scratch(len(groups), a.M, R, dtype), ls.flags(len(groups), a.M), ls)
     t, flags, ls = sync
@@ -680,7 +725,7 @@ def gemm(
         a.stats_out = stats_out.data_ptr()
         keep.append(stats_out)
     _fill_colstats(a, colstats_out, keep)
-    _fill_split(a, tile, ksplit, ws, stages)
+    _fill_split(a, tile, ksplit, ws, stages, operand=out if out is not None else out_t)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm", keep=tuple(keep))
     return out
 
@@ -703,6 +748,7 @@ def conv_gemm(
     lora: Optional[tuple] = None,
     lora_sync: Optional[tuple] = None,
     colstats_out: Optional[Tensor] = None,
+    table_may_replace_split: bool = False,
 ) -> Tensor:
     """Implicit-GEMM convolution over NHWC images.
 
@@ -735,7 +781,7 @@ def conv_gemm(
     if lora is not None:
         _lora_fill(a, lora, False, img0.dtype, tuple(w0.shape)[1], keep, lora_sync)
     _fill_colstats(a, colstats_out, keep)
-    _fill_split(a, tile, ksplit, ws, stages)
+    _fill_split(a, tile, ksplit, ws, stages, table_may_replace_split=table_may_replace_split, operand=out)
     _launch("mi355x_gemm", (C.byref(a),), "mi355x_gemm(conv)", keep=tuple(keep))
     return out
 
@@ -813,7 +859,8 @@ def _fill_colstats(a: GemmArgs, cs: Optional[Tensor], keep: list) -> None:
 
 class StreamK:
     """Scratch of the stream-K launches (tile 8; mi355x_gemm_args.sk_ws / sk_flags): 256 slots of 256 KB + the hand-off flags.  Launches on ONE stream
-    share it (a recorded program owns one: Lowering.streamk(); eager calls use one per device); allocated on first use."""
+    share it (a recorded program owns one: Lowering._sk, installed by Lowering._Section while the program is recorded; eager calls use one per
+    (operand device, stream): _fill_split); allocated on first use."""
 
     SLOTS = 256
 
@@ -828,15 +875,21 @@ class StreamK:
             self.flags = torch.zeros(self.SLOTS + 1, dtype=torch.int32, device=self.device)
         return self.ws, self.flags
 
+    def pending(self) -> Optional[Tensor]:
+        """A 0-d bool tensor on the device: a launch reported a lost deposit (None: the scratch was never used).  No host synchronisation."""
+        return None if self.flags is None else self.flags[-1] != 0
+
     def check(self) -> None:
-        """Raise if a launch reported a lost deposit (the flags are reset so that later launches start clean)."""
-        if self.flags is not None and int(self.flags[-1].item()) != 0:
-            self.flags.zero_()
+        """Raise if a launch reported a lost deposit.  ALL flags are reset then: an owner that gave up has cleared its range, but a late depositor may
+        still have set its flag afterwards, and the next launch on this scratch would find it set at once and add a stale slot (round-5 advisor)."""
+        bad = self.pending()
+        if bad is not None and bool(bad.item()):
+            self.flags.zero_()  # type: ignore[union-attr]
             raise NativeError("mi355x_gemm (stream-K): a workgroup's partial tile never arrived (MI355X_ELAUNCH)")
 
 
 _streamk_current: Optional[StreamK] = None
-_streamk_eager: dict[int, StreamK] = {}
+_streamk_eager: dict[tuple[int, int], StreamK] = {}
 
 
 def set_streamk(sk: Optional[StreamK]) -> Optional[StreamK]:
@@ -852,23 +905,35 @@ def attach_streamk(a: GemmArgs, sk: StreamK) -> None:
     a._sk_keep = sk
 
 
-def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor], stages: int = 0) -> None:
-    if tile == 0 and ksplit <= 1:  # no explicit choice: the measured table of this GPU, if it knows the shape
+def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor], stages: int = 0, table_may_replace_split: bool = False, operand: Optional[Tensor] = None) -> None:
+    """tile / stages / split-K of a launch.  tile == 0 and no split: the measured table of this GPU decides, if it knows the shape.  An EXPLICIT choice
+    (tile != 0, or a split) is the caller's and stays (tests and probes of split-K on tabled shapes must run split-K) -- unless the caller says its
+    split is only a heuristic (`table_may_replace_split`: Lowering.conv's three-way split for want of tiles): where the table prefers the 8-wave loop
+    (tiles 7 / 8 / 9: whole tiles or stream-K) the launch asks for that tile and KEEPS ksplit / ws: mi355x_gemm drops the split when the 8-wave loop
+    takes the launch and runs the split on the 128 x 128 tile when it cannot (unaligned operands, 2 GB and more)."""
+    if tile == 0 and ksplit <= 1:
         from .engine import tuning
 
         tile, stages = tuning.lookup(gemm_signature(a), stages)
-    elif ksplit > 1:  # the caller split K for want of tiles: where the table prefers the 8-wave loop (whole tiles or stream-K), that replaces the split
+    elif ksplit > 1 and table_may_replace_split:
         from .engine import tuning
 
         t8, _ = tuning.lookup(gemm_signature(a), 0)
         if t8 in (7, 8, 9):
-            tile, ksplit, ws = t8, 1, None
+            tile = t8
     a.tile, a.ksplit, a.stages = tile, ksplit, stages
     if tile == 8 or os.environ.get("REFINERS_AMD_FORCE_TILE") == "8":
         sk = _streamk_current
         if sk is None:
-            dev = torch.device("cuda", torch.cuda.current_device())
-            sk = _streamk_eager.setdefault(dev.index, StreamK(dev))
+            # eager call (tests, probes): one scratch per (device of the operands, current stream) -- launches on two streams of one device must not
+            # share it, and the current device need not be the operands' (round-5 advisor)
+            dev = operand.device if operand is not None and operand.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+            if dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            sk = _streamk_eager.get(key)
+            if sk is None:
+                sk = _streamk_eager[key] = StreamK(dev)
         attach_streamk(a, sk)
     if ksplit > 1:
         assert ws is not None and ws.is_contiguous(), "split-K needs a scratch tensor of ksplit * M * N float32"
@@ -962,7 +1027,7 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Tensor) -
     return out
 
 
-_gn_ws: dict[tuple[int, int], Tensor] = {}
+_gn_ws: "weakref.WeakValueDictionary[tuple[int, int, int], Tensor]" = weakref.WeakValueDictionary()
 
 
 def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool, out: Tensor, colstats: Optional[Tensor] = None,
@@ -978,11 +1043,14 @@ def groupnorm_nhwc(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: flo
         assert x2.shape[:2] == x.shape[:2] and x2.stride(2) == 1 and x2.stride(0) == HW * x2.stride(1) and x2.dtype == x.dtype and (colstats is None) == (colstats2 is None)
         a.x2, a.ldx2, a.C1 = x2.data_ptr(), x2.stride(1), C1
     need = load().mi355x_groupnorm_ws_floats(B, HW, Cc)
+    # one scratch per (device, stream) for eager calls, one per PROGRAM while recording: two recorded programs may replay concurrently on two
+    # streams (CompiledSDXL's split CFG pair, two trajectories in one process) whatever stream they were lowered on.  The table holds weak
+    # references: a program's scratch lives in the keep-alive tuples of its launches and goes with them.
     if x.device.type == "cuda":
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-        key = (dev, torch.cuda.current_stream().cuda_stream)
+        key = (dev, torch.cuda.current_stream().cuda_stream, id(_recorder) if _recorder is not None else 0)
     else:  # dry-run lowering on the meta / cpu device (tests): nothing is launched
-        key = (-1, 0)
+        key = (-1, 0, 0)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)

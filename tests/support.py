@@ -114,6 +114,35 @@ def oracle_sources_digest() -> str:
     return h.hexdigest()
 
 
+def synth_digest() -> str:
+    """sha256 of refiners_amd/synth.py: what a reference-written full-size tensor depends on besides its recipe (weights, adapters and inputs are drawn there)."""
+    import hashlib
+
+    return hashlib.sha256((GOLD.parent.parent / "refiners_amd" / "synth.py").read_bytes()).hexdigest()
+
+
+def full_size_reference(name: str) -> "torch.Tensor | None":
+    """x_next of a FULL_SIZE recipe as the REAL reference computed it (tests/golden/full_size_reference.safetensors, written in the build container by
+    oracle/make_golden_full_size_reference.py from refiners' own classes), or None when the committed file does not hold the recipe as it stands now (an edited
+    recipe or an edited synth.py): callers then fall back to the oracle, which tests/test_oracle_golden.py pins to the reference."""
+    from safetensors import safe_open
+
+    path = GOLD / "full_size_reference.safetensors"
+    if not path.exists():
+        return None
+    with safe_open(str(path), framework="pt") as f:
+        meta = f.metadata() or {}
+        if name in f.keys() and json.loads(meta.get(name, "null")) == FULL_SIZE[name] and meta.get("synth") == synth_digest():
+            return f.get_tensor(name)
+    return None
+
+
+def full_size_golden(name: str) -> tuple[torch.Tensor, str]:
+    """(x_next, who computed it): the REAL reference's full-size step where the committed file holds the recipe ("reference"), else the CPU oracle's ("oracle")."""
+    ref = full_size_reference(name)
+    return (ref, "reference") if ref is not None else (full_size_oracle(name), "oracle")
+
+
 def full_size_oracle(name: str) -> torch.Tensor:
     from safetensors import safe_open
 

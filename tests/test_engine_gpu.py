@@ -87,6 +87,64 @@ def test_unet_bfloat16_close_to_float32_reference(case):
     assert l2 < 1.15 * l2_t + 1e-3, "the fused path must not be less accurate than the unfused bf16 path"
 
 
+@pytest.mark.parametrize("case", ["sdxl_bare", "sdxl_lora_ip", "sdxl_control"])
+def test_cfg_pair_as_two_programs_on_two_streams(case):
+    """`cfg_split=True`: the two halves of the CFG pair lowered as two batch-n programs (one set of packed weights) and replayed on two streams -- two branches of
+    the one captured graph -- then the unchanged guidance + DDIM kernel on the shared 2n-row output.  Parity against the reference's own x_next, the result of the
+    single-program engine to float32 rounding, and bit-identical replays (live LoRA hand-overs, GroupNorm scratch and stream-K scratch are per program: two
+    programs of one process run concurrently here)."""
+    cfg, unet, specs, handles, inp = build(case, torch.float32)
+    kw = {}
+    if specs["ip"] is not None:
+        kw["clip_image_embedding"] = specs["ip"]["tokens"].to("cuda")
+    if specs["control"]:
+        kw["conditions"] = {c["name"]: c["condition"].to("cuda") for c in specs["control"]}
+    outs = {}
+    for split in (True, False):
+        sd = CompiledSDXL(unet, num_inference_steps=cfg["num_steps"], condition_scale=cfg["condition_scale"], cfg_split=split)
+        sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], **kw)
+        x1 = sd.step(cfg["step"]).clone()
+        assert (sd.engine_c is not None) == split and sd.engine.stats["fallback_nodes"] == []
+        if split:
+            assert sd.engine_c.cache is sd.engine.cache and sd.engine.io.x.shape[0] == inp["x"].shape[0]  # batch-n programs, one PackCache
+            for _ in range(3):  # captured graph, same inputs: bit-identical
+                sd.set_inputs(inp["x"], clip_text_embedding=inp["text"], pooled_text_embedding=inp["pooled"], time_ids=inp["time_ids"], **kw)
+                assert torch.equal(sd.step(cfg["step"]), x1)
+        outs[split] = x1
+    l2, mx = S.rel_err(outs[True], S.golden(case)["x_next"])
+    l2s, mxs = S.rel_err(outs[True], outs[False])
+    print(f"{case} f32, CFG pair as two programs: vs reference l2 {l2:.2e} max {mx:.2e}; vs the single program l2 {l2s:.2e} max {mxs:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (case, l2, mx)
+    assert l2s < 1e-4, (case, l2s, mxs)
+
+
+def test_engine_raises_on_a_lost_lora_hand_over():
+    """Round-5 advisor: a tile that gives up waiting for t = x A^T raises an error word on the device and goes on with undefined operands; only the tests
+    looked at those words.  The engine now does at its host sync points (CompiledUNet.check_handovers): with the producers switched off
+    (mi355x_set_option "lora_dbg" bit 0: every tile waits its 2 s) the call after the poisoned replay raises NativeError instead of returning garbage."""
+    cfg, unet, specs, handles, inp = build("sdxl_lora_ip", torch.float32)
+    fast = CompiledUNet(unet, use_graph=False)
+    set_context(unet, cfg, inp, torch.float32)
+    x = torch.cat((inp["x"], inp["x"]))
+    y = fast(x)
+    assert fast.low._lsync is not None and fast.low.handover_pending(), "this tree must run in-launch LoRA sites"
+    lib = native.load()
+    # one adapted launch alone with its producers switched off: a replay of the whole step that way would wait 2 s per launch
+    site = next(e for e in fast.low.step if e[0] is not None and e[2] == "mi355x_gemm" and e[1][0]._obj.lora_b)
+    try:
+        lib.mi355x_set_option(b"lora_dbg", 1)
+        native.replay([fast.low.step[0], site])  # (the epoch bump + the site)
+        torch.cuda.synchronize()
+    finally:
+        lib.mi355x_set_option(b"lora_dbg", 0)
+    set_context(unet, cfg, inp, torch.float32)
+    with pytest.raises(native.NativeError):
+        fast.check_handovers()
+    fast.check_handovers()  # the words were cleared with the raise: the engine goes on
+    set_context(unet, cfg, inp, torch.float32)
+    assert torch.equal(fast(x), y)
+
+
 @pytest.mark.parametrize("case", ["sdxl_bare", "sdxl_lora_ip"])
 def test_cfg_ddim_step_matches_reference(case):
     cfg, unet, specs, handles, inp = build(case, torch.float32)
@@ -164,10 +222,12 @@ def test_full_size_step_matches_oracle():
     sd = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0)
     sd.set_inputs(inp["x"].cuda(), clip_text_embedding=inp["text"].cuda(), pooled_text_embedding=inp["pooled"].cuda(), time_ids=inp["time_ids"].cuda())
     x1 = sd.step(0).clone()
-    ref = S.full_size_oracle("bare_step0")  # the oracle's step, committed by oracle/make_golden_full_size.py (computed here if the recipe changed)
+    # the step as refiners ITSELF computed it at this size (tests/golden/full_size_reference.safetensors, oracle/make_golden_full_size_reference.py); the oracle's
+    # committed step (oracle/make_golden_full_size.py) where the recipe changed since
+    ref, who = S.full_size_golden("bare_step0")
     l2, mx = S.rel_err(x1, ref)
-    print(f"full-size f32 step: l2 {l2:.2e} max {mx:.2e}")
-    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    print(f"full-size f32 step vs the {who}: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (who, l2, mx)
 
 
 @pytest.mark.parametrize("case", ["sdxl_lora_ip", "sdxl_conv_lora", "sdxl_control", "sdxl_control2"])
@@ -614,7 +674,9 @@ def full_size_lora_ip_oracle():
     """BASELINE configs[2] at its benchmarked geometry (128x128 latents, CFG pair): one CPU-oracle step, shared by the tests below
     (committed by oracle/make_golden_full_size.py; computed here if the recipe in tests/support.py changed)."""
     specs, inp = S.full_size_inputs("lora_ip_step7")
-    return specs, inp, S.full_size_oracle("lora_ip_step7")
+    ref, who = S.full_size_golden("lora_ip_step7")  # refiners' own step at this size where the committed file holds the recipe, else the oracle's
+    print(f"full-size lora_ip golden written by the {who}")
+    return specs, inp, ref
 
 
 @pytest.mark.parametrize("mode", ["merged", "fused"])
@@ -695,10 +757,10 @@ def test_full_size_control_batch_of_four():
     l2, mx = S.rel_err(x1, x4[:1])
     print(f"full-size control batch invariance: l2 {l2:.2e} max {mx:.2e}")
     assert mx < 5e-3, (l2, mx)
-    refo = S.full_size_oracle("control_single_step12")
+    refo, who = S.full_size_golden("control_single_step12")  # refiners' own step (ControlLoraAdapter through its own API) where committed, else the oracle's
     l2, mx = S.rel_err(x1, refo)
-    print(f"full-size control single image vs oracle: l2 {l2:.2e} max {mx:.2e}")
-    assert l2 < F32_TOL and mx < F32_TOL, (l2, mx)
+    print(f"full-size control single image vs the {who}: l2 {l2:.2e} max {mx:.2e}")
+    assert l2 < F32_TOL and mx < F32_TOL, (who, l2, mx)
     # the same shape in the benchmarked dtype (configs[3] per GPU, bfloat16): reported against the float32 result above, bar = stock torch bf16
     del sd, sd1
     unet_b = SDXLUNet(4, device="meta")

@@ -41,6 +41,19 @@ def test_sd1_oracle_matches_reference():
     assert torch.equal(gold["unet_out"], gold["unet_out_again"])  # the reference itself is bit-reproducible
 
 
+def test_oracle_matches_reference_at_full_size():
+    """The oracle pinned to the reference AT THE BENCHMARKED GEOMETRY (128 x 128 latents): refiners' own steps of the FULL_SIZE recipes
+    (tests/golden/full_size_reference.safetensors, written in the build container by oracle/make_golden_full_size_reference.py -- configs[1] bare, configs[2] with
+    2 LoRAs x 722 Linears + IP-Adapter, configs[3]'s ControlLora image) against the oracle's committed steps of the same recipes.  Two committed tensors per
+    recipe, no computation: until round 6 every reference-written golden was 32 x 32."""
+    for name in S.FULL_SIZE:
+        ref = S.full_size_reference(name)
+        assert ref is not None, f"{name}: re-run `python oracle/make_golden_full_size_reference.py` (recipe or synth.py changed)"
+        l2, mx = S.rel_err(S.full_size_oracle(name), ref)
+        print(f"{name}: oracle vs reference at full size: l2 {l2:.2e} max {mx:.2e}")
+        assert l2 < TOL and mx < TOL, (name, l2, mx)
+
+
 def test_full_size_fixture_is_current():
     """tests/golden/full_size_oracle.safetensors holds the oracle's steps at the benchmarked geometry (the GPU tests compare the engine with them).  An entry is only
     served when its recipe AND the digest of the sources it was computed from (oracle/*.py, refiners_amd/synth.py) match the tree: a stale file would otherwise cost every

@@ -23,7 +23,7 @@ from refiners_amd.engine import tuning  # noqa: E402
 from refiners_amd.engine.compiled import CompiledSDXL  # noqa: E402
 
 KEYS = ("REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH", "REFINERS_AMD_TIME_BATCH", "REFINERS_AMD_ATTN_PIPE",
-        "REFINERS_AMD_GN_STATS", "REFINERS_AMD_TIME_TABLE", "REFINERS_AMD_CAT_FUSE", "REFINERS_AMD_TUNING_TABLE", "REFINERS_AMD_PF_BLOCKS", "REFINERS_AMD_LORA_G8")
+        "REFINERS_AMD_GN_STATS", "REFINERS_AMD_TIME_TABLE", "REFINERS_AMD_CAT_FUSE", "REFINERS_AMD_TUNING_TABLE", "REFINERS_AMD_PF_BLOCKS", "REFINERS_AMD_LORA_G8", "REFINERS_AMD_CFG_SPLIT", "REFINERS_AMD_CFG_SPLIT_LEAD")
 
 
 def main() -> None:
@@ -43,6 +43,7 @@ def main() -> None:
     del pipe0
     variants = [v.split("=", 1) for v in (args.variants or ["default="])]
     pipes = {}
+    after2: dict = {}
     for name, envs in variants:
         for k in KEYS:
             os.environ.pop(k, None)
@@ -65,7 +66,10 @@ def main() -> None:
         p.step(1)
         torch.cuda.synchronize()
         pipes[name] = p
-        print(f"{name}: {p.engine.stats['step_ops']} launches/step, tuning {p.engine.stats.get('gemm_tuning')}", flush=True)
+        after2[name] = p.x.float().clone()
+        first = after2[next(iter(after2))]
+        print(f"{name}: {p.engine.stats['step_ops']} launches/step{' x 2 programs (split CFG pair)' if p.engine_c is not None else ''}, tuning {p.engine.stats.get('gemm_tuning')}, "
+              f"x after 2 steps vs the first variant: rel l2 {float((after2[name] - first).norm() / first.norm()):.3e}", flush=True)
         if libtag is not None:
             native.switch_library(None)
     res = {n: [] for n in pipes}

@@ -142,18 +142,18 @@ def pmc_families(db: str, program: list[dict] | None = None) -> dict:
     calibration launch) every dispatch of the process counts.  Returns {"scope", "families": {family: {counter: {dispatches, sum}}},
     "classes": {class key: {counter: {dispatches, sum, launches}}}}."""
     con = sqlite3.connect(db)
-    per: dict[int, dict] = {}
+    # every dispatch of the traced process comes from the kernel trace (a filtered counter pass -- --kernel-include-regex -- holds counters for some kernels
+    # only, and the mapping onto the recorded program needs them all); counters are joined on the dispatch's start timestamp (one pmc_events row per XCD
+    # instance of a dispatch: summed)
+    pm: dict[int, dict] = {}
     for did, name, start, counter, val in con.execute("select dispatch_id, name, min(start), counter_name, sum(counter_value) from pmc_events group by dispatch_id, counter_name"):
-        d = per.setdefault(did, {"name": name, "start": start, "c": {}})
-        d["c"][counter] = val  # (one row per XCD instance of a dispatch: summed)
-    try:  # the dispatch's own duration from the kernel trace of the same run (joined on the start timestamp): a pseudo counter
-        durs = {s: d for _, s, d in kernel_rows(db)}
-        for d in per.values():
-            if d["start"] in durs:
-                d["c"]["DURATION_NS"] = float(durs[d["start"]])
-    except Exception as exc:  # noqa: BLE001
-        print("  no durations:", exc)
-    rows = sorted(((d["name"], d["start"], dict(d["c"], _name=d["name"])) for d in per.values()), key=lambda r: r[1])
+        pm.setdefault(start, {})[counter] = val
+    rows = []
+    for n, st_, dur in kernel_rows(db):
+        cs = dict(pm.get(st_, {}), _name=n)
+        if st_ in pm:
+            cs["DURATION_NS"] = float(dur)  # the dispatch's own duration from the kernel trace of the same run: a pseudo counter (counted dispatches only)
+        rows.append((n, st_, cs))
     fams: dict = {}
     classes: dict = {}
     kernels: dict = {}
@@ -244,13 +244,15 @@ def main() -> None:
     ap.add_argument("--tag", required=True)
     ap.add_argument("--workload", default="lora_ip")
     ap.add_argument("--skip-pmc", action="store_true")
+    ap.add_argument("--lora-mode", default="fused")
+    ap.add_argument("--groups", default="", help="skip the unfiltered attempt of every PMC pass and collect these kernel-name groups only (4wave,8wave,other)")
     ap.add_argument("--passes", default="fetch,write,mfma,sq", help="which PMC passes to run (a pass the profiler crashed in can be repeated alone)")
     args = ap.parse_args()
     OUT.mkdir(exist_ok=True)
     tag = args.tag
     prof = Path("/tmp") / f"{tag}_prof"  # raw profiler databases stay on the box: only the summaries go to gpurun_out/ (64 MiB cap)
     prof.mkdir(exist_ok=True)
-    bench = [sys.executable, str(ROOT / "bench.py"), "--workload", args.workload, "--no-cpu-baseline", "--no-extra", "--no-roofline", "--no-graph"]
+    bench = [sys.executable, str(ROOT / "bench.py"), "--workload", args.workload, "--no-cpu-baseline", "--no-extra", "--no-roofline", "--no-graph", "--lora-mode", args.lora_mode]
     prog_path = prof / "program.json"
     # 1. kernel trace of the timed steps
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "-d", str(prof / "kt"), "--", *bench, "--steps", "5", "--warmup", "2", "--dump-program", str(prog_path)], prof / "kt.log")
@@ -267,34 +269,79 @@ def main() -> None:
               "sq": ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES"]}
     got: dict[str, dict] = {}
     got_cls: dict[str, dict] = {}
+    got_k: dict[str, dict] = {}
     scope = None
     program = json.loads(prog_path.read_text()) if prog_path.exists() else None
     passes = {k: v for k, v in passes.items() if k in args.passes.split(",")}
-    for name, counters in passes.items():
-        for attempt in range(3):  # the profiler's TCC / SQ collection dies with SIGSEGV at the first dispatch now and then on this pool: try again
-            rc = run(["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", str(prof / name), "--", *bench, "--steps", "2", "--warmup", "1"], prof / f"{name}.log")
+    # Kernel-name groups for the fallback: the counter collection of this pool's profiler build dies (SIGSEGV inside the dispatch interception) on some
+    # whole-step passes -- rounds 4 and 5 lost every FETCH_SIZE / WRITE_SIZE pass that way.  A pass that dies unfiltered is repeated as three
+    # processes, each collecting counters for ONE group of kernels (--kernel-include-regex / --kernel-exclude-regex; the kernel trace still holds every
+    # dispatch, so the mapping onto the recorded program works per process) and the per-class sums are merged.
+    groups = [("4wave", ["--kernel-include-regex", "gemm_kernel|splitk_reduce_kernel"]), ("8wave", ["--kernel-include-regex", "gemm8_kernel"]),
+              ("other", ["--kernel-exclude-regex", "gemm_kernel|gemm8_kernel|splitk_reduce_kernel"])]
+    if args.groups:
+        groups = [g for g in groups if g[0] in args.groups.split(",")]
+    how_groups: dict[str, str] = {}
+
+    def merge(dst: dict, src: dict) -> None:
+        for key, cs in src.items():
+            for counter, e in cs.items():
+                d = dst.setdefault(key, {}).setdefault(counter, {"dispatches": 0, "sum": 0.0, "launches": 0})
+                for f in ("dispatches", "sum", "launches"):
+                    d[f] += e[f]
+
+    def one_run(name: str, counters: list, extra: list, sub: str) -> dict | None:
+        d = prof / f"{name}{sub}"
+        rc = -1
+        for attempt in range(2):  # the collection dies with SIGSEGV at the first dispatch now and then on this pool: try again
+            rc = run(["rocprofv3", "--pmc", *counters, "--kernel-trace", *extra, "-d", str(d), "--", *bench, "--steps", "2", "--warmup", "1"], prof / f"{name}{sub}.log")
             if rc == 0:
                 break
-            print("pmc pass", name, "attempt", attempt + 1, "rc", rc)
-        db = find_db(prof / name)
-        print("pmc pass", name, "rc", rc, "db", db)
+            print("pmc pass", name + sub, "attempt", attempt + 1, "rc", rc)
+        db = find_db(d)
+        print("pmc pass", name + sub, "rc", rc, "db", db)
         if rc != 0:  # keep what the profiler said: the raw logs stay on the box
-            tail = [ln for ln in (prof / f"{name}.log").read_text(errors="replace").splitlines() if "amdgpu.ids" not in ln][-40:]
-            (OUT / f"{tag}_pmc_{name}_failed.log").write_text("\n".join(tail) + "\n")
-        if db:
-            try:
-                r = pmc_families(db, program)
-                got[name], got_cls[name], scope = r["families"], r["classes"], r["scope"]
-                if name == "sq":  # which kernel VARIANT loses LDS cycles to bank conflicts (the family figure hides it)
-                    by_k = {k: {c: v["sum"] for c, v in cs.items()} for k, cs in r["kernels"].items()}
-                    for k, cs in by_k.items():
-                        if cs.get("SQ_LDS_IDX_ACTIVE"):
-                            cs["lds_conflict_frac"] = cs.get("SQ_LDS_BANK_CONFLICT", 0.0) / cs["SQ_LDS_IDX_ACTIVE"]
-                    (OUT / f"{tag}_pmc_sq_by_kernel.json").write_text(json.dumps({"how": how, "scope": scope, "kernels": by_k}, indent=1))
-                    print({k[:60]: round(v.get("lds_conflict_frac", 0.0), 3) for k, v in by_k.items() if "attn" in k})
-                print("  scope:", scope)
-            except Exception as exc:  # noqa: BLE001
-                print("  failed to read", exc)
+            tail = [ln for ln in (prof / f"{name}{sub}.log").read_text(errors="replace").splitlines() if "amdgpu.ids" not in ln][-40:]
+            (OUT / f"{tag}_pmc_{name}{sub}_failed.log").write_text("\n".join(tail) + "\n")
+            return None
+        try:
+            return pmc_families(db, program) if db else None
+        except Exception as exc:  # noqa: BLE001
+            print("  failed to read", exc)
+            return None
+
+    for name, counters in passes.items():
+        r = None if args.groups else one_run(name, counters, [], "")
+        if r is not None and "step program only" in r["scope"]:
+            how_groups[name] = "one unfiltered process"
+        else:
+            r = {"scope": None, "families": {}, "classes": {}, "kernels": {}}
+            done, died = [], []
+            for gname, extra in groups:
+                rg = one_run(name, counters, extra, "_" + gname)
+                if rg is None or "step program only" not in rg["scope"]:
+                    died.append(gname)
+                    continue
+                done.append(gname)
+                r["scope"] = rg["scope"]
+                for part in ("families", "classes", "kernels"):
+                    merge(r[part], rg[part])
+            how_groups[name] = f"kernel-name groups, one process each: collected {done or 'none'}" + (f", died in the profiler: {died}" if died else "")
+            if not done:
+                r = None
+            else:
+                r["scope"] += f"; counters collected per kernel-name group in separate processes ({', '.join(done)}" + (f"; NOT {', '.join(died)}: the profiler died" if died else "") + ")"
+        if r is not None:
+            got[name], got_cls[name], scope = r["families"], r["classes"], r["scope"]
+            got_k[name] = r["kernels"]
+            if name == "sq":  # which kernel VARIANT loses LDS cycles to bank conflicts (the family figure hides it)
+                by_k = {k: {c: v["sum"] for c, v in cs.items()} for k, cs in r["kernels"].items()}
+                for k, cs in by_k.items():
+                    if cs.get("SQ_LDS_IDX_ACTIVE"):
+                        cs["lds_conflict_frac"] = cs.get("SQ_LDS_BANK_CONFLICT", 0.0) / cs["SQ_LDS_IDX_ACTIVE"]
+                (OUT / f"{tag}_pmc_sq_by_kernel.json").write_text(json.dumps({"how": how, "scope": scope, "kernels": by_k}, indent=1))
+            print("  scope:", scope)
+    how = how + " | " + "; ".join(f"{k}: {v}" for k, v in how_groups.items())
     if "fetch" in got and "write" in got:
         fams = {}
         for f in set(got["fetch"]) | set(got["write"]):
@@ -313,7 +360,18 @@ def main() -> None:
                 if d and d["launches"]:
                     row[counter] = {"launches": d["launches"], "bytes_per_launch": d["sum"] / d["launches"] * 1024 * (2 if counter == "FETCH_SIZE" else 1)}
             cls[k] = row
-        (OUT / f"{tag}_pmc_traffic.json").write_text(json.dumps({"how": how, "scope": scope, "units": "counter values are KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); families: per KERNEL dispatch (GroupNorm: per kernel, not per call); classes: per program launch (all its kernels)", "families": fams, "classes": cls}, indent=1))
+        # the HBM-bound kernels of the step in GB/s: per kernel name, fetched (doubled) + written bytes over the dispatches' own durations
+        hbm = {}
+        for k in set(got_k.get("fetch", {})) & set(got_k.get("write", {})):
+            if "gemm" in k or "attn" in k:
+                continue
+            fk, wk = got_k["fetch"][k], got_k["write"][k]
+            if "FETCH_SIZE" in fk and "WRITE_SIZE" in wk and fk.get("DURATION_NS", {}).get("sum"):
+                n = fk["FETCH_SIZE"]["dispatches"]
+                byts = fk["FETCH_SIZE"]["sum"] * 1024 * 2 + wk["WRITE_SIZE"]["sum"] * 1024 * n / max(wk["WRITE_SIZE"]["dispatches"], 1)
+                ns = fk["DURATION_NS"]["sum"]
+                hbm[k] = {"dispatches": n, "bytes_per_dispatch": byts / n, "avg_us": ns / n / 1e3, "gbps": byts / ns, "frac_of_8TBps": byts / ns / 8000.0}
+        (OUT / f"{tag}_pmc_traffic.json").write_text(json.dumps({"how": how, "scope": scope, "hbm_bound_kernels": hbm, "units": "counter values are KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); families: per KERNEL dispatch (GroupNorm: per kernel, not per call); classes: per program launch (all its kernels)", "families": fams, "classes": cls}, indent=1))
         print({f: {c: round(v["bytes_per_launch"] / 1e6, 2) for c, v in cs.items()} for f, cs in fams.items()})
     if not ("fetch" in got and "write" in got) and ("fetch" in passes or "write" in passes):
         traffic_micro(tag, prof)
