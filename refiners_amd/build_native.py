@@ -14,8 +14,15 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libmi355x_refiners.so"
 SOURCES = ["gemm.hip", "gemm_conv.hip", "gemm8.hip", "attention.hip", "attention_general.hip", "norm.hip", "elementwise.hip"]
-HEADERS = ["common.cuh", "gemm_params.cuh", "gemm_epilogue.cuh", "gemm_kernel.cuh", "gemm8_kernel.cuh", "../../include/mi355x_refiners.h"]
+HEADERS = ["common.cuh", "gemm_params.cuh", "gemm_epilogue.cuh", "gemm_kernel.cuh", "gemm8_kernel.cuh", "gemm_lora_producer.cuh", "../../include/mi355x_refiners.h"]
 ARCH = "gfx950"
+#: headers each translation unit includes (an incremental build -- `python -m refiners_amd.build_native` without --force -- recompiles a source only when it or one of these changed)
+DEPS = {
+    "gemm.hip": ["common.cuh", "gemm_params.cuh", "gemm_epilogue.cuh", "gemm_kernel.cuh", "gemm8_kernel.cuh", "gemm_lora_producer.cuh"],
+    "gemm_conv.hip": ["common.cuh", "gemm_params.cuh", "gemm_epilogue.cuh", "gemm_kernel.cuh", "gemm_lora_producer.cuh"],
+    "gemm8.hip": ["common.cuh", "gemm_params.cuh", "gemm_epilogue.cuh", "gemm8_kernel.cuh", "gemm_lora_producer.cuh"],
+    "attention.hip": ["common.cuh"], "attention_general.hip": ["common.cuh"], "norm.hip": ["common.cuh"], "elementwise.hip": ["common.cuh"],
+}
 
 
 def hipcc_path() -> str:
@@ -52,6 +59,11 @@ def build_native(force: bool = False, verbose: bool = False, defines: list[str] 
     procs = []
     for src in SOURCES:
         obj = objdir / (src.replace(".hip", ".o"))
+        if not force and not defines and obj.exists():  # incremental: the object is newer than its source and every header it includes
+            deps = [CSRC / src, (CSRC / "../../include/mi355x_refiners.h").resolve(), Path(__file__)] + [CSRC / h for h in DEPS[src]]
+            if all(d.stat().st_mtime <= obj.stat().st_mtime for d in deps):
+                objs.append(obj)
+                continue
         # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified), which removes the
         # v_accvgpr_read/write traffic between the softmax / epilogue VALU code and the matrix cores (attention inner
         # loop: 1062 -> 876 instructions) and lowers the total register count of every kernel.

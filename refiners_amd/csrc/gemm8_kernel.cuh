@@ -28,11 +28,13 @@
 // running K offset in the instruction's SCALAR offset, the descriptor per segment -- no vector ALU work per load -- and out-of-range lanes
 // (conv padding, rows beyond M / N) are given offset 0x80000000, for which the hardware writes zeros to LDS (no zero page, no select).
 // In-launch LoRA (its own kernel instance, LORA = true: the plain instance's register allocation is untouched): ONE column group of a plain one-segment GEMM
-// without a transposed part.  t = x A^T comes from "t-tiles" -- the first tiles_m workgroups of the grid run this same loop on their row tile with the stacked
-// down rows in the W slot and publish t (LayerNorm correction folded in, rounded to the storage type, write-through stores, one flag per 32 rows) --, and every
-// output tile adds T(t) (s B)^T after its K loop: fragments of t and of the up rows straight from memory (a wave's 16 rows x 64 B are 1 KB contiguous), 32 MFMAs
-// per 32 ranks.  Register notes that shaped the code: (a) the accumulators must have ONE consumer after the K loop -- with the t-tile epilogue and the tail as
-// alternatives the allocator gave up on keeping them in place (1 400 spills), so t-tiles pass through the tail with zero steps; (b) everything after the K loop
+// without a transposed part.  t = x A^T comes from PRODUCER workgroups at the head of the grid -- gemm_lora_producer.cuh, the 4-wave kernel's producers: one per
+// 32 rows, an 8-deep LDS ring in this launch's 128 KB of stage buffers, waves 4 .. 7 of the workgroup exit at once; t with the LayerNorm correction folded in,
+// rounded to the storage type, write-through stores, one flag per 32 rows -- and every output tile adds T(t) (s B)^T after its K loop: fragments of t and of the
+// up rows straight from memory (a wave's 16 rows x 64 B are 1 KB contiguous), 32 MFMAs per 32 ranks.  (Round 5 computed t in "t-tiles": the first tiles_m
+// workgroups ran this loop on their row tile with the stacked down rows in the W slot.  t was then published when the tiles of the first dispatch round LEFT
+// their K loops -- every one of them waited for the t-tile's epilogue and the hand-over, ~7 us of the 11 us the live LoRAs cost the CFG pair's FF1 -- where a
+// producer's 20-K-block loop is done a quarter into the tiles' loop: profiles/r06_*.)  Register notes that shaped the code: (b) everything after the K loop
 // reads the launch arguments through a pointer to the kernel-argument segment made opaque AFTER the loop: as fields of the by-value argument they are loaded at
 // kernel entry, spilt over the loop and re-loaded one v_readlane per use (3 181 of them; 59 per 16-row block of the epilogue).
 // Not in this loop (the host keeps such launches on gemm_kernel.cuh): other LoRA forms (several column groups, a transposed group, convolutions), operands of 2 GB and more.
@@ -40,6 +42,7 @@
 #include <vector>
 
 #include "gemm_epilogue.cuh"
+#include "gemm_lora_producer.cuh"
 
 namespace mi355x {
 
@@ -133,21 +136,26 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         return;
     }
     int bid = (int)blockIdx.x - p.pf_blocks;
-    // In-launch LoRA (one column group, GemmP::lora_*; fluxion/adapters/lora.py:383-397): the first lp_blocks workgroups are T-TILES -- ordinary tiles of row tile
-    // `bid` whose W slot holds the stacked down rows (rank r in LDS-row order, everything beyond the rank reads as zero), so the same K loop leaves
-    // t = x A^T in their accumulators; their epilogue applies the folded LayerNorm's correction, rounds t to the storage type like the reference's
-    // intermediate tensor, stores it write-through and raises the flags of the tile's eight 32-row blocks.  Every output tile adds T(t) (s B)^T after its K loop
-    // (32 MFMAs per wave and 32 ranks, t and the up rows read straight into fragment layout: no LDS) once its rows' flags carry the launch's epoch.
-    // t-tiles have the lowest ids: dispatched first, they run their K loop beside the tiles that will want t when THEY leave theirs.
-    bool ttile = false;
+    // In-launch LoRA (one column group, GemmP::lora_*; fluxion/adapters/lora.py:383-397): the first lp_blocks workgroups are PRODUCERS of t = x A^T (one per 32 rows:
+    // LayerNorm correction folded in, rounded to the storage type like the reference's intermediate tensor, write-through stores, one flag per block).  Every output
+    // tile adds T(t) (s B)^T after its K loop (32 MFMAs per wave and 32 ranks, t and the up rows read straight into fragment layout: no LDS) once its rows' flags
+    // carry the launch's epoch.  Producers have the lowest ids: dispatched before any tile that will wait for them.
     if (LORA && p.lp_blocks > 0) {
-        if (bid < p.lp_blocks) {
-            if (bid >= p.tiles_m || (p.lora_dbg & 1)) return;  // (padding up to a multiple of 8 keeps tile b on XCD b % 8; lora_dbg bit 0, probing / tests: the t-tiles exit
-                                                               //  at once -- a LOST hand-over: every tile waits its 2 s and raises the launch's error word)
-            ttile = true;
-        } else {
-            bid -= p.lp_blocks;
+        if (bid < p.lp_blocks) {  // producer role (gemm_lora_producer.cuh): a producer is 256 threads and one 32-row block of t
+            // ranks 32 / 64: TWO producers per workgroup (waves 0-3 / 4-7, row blocks 2 bid / 2 bid + 1, half of the stage buffers each) -- a workgroup of this
+            // launch owns a whole CU's LDS, so M / 32 one-producer workgroups would be a dispatch round of their own at M = 8192; rank 128 (20 KB per
+            // ring stage): one producer with the whole ring, waves 4 .. 7 exit (an ended wave no longer counts at the workgroup's barriers)
+            const int npb = (p.M + LORA_PM - 1) / LORA_PM, halves = p.lora_r <= 64 ? 2 : 1, half = wid >> 2;
+            const int q = halves * bid + half;
+            if (half >= halves || q >= npb || (p.lora_dbg & 1)) return;  // (padding up to a multiple of 8 keeps tile b on XCD b % 8; lora_dbg bit 0, probing / tests:
+                                                                         //  the producers exit at once -- a LOST hand-over: every tile waits its 2 s and raises the launch's error word)
+            constexpr int RING = 2 * BUFB, HALF = RING / 2, PB2 = (LORA_PM + 64) * 128, PB4 = (LORA_PM + 128) * 128;
+            if (p.lora_r == 32) lora_producer<T, false, 1, (HALF / 8192 < 8 ? HALF / 8192 : 8)>(p, q, tid0 & 255, smem + half * HALF);
+            else if (p.lora_r == 64) lora_producer<T, false, 2, (HALF / PB2 < 8 ? HALF / PB2 : 8)>(p, q, tid0 & 255, smem + half * HALF);
+            else lora_producer<T, false, 4, (RING / PB4 < 8 ? RING / PB4 : 8)>(p, q);
+            return;
         }
+        bid -= p.lp_blocks;
     }
     // ---- this workgroup's span of the launch's work.  The unit of work is one K tile of one output tile; an output tile is sk_nk consecutive units.
     //   sk_mode 0: whole tiles: workgroup b takes tiles b, b + sk_g, ... in the XCD-aware rasterisation of plan_grid (sk_g = tiles: one each);
@@ -223,10 +231,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             more = tile_next < p.grid0;
         }
         int tm, tn;
-        if (LORA && ttile) {
-            if (tile != bid) break;  // (a t-tile is one tile)
-            tm = bid, tn = 0, more = false;
-        } else if (p.sk_mode == 1) {  // tiles in row-major (sk_order 0) or column-major order along the unit axis
+        if (p.sk_mode == 1) {  // tiles in row-major (sk_order 0) or column-major order along the unit axis
             if (p.sk_order == 0) {
                 tm = tile / p.tiles_n;
                 tn = tile - tm * p.tiles_n;
@@ -250,14 +255,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         //   = 128 s + 8 h + wlane.  Rows beyond the operand get row -1 (offset 2^32 - ld + coff: beyond every descriptor, the load writes zeros).
         const int wq = 8 * (wid & 3) + lr8;
         const int xlane = 8 * wid + lr8, wlane = 64 * (wid >> 2) + 16 * ((wq >> 2) & 3) + 4 * (wq >> 4) + (wq & 3);
-        const int ws_lim_eff = LORA && ttile ? p.lora_r : ws_lim;  // (t-tile: virtual column = rank)
         auto xrow = [&](int h, int s2) __attribute__((always_inline)) {
             const int r = xs_0 + WR * s2 + QR * h + xlane;
             return r < xs_lim && (MT == 8 || wid < XW) ? r : -1;  // (MT = 6: waves 6 and 7 stage nothing real -- zeros into a spare LDS area)
         };
         auto wrow = [&](int h, int s2) __attribute__((always_inline)) {
             const int r = ws_0 + 128 * s2 + 8 * h + wlane;
-            return r < ws_lim_eff ? r : -1;
+            return r < ws_lim ? r : -1;
         };
         int xb[2][2], xyx[2][2];  // conv: image index (-1: a row beyond M), (oy | ox << 16) of the output pixel
         if constexpr (CONV) {
@@ -339,11 +343,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             wrs = tr ? make_rsrc(sp.x, sp.xbytes) : make_rsrc(sp.w, sp.wbytes);
             w_step = kbl ? (uint32_t)ws_lim * 128u : 128u;
             uint32_t ld = kbl ? 128u : (uint32_t)(tr ? sp.ldxb : sp.ldwb);
-            if (LORA && ttile) {  // the stacked down rows, K-blocked: [K blocks][lora_r][128 B] (the LoRAs adapt K segment 0: the only one of such a launch)
-                wrs = make_rsrc(p.lora_a[0], (int64_t)sp.nkb * p.lora_r * 128);
-                w_step = (uint32_t)p.lora_r * 128u;
-                ld = 128u;
-            }
             w_so = (uint32_t)kb * w_step;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -441,7 +440,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             adv_w();
         }
         if (p.ln_stats && owner) ln_rowstat<256, NTHR>(p, m0, tid, rowstat);  // (256 rows whatever the tile: two threads per row; a 192-row tile's last 64 are the next tile's, unused)
-        if (owner && !(LORA && ttile) && tid < BN && (p.ln_stats || p.bias)) {  // per-column vectors of the tile -> LDS (read by the epilogue: see tile_epilogue's colvec)
+        if (owner && tid < BN && (p.ln_stats || p.bias)) {  // per-column vectors of the tile -> LDS (read by the epilogue: see tile_epilogue's colvec)
             const int n = min(n0 + tid, p.N - 1);
             if (p.ln_stats) {
                 colvec[tid] = p.ln_s[n];
@@ -591,7 +590,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
         if (LORA) {
             // ---- LoRA tail of an output tile: acc += T(t) (s B)^T, 32 ranks per step ----
             const int nfl = (pe->M + 31) / 32, lora_tag = *pe->lora_epoch;
-            if (!ttile) {  // this wave's four row blocks: lanes 0..3 poll one flag each (relaxed agent-scope loads bypass the CU's L1), bounded by the wall clock
+            {  // this wave's four row blocks: lanes 0..3 poll one flag each (relaxed agent-scope loads bypass the CU's L1), bounded by the wall clock
                 const int fb = (m0 + WR * wm) / 32 + min(lane_e & 3, WR / 32 - 1);
                 const int* fp = pe->lora_flags + (fb < nfl ? fb : nfl - 1);
                 const uint64_t t0 = wall_clock64();
@@ -608,8 +607,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             const int rb = pe->lora_r * (int)sizeof(T);  // bytes per row of t / of the up rows
             // the W slot's row order (gemm_kernel.cuh header): MMA row ce of block j is output column 64 wn + 16 (ce >> 2) + 4 j + (ce & 3)
             const int ncol = n0 + 64 * wn + 16 * (ce >> 2) + (ce & 3);
-            const int nc32 = ttile ? 0 : pe->lora_r / 32;  // (a t-tile passes through here with no steps: its accumulators then have ONE consumer after the K loop, this loop --
-            // with the t-tile's own epilogue as a second one beside it the register allocator gave up on keeping them in place: 1400 spills)
+            const int nc32 = pe->lora_r / 32;
             for (int c = 0; c < nc32; ++c) {
                 frag_t tfr[MT][KS32], bfr[NT][KS32];
 #pragma unroll
@@ -632,49 +630,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
 #pragma unroll
                         for (int j = 0; j < NT; ++j) mma_step<T>(acc[i][j], bfr[j][ks], tfr[i][ks]);
             }
-        }
-        if (LORA && ttile) {
-            // ---- t-tile epilogue: lane_e (ge, ce) of wave (wm, wn) holds, for rows 128 wm + 16 i + ce, the virtual columns 64 wn + 16 ge + (4 j + r): ranks ----
-            const int r0 = 64 * wn + 16 * ge;
-            const int lora_tag = *pe->lora_epoch;
-            if (r0 < pe->lora_r) {
-                char* tg = pe->lora_t;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int mrow = WR * wm + 16 * i + ce, m = m0 + mrow;
-                    if (m >= pe->M) continue;
-                    float v[16];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
-                    if (pe->ln_stats) {  // what is published is t / rstd = (x A'^T - mean sA) + cA / rstd: the tiles' LayerNorm epilogue scales the product back
-                        const float mean = rowstat[2 * mrow], inv = 1.0f / rowstat[2 * mrow + 1];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const f32x4 sa = *reinterpret_cast<const f32x4*>(pe->lora_ls + r0 + 4 * c), ca = *reinterpret_cast<const f32x4*>(pe->lora_lc + r0 + 4 * c);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[4 * c + e] = (v[4 * c + e] - mean * sa[e]) + ca[e] * inv;
-                        }
-                    }
-                    char* dst = tg + ((int64_t)m * pe->lora_r + r0) * (int)sizeof(T);
-                    if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) st_agent8(dst + 8 * c, __builtin_bit_cast(uint64_t, f32x2{v[2 * c], v[2 * c + 1]}));
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const bf16x4 b4 = {(bf16_t)v[4 * c], (bf16_t)v[4 * c + 1], (bf16_t)v[4 * c + 2], (bf16_t)v[4 * c + 3]};
-                            st_agent8(dst + 8 * c, __builtin_bit_cast(uint64_t, b4));
-                        }
-                    }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
-            __syncthreads();
-            const int nfl = (pe->M + 31) / 32;
-            if (tid < BM / 32 && m0 / 32 + tid < nfl) __hip_atomic_store(pe->lora_flags + m0 / 32 + tid, lora_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
         }
         if constexpr ((MI355X_G8_ABL & 1) != 0) {
 #pragma unroll
@@ -728,8 +683,9 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
     GemmP q = p;
     plan_grid(q, 32 * MT, 256, CONV, 2);
     q.lora_dbg = g_lora_dbg & 1;  // (mi355x_set_option "lora_dbg"; the other probing bits belong to the 4-wave kernel's producers)
-    q.lora_tt = 1;
-    q.lp_blocks = q.lora_b ? (q.tiles_m + 7) / 8 * 8 : 0;  // t-tiles: one per row tile, padded to a multiple of 8 (tile b stays on XCD b % 8)
+    q.lora_tt = 0;
+    // producers: one per 32 rows, two to a workgroup for ranks 32 / 64 (see the kernel), padded to a multiple of 8 workgroups (tile b stays on XCD b % 8)
+    q.lp_blocks = q.lora_b ? (((q.M + LORA_PM - 1) / LORA_PM + (q.lora_r <= 64 ? 1 : 0)) / (q.lora_r <= 64 ? 2 : 1) + 7) / 8 * 8 : 0;
     q.ksplit = 1;
     q.sk_nk = 0;
     for (int s = 0; s < q.nseg; ++s) q.sk_nk += q.seg[s].nkb;
@@ -774,7 +730,9 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
             }
         }
     }
-    if (q.sk_mode == 0 && g_g8_persist && q.grid0 > ncu && ncu % 8 == 0 && !q.lora_b) q.sk_g = ncu;  // several whole tiles per workgroup: b, b + ncu, ... (the same XCD each time)
+    // several whole tiles per workgroup: b, b + ncu, ... (the same XCD each time).  LoRA launches too (round 6): their producers leave the CU after a quarter of a tile's
+    // time, and the persistent workgroups that start behind them are the highest ids -- the ones with the fewest tiles
+    if (q.sk_mode == 0 && g_g8_persist && q.grid0 > ncu && ncu % 8 == 0) q.sk_g = ncu;
     const int grid = q.pf_blocks + q.lp_blocks + q.sk_g;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, stream, q);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
@@ -795,7 +753,7 @@ int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk, int mt) {  //
 inline bool gemm8_ok(const GemmP& p, bool conv = false, int mt = 8) {
     if (mt == 6 && p.out_t) return false;  // (the 192-row tile has no transposed form)
     if (p.ksplit > 1 || !p.vec_ok || p.N % 16) return false;  // (the epilogue instances of this loop are the vectorised ones)
-    if (p.lora_b && (conv || p.lora_groups != 1 || p.nseg != 1 || p.out_t || p.lora_r % 32 || p.lora_r > 256 || !p.lora_t || !p.lora_flags || !p.lora_epoch)) return false;  // in-launch LoRA here: one column group of a plain GEMM
+    if (p.lora_b && (conv || p.lora_groups != 1 || p.nseg != 1 || p.out_t || (p.lora_r != 32 && p.lora_r != 64 && p.lora_r != 128) || !p.lora_t || !p.lora_flags || !p.lora_epoch)) return false;  // in-launch LoRA here: one column group of a plain GEMM
     if (p.out_t && p.nt_begin % 256) return false;  // a tile is either stored row-major or transposed
     for (int s = 0; s < p.nseg; ++s)
         if (p.seg[s].xbytes <= 0 || p.seg[s].wbytes <= 0 || p.seg[s].xbytes >= (1ll << 31) || p.seg[s].wbytes >= (1ll << 31)) return false;

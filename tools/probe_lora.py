@@ -142,6 +142,15 @@ def main():
                 case(M, 640, 5120, geglu=True, ln=True, tile=tile, only=("g8",))
                 case(M, 2560, 640, tile=tile, only=("g8",))
         return
+    if "--ff1" in sys.argv:  # round 6: the classes the tuning table sends to the 8-wave loop with live LoRAs (producers instead of t-tiles, persistent workgroups)
+        for tile in (1, 9, 7):
+            case(2048, 1280, 10240, geglu=True, ln=True, tile=tile, only=("g8",))
+        for tile in (1, 7):
+            case(8192, 640, 5120, geglu=True, ln=True, tile=tile, only=("g8",))
+        for tile in (0, 9):
+            case(2048, 1280, 1280, tile=tile, only=("g8",))
+            case(2048, 5120, 1280, tile=tile, only=("g8",))
+        return
     if "--ablate" in sys.argv:
         case(2048, 1280, 1280, tile=1)
         return
