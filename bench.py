@@ -36,6 +36,14 @@ PEAK_HBM_GBPS = 8000.0     # HBM3E peak of the same guide (6.3 TB/s is what a fl
 LATENT = (128, 128)
 
 
+_T0 = time.time()
+
+
+def note(msg: str) -> None:
+    """Progress on stderr (the one JSON line on stdout comes last: a leg that takes minutes should be findable in the log of a run that was cut short)."""
+    print(f"[bench {time.time() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def gpu_weights(unet, seed: int, dtype: torch.dtype, device: torch.device) -> None:
     """Random-init every parameter directly in HBM (same per-kind scaling rule as refiners_amd.synth)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -402,6 +410,25 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
+def usable_cpus() -> int:
+    """CPUs this PROCESS may run on: the scheduler affinity mask, cut by the cgroup's CPU quota where one is set (a container on a 256-thread host may own a
+    fraction of it; intra-op threads beyond that only queue behind each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline_step(bare_sd: dict, specs: dict, workload: str, threads: int, budget_s: float = 75.0) -> dict:
     """The benchmarked workload's denoising step on this host's cores, float32.  With refiners' own package at hand (reference_checkout) the timed
     step runs refiners ITSELF (`kind: "reference"`); the mirror's unfused Chain forward -- the stand-in of earlier rounds, and the fallback when no
@@ -413,6 +440,7 @@ def cpu_baseline_step(bare_sd: dict, specs: dict, workload: str, threads: int, b
     from refiners_amd import synth
 
     phys, logical = physical_cores(), os.cpu_count() or 1
+    usable = usable_cpus()
     ref_src = reference_checkout() if workload in ("bare", "lora_ip", "control") else None
     if workload == "control" and specs["control"] and specs["control"][0]["condition"].shape[0] != 2:
         ref_src = None  # the bounded sample below is one image
@@ -421,18 +449,21 @@ def cpu_baseline_step(bare_sd: dict, specs: dict, workload: str, threads: int, b
     cin = synth.sdxl_inputs(1, LATENT, seed=100)
     small = [cin["x"][:, :, :32, :32], cin["text"], cin["pooled"], cin["time_ids"]]
     mid = [cin["x"][:, :, :64, :64], *small[1:]]
+    note(f"cpu baseline: {kind}, {phys} physical / {logical} logical / {usable} usable cpus")
     with torch.no_grad():
-        torch.set_num_threads(threads or min(phys, logical))
+        torch.set_num_threads(threads or min(phys, usable))
         step(cin["x"][:, :, :16, :16], *small[1:])  # page-in / thread-pool warm-up on a 16x16 latent
+        note("cpu baseline: warm-up done")
         sweep = None
         if not threads:
             sweep = {}
-            for n in sorted({max(1, phys // 4), max(1, phys // 2), phys, logical}):
+            for n in sorted({min(usable, n) for n in (max(1, phys // 4), max(1, phys // 2), phys, logical)} | {max(1, min(usable, 16))}):
                 torch.set_num_threads(n)
                 step(cin["x"][:, :, :16, :16], *small[1:])  # (the pool is rebuilt at the new size)
                 ts = time.perf_counter()
                 step(*mid)
                 sweep[n] = round(time.perf_counter() - ts, 3)
+                note(f"cpu baseline: sweep {n} threads: {sweep[n]} s on 64x64 latents")
             threads = min(sweep, key=sweep.get)
             torch.set_num_threads(threads)
             step(cin["x"][:, :, :16, :16], *small[1:])
@@ -442,12 +473,13 @@ def cpu_baseline_step(bare_sd: dict, specs: dict, workload: str, threads: int, b
             out = step(cin["x"], *small[1:])
             times.append(time.perf_counter() - tc)
             spent += times[-1]
+            note(f"cpu baseline: full-size step {len(times)}: {times[-1]:.1f} s at {threads} threads")
             if spent + times[-1] > budget_s:
                 break
         cpu_s = sorted(times)[len(times) // 2]
         assert bool(torch.isfinite(out).all())
         res = {"value": round(1.0 / (cpu_s * 50), 6), "unit": "images/s", "cores": threads, "kind": kind, "path": desc, "dtype": "f32",
-               "ms_per_step": round(cpu_s * 1e3, 1), "timed_steps_s": [round(t, 2) for t in times], "host_cpus": logical, "physical_cores": phys,
+               "ms_per_step": round(cpu_s * 1e3, 1), "timed_steps_s": [round(t, 2) for t in times], "host_cpus": logical, "physical_cores": phys, "usable_cpus": usable,
                "thread_sweep_s_on_64x64_latents": sweep,
                "sample": f"1 warm-up + {len(times)} timed step(s) (median) of the 50 DDIM steps of one 1024x1024 image (CFG pair) of this workload, intra-op threads = "
                          f"{'the best of the sweep' if sweep else 'as given'}; images/s extrapolated x50"}
@@ -616,7 +648,9 @@ def main() -> None:
     t0 = time.time()
     unet, specs, bare_sd, pipe, bc = build_pipeline(args.workload, n_img, rank, dev, dtype, args.lora_mode, use_graph, packs=args.packs)
     n_params = sum(p.numel() for p in unet.parameters())
+    note("pipeline built, timing")
     elapsed = timed_steps(pipe, args.steps, args.warmup, world, dev)
+    note(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms per step")
     if world > 1:  # every rank's own clock around the same K steps (value uses the max): a slow GPU / link shows up here
         mine = torch.tensor([timed_steps.last_local_s / args.steps * 1e3], dtype=torch.float64, device=dev)
         bc["per_rank_ms_per_step"] = [round(float(t), 3) for t in parallel.all_gather(mine)]
@@ -650,6 +684,7 @@ def main() -> None:
             cpu = {"value": None, "unit": "images/s", "cores": args.cpu_threads, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"}
         if not args.no_extra:
             try:  # BASELINE configs[0]: the reference's SD1.5 UNet on the same cores
+                note("configs[0]: SD1.5 UNet on the CPU")
                 extra["configs0_sd15_cpu"] = sd15_cpu_point(int(cpu.get("cores") or physical_cores()))
             except Exception as exc:  # noqa: BLE001
                 extra["configs0_sd15_cpu"] = f"failed: {type(exc).__name__}: {exc}"
@@ -671,6 +706,7 @@ def main() -> None:
                 extra["lora_mode_other"] = f"failed: {type(exc).__name__}: {exc}"
         # ---- the headline configuration's throughput points: configs[2] with LIVE LoRAs at 4 and 8 images per GPU (UNet batch 8 / 16) ----
         if args.workload == "lora_ip":
+            note("configs[2] throughput points (4 and 8 images per GPU)")
             pts = []
             for n4 in (4, 8):
                 try:
@@ -687,6 +723,7 @@ def main() -> None:
             extra["throughput_operating_point_configs2"] = pts
         # ---- the benchmarked dtype's error against refiners' own full-size step (reported alongside: BASELINE.md section 4) ----
         try:
+            note("bf16 parity point against the reference-written full-size step")
             extra["parity"] = parity_point(dev)
         except Exception as exc:  # noqa: BLE001
             extra["parity"] = {"parity_bf16_rel_l2": None, "why": f"failed: {type(exc).__name__}: {exc}"}
@@ -697,6 +734,7 @@ def main() -> None:
 
             vae = SDXLAutoencoder(device="meta")
             gpu_weights(vae, seed=7, dtype=dtype, device=dev)
+            note("VAE decode")
             dec = CompiledVAEDecoder(vae)
             z = pipe.x[:1] * 0.13
             dec(z)
@@ -718,6 +756,7 @@ def main() -> None:
             del unet, bare_sd
             try:
                 torch.cuda.empty_cache()
+                note("configs[1] bare")
                 unet_b, _, _, pipe_b, _ = build_pipeline("bare", 1, rank, dev, dtype, args.lora_mode, use_graph, broadcast=False)
                 sb = timed_steps(pipe_b, 20, 3, 1, dev)
                 msb = sb / 20 * 1e3
@@ -734,6 +773,7 @@ def main() -> None:
                 from refiners_amd.engine.compiled import CompiledSDXL
 
                 inp4 = synth.sdxl_inputs(4, LATENT, seed=300)
+                note("bare x4 operating point")
                 pipe4 = CompiledSDXL(unet, num_inference_steps=50, condition_scale=5.0, use_graph=use_graph, lora_mode=args.lora_mode)
                 pipe4.set_inputs(inp4["x"].to(dev), clip_text_embedding=inp4["text"].to(dev), pooled_text_embedding=inp4["pooled"].to(dev), time_ids=inp4["time_ids"].to(dev))
                 s4 = timed_steps(pipe4, 10, 2, 1, dev)
@@ -748,6 +788,7 @@ def main() -> None:
     if world == 1 and n_img == 1 and not args.no_extra:
         # ---- BASELINE configs[3]'s per-GPU shape: ControlLora (canny), 4 prompts per GPU (UNet batch 8) ------------------------------
         try:
+            note("configs[3] per-GPU shape")
             unet_c, _, _, pipe_c, _ = build_pipeline("control", 4, rank, dev, dtype, args.lora_mode, use_graph, broadcast=False)
             sc = timed_steps(pipe_c, 6, 2, 1, dev)
             msc = sc / 6 * 1e3
@@ -760,6 +801,7 @@ def main() -> None:
             extra["configs3_per_gpu_shape"] = f"failed: {type(exc).__name__}: {exc}"
         # ---- BASELINE configs[4]: SegmentAnything ViT-H image encoder + HQ-SAM hook, 1024x1024, bf16 ---------------------------------
         try:
+            note("configs[4] SAM ViT-H")
             extra["configs4_sam_vit_h"] = sam_point(dev, dtype)
         except Exception as exc:  # noqa: BLE001
             extra["configs4_sam_vit_h"] = f"failed: {type(exc).__name__}: {exc}"

@@ -120,10 +120,12 @@ typedef struct {
                                falls back to 7 without them);  9: the same loop on 192x256 tiles (wave tile 96x64), whole tiles only and no transposed
                                part: for launches whose 256-row tiles leave CUs idle in their only round (M = 8192, N = 1280: 160 tiles / 215).
                                In-launch LoRA on this loop: ONE column group of a plain one-segment GEMM without out_t,
-                               as whole tiles (8 with LoRA runs as 7) -- t = x A^T comes from "t-tiles" at the head of the grid (the same loop with
-                               the stacked down rows in the weight slot), every tile adds (t)(s B)^T after its K loop.  7 / 8 / 9 do not combine with
-                               other in-launch LoRA forms (several groups, out_t, conv), a column group transposed from a column that is not a
-                               multiple of 256, ksplit, or operands of 2 GB and more: such launches run on the library's own choice among 1..4 */
+                               as whole tiles (8 with LoRA runs as 7) -- t = x A^T comes from producer workgroups at the head of the grid (one per
+                               32 rows, two to a workgroup for stacked ranks 32 / 64; the 4-wave tiles' producers with this launch's larger LDS ring),
+                               every tile adds (t)(s B)^T after its K loop.  7 / 8 / 9 do not combine with other in-launch LoRA forms (several groups,
+                               out_t, conv), a column group transposed from a column that is not a multiple of 256, or operands of 2 GB and more: such
+                               launches run on the library's own choice among 1..4.  With ksplit > 1 (a caller that split K for want of tiles) the
+                               split is dropped where the 8-wave loop takes the launch and kept, on the 128x128 tile, where it cannot */
     int32_t ksplit;         /* <= 1: no split; s > 1: s workgroups share each output tile's K range and write float32
                                partial sums into `ws`, a second launch adds them in a fixed order (deterministic) and
                                applies the epilogue.  Not combinable with geglu. */

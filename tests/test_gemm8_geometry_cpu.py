@@ -83,14 +83,40 @@ def test_lora_flag_blocks_of_a_tile_and_of_a_wave(MT):
     g = geometry(MT)
     assert g["BM"] % 32 == 0 and g["WR"] % 32 == 0
     for m0 in (0, g["BM"], 7 * g["BM"]):
-        published = {m0 // 32 + t for t in range(g["BM"] // 32)}  # the t-tile's epilogue: tid < BM / 32
+        blocks = {m0 // 32 + t for t in range(g["BM"] // 32)}  # the 32-row blocks of the tile: one producer (one flag) each
         polled = set()
         for wm in range(2):
             for lane in range(64):
                 polled.add((m0 + g["WR"] * wm) // 32 + min(lane & 3, g["WR"] // 32 - 1))  # the consumer's poll
-        assert polled == published
+        assert polled == blocks
         rows = {m0 + g["WR"] * wm + 16 * i + ce for wm in range(2) for i in range(MT) for ce in range(16)}
-        assert {r // 32 for r in rows} == published
+        assert {r // 32 for r in rows} == blocks
+
+
+@pytest.mark.parametrize("MT", [8, 6])
+@pytest.mark.parametrize("R", [32, 64, 128])
+@pytest.mark.parametrize("M", [2048, 8192, 300, 33])
+def test_lora_producers_of_the_8_wave_loop_cover_every_row_block_once(MT, R, M):
+    """Round 6: t comes from producer workgroups (gemm_lora_producer.cuh) instead of t-tiles.  Workgroup `bid` of the head of the grid runs, for ranks 32 / 64,
+    TWO producers (waves 0-3 / 4-7: row blocks 2 bid, 2 bid + 1, half of the stage buffers each), for rank 128 one; the launcher pads the workgroup count
+    to a multiple of 8.  Every 32-row block must be produced exactly once, every ring must fit its share of the LDS with at least two stages."""
+    npb = (M + 31) // 32
+    halves = 2 if R <= 64 else 1
+    lp_blocks = ((npb + (1 if halves == 2 else 0)) // halves + 7) // 8 * 8
+    made = []
+    for bid in range(lp_blocks):
+        for half in range(2):
+            q = halves * bid + half
+            if half >= halves or q >= npb:
+                continue
+            made.append(q)
+    assert sorted(made) == list(range(npb))
+    ring = 2 * (32 * MT + 256) * 128
+    share = ring // halves
+    stage = (32 + R) * 128  # 32 rows of x + R stacked down rows, 128 bytes of K each
+    pst = min(8, share // stage)
+    assert pst >= 2, (MT, R, pst)
+    assert pst * stage * halves <= ring
 
 
 @pytest.mark.parametrize("MT", [8, 6])

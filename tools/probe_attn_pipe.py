@@ -60,7 +60,11 @@ def main():
             variants += [] and [("-kvload", 1 | (1 << 8), 1), ("-softmax", 1 | (2 << 8), 1), ("-pv", 1 | (4 << 8), 1), ("-qk", 1 | (8 << 8), 1), ("-softmax-pv", 1 | (6 << 8), 1),
                          ("barriers+loads only", 1 | (14 << 8), 1), ("barriers only", 1 | (15 << 8), 1), ("  and no store", 1 | (31 << 8), 1),
                          ("  and no Q load", 1 | (63 << 8), 1), ("  and no K/V tile 0", 1 | (127 << 8), 1), ("full, no store", 1 | (16 << 8), 1)]
+        if Lk2 == 0:  # round 6: 16-query waves (64-query workgroups of 4 waves / 128-query workgroups of 8 waves), key-split forced / forbidden
+            variants += [("4 waves x 16 queries", 0x11 | (14 << 24), 1), ("8 waves x 16 queries", 0x11 | (18 << 24), 1), ("key-split always", 0x11 | (2 << 16), 1), ("key-split never", 0x11 | (1 << 16), 1)]
         for name, code, xcd in variants:
+            lib.mi355x_attention_set_nw((code >> 24) & 31)
+            code &= (1 << 24) - 1
             lib.mi355x_attention_set_pipeline(code, xcd)
             us = time_us(fns)
             o = sets[0][1].float().clone()
@@ -68,6 +72,7 @@ def main():
                 ref = o
             same = bool(torch.allclose(ref, o, atol=2e-2, rtol=2e-2)) or ((code >> 8) & 255) != 0
             line += f"\n    {name:22s} {us:7.1f} us {4.0 * B * H * Lq * (Lk + Lk2) * 64 / us / 1e6:6.0f} TF{'' if same else ' DIFF'}"
+        lib.mi355x_attention_set_nw(0)
         native.attention_pipeline_from_env()
         print(line, flush=True)
 
