@@ -57,7 +57,7 @@ def main():
         ref = None
         variants = [("general", 0x11 | 0x40000, 1), ("default", 0x11, 1)]
         if Lk2 == 0 and B == 2:  # where a tile's time goes: pieces removed (results are wrong by construction)
-            variants += [] and [("-kvload", 1 | (1 << 8), 1), ("-softmax", 1 | (2 << 8), 1), ("-pv", 1 | (4 << 8), 1), ("-qk", 1 | (8 << 8), 1), ("-softmax-pv", 1 | (6 << 8), 1),
+            variants += ([] if "--ablate" not in sys.argv else [("key-split never", 0x11 | (1 << 16), 1)]) and [("-kvload", 1 | (1 << 8), 1), ("-softmax", 1 | (2 << 8), 1), ("-pv", 1 | (4 << 8), 1), ("-qk", 1 | (8 << 8), 1), ("-softmax-pv", 1 | (6 << 8), 1),
                          ("barriers+loads only", 1 | (14 << 8), 1), ("barriers only", 1 | (15 << 8), 1), ("  and no store", 1 | (31 << 8), 1),
                          ("  and no Q load", 1 | (63 << 8), 1), ("  and no K/V tile 0", 1 | (127 << 8), 1), ("full, no store", 1 | (16 << 8), 1)]
         if Lk2 == 0:  # round 6: 16-query waves (64-query workgroups of 4 waves / 128-query workgroups of 8 waves), key-split forced / forbidden
