@@ -725,7 +725,7 @@ int g_attn_depth = 1;  // K/V tiles in flight in the register-staged loader (mi3
 int g_attn_xcd = 1;    // q-tiles of a head on one XCD
 int g_attn_opt = 1;    // OPT bits of attn_kernel (permlane reductions: +1-4 % on every self-attention shape, r02_k / r02_m probes)
 int g_attn_abl = 0;    // ABL bits (probing)
-int g_attn_kvs = 0;    // key-split workgroups: 0 = where the grid is short (see launch_attn_nw), 1 = never, 2 = always (single-stream launches)
+int g_attn_kvs = 0;    // short grids (see launch_attn_nw): 0 = 16-query waves where the grid is short, 1 = never, 2 = key-split workgroups always, 3 = 16-query waves always (single-stream launches)
 
 template <typename T, int NW, int NSTREAM, bool GLDS, int NJQ = 2, int RD = 2, int OPT = 0, int ABL = 0, int KVS = 1>
 int launch_attn(const AttnP& p0, hipStream_t stream) {
@@ -789,8 +789,12 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
         // a grid of 128-query workgroups that leaves most SIMDs with a single wave (a CFG pair's 1024-token self-attention: 320 workgroups):
         // 64-query key-split workgroups instead -- twice the waves, each with half the dependent chain per tile
         const int64_t wg128 = (int64_t)((p.Lq + 127) / 128) * p.H * p.B;
-        const bool use = g_attn_kvs == 2 || (g_attn_kvs == 0 && wg128 <= 384 && p.kv[0].Lk >= 256);
-        if (p.nstream == 1 && use) return (g_attn_opt & 1) ? launch_attn<T, 4, 1, false, 2, 1, 1, 0, 2>(p, stream) : launch_attn<T, 4, 1, false, 2, 1, 0, 0, 2>(p, stream);
+        const bool short_grid = wg128 <= 384 && p.kv[0].Lk >= 256;
+        // round 6: such grids run 64-query workgroups of four 16-QUERY waves (twice the waves, each with half the softmax / MFMA chain per tile AND per-wave state small
+        // enough for 5-7 resident workgroups): in the step 24.40 -> 24.31 ms against the key-split workgroups of rounds 3-5, which stay available (mode 2)
+        // and beat the plain 128-query workgroups (24.48) -- profiles/r06_s_ab_attn_q16.log
+        if (p.nstream == 1 && (g_attn_kvs == 3 || (g_attn_kvs == 0 && short_grid))) return launch_attn<T, 4, 1, false, 1, 1, 1>(p, stream);
+        if (p.nstream == 1 && g_attn_kvs == 2) return (g_attn_opt & 1) ? launch_attn<T, 4, 1, false, 2, 1, 1, 0, 2>(p, stream) : launch_attn<T, 4, 1, false, 2, 1, 0, 0, 2>(p, stream);
     }
     switch (g_attn_opt) {
         case 1: return launch_attn_opt<T, NW, 1>(p, stream);

@@ -345,7 +345,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
 
 
 def attention_pipeline_from_env() -> None:
-    """A/B: REFINERS_AMD_ATTN_PIPE="<K/V tiles in flight 1|2>,<XCD-aware block order 0|1>,<OPT bits of attn_kernel>,<key-split 0 auto|1 never|2 always>"
+    """A/B: REFINERS_AMD_ATTN_PIPE="<K/V tiles in flight 1|2>,<XCD-aware block order 0|1>,<OPT bits of attn_kernel>,<short grids: 0 auto = 16-query waves where the grid is short|1 never|2 key-split workgroups always|3 16-query waves always>"
     (default 1,1,1,0); read at launch / capture time."""
     import os
 

@@ -970,8 +970,10 @@ def all_cases():
                              ("3tiles", (2, 2, 192, 192), {"seed": 72})):
             for code in (0x20001, 0x20011):
                 cases.append((f"attn_{tag}_kvsplit{code & 0xff:02x}_{nm}", lambda dt=dt, args=args, kw=kw, code=code: attention_case(*args, dt, pipe=code, **kw)))
-        cases += [
-        ]
+        # 64-query workgroups of four 16-query waves (0x30000 = forced; round 6: what short grids take by default): the same tile counts and ragged tails
+        for nm, args, kw in (("self_1024", (2, 4, 1024, 1024), {}), ("spike", (1, 2, 256, 512), {"spike": True}), ("Lk20", (1, 2, 96, 20), {"seed": 76}),
+                             ("Lk257_Lq130", (1, 2, 130, 257), {"seed": 74}), ("Lk300_Lq200", (2, 3, 200, 300), {"seed": 78}), ("Lq_edge_40", (1, 2, 40, 320), {"seed": 82})):
+            cases.append((f"attn_{tag}_q16waves_{nm}", lambda dt=dt, args=args, kw=kw: attention_case(*args, dt, pipe=0x30011, **kw)))
         # launches of at most three K/V tiles take the all-tiles-up-front kernel by default (the cases above: cross_77, cross_77_ip4, 1tile, 3tiles,
         # Lq_edge_200); 0x40000 switches it off, so the same shapes also run through the general tile loop; and its remaining slot layouts
         cases += [
