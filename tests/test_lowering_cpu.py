@@ -419,7 +419,7 @@ def test_tuning_table_lookup_rules(tmp_path, monkeypatch):
 def test_every_tuned_signature_is_a_launch_of_the_lowered_step(monkeypatch):
     """engine/tuning_gfx950.json is keyed by launch signature; a lowering change that alters a signature (the concat-shortcut split turned two `:s2:`
     convolutions into `:s3:` in round 4) silently orphans its entry.  Every key of the table must be carried by a launch of the bare SDXL step at the
-    two batch sizes the table was measured on (CFG pair = UNet batch 2; four images per GPU = batch 8), 128 x 128 latents, bf16."""
+    batch sizes the table was measured on (CFG pair = UNet batch 2; four images per GPU = batch 8; eight = batch 16, round 6), 128 x 128 latents, bf16."""
     import json
 
     from refiners_amd import native
@@ -428,7 +428,7 @@ def test_every_tuned_signature_is_a_launch_of_the_lowered_step(monkeypatch):
     monkeypatch.setattr(tuning, "enabled", False)  # (signatures do not depend on the choice; this keeps tile-8 scratch off the meta device)
     table = json.loads(tuning.TABLE_PATH.read_text())["choices"]
     seen = set()
-    for B in (2, 8):
+    for B in (2, 8, 16):
         unet = SDXLUNet(4, device="meta", dtype=torch.bfloat16)
         low = _dry(unet, B, 128, 128, torch.bfloat16, {("cross_attention_block", "clip_text_embedding"): (77, 2048)})
         seen |= {native.gemm_signature(e[1][0]._obj).rsplit(":", 1)[0] for e in low.step if e[0] is not None and e[2].startswith("mi355x_gemm")}
