@@ -815,7 +815,6 @@ def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 1
     import os
 
     lo, hi = (os.environ.get("REFINERS_AMD_PF_BLOCKS", "").replace("-", ",") + ",").split(",")[:2]  # "min,max" or "min-max" (tools/ab_step.py splits its variants on commas)
-    pf_lora = os.environ.get("REFINERS_AMD_PF_LORA", "1") != "0"
     min_blocks = min_blocks if min_blocks is not None else int(lo or 32)
     max_blocks = max(min_blocks, max_blocks if max_blocks is not None else int(hi or 128))
     gemms = [e[1][0]._obj for e in ops if e[0] is not None and e[2].startswith("mi355x_gemm")]
@@ -826,12 +825,9 @@ def link_weight_prefetch(ops: list, enable: bool = True, min_bytes: int = 1 << 1
         a.prefetch_blocks = 0
         if not enable or len(gemms) < 2:
             continue
-        nxt = gemms[(i + 1) % len(gemms)]
-        spans = [(p, b) for p, b in weight_spans(nxt) if p and b >= min_bytes][:MAX_PREFETCH]
-        if pf_lora and nxt.lora_b and len(spans) < MAX_PREFETCH:
-            # the next launch's pre-scaled LoRA up rows [N, R]: small, read by every tile's tail -- i.e. on the path between its last MFMA and its epilogue --
-            # and otherwise first touched there (REFINERS_AMD_PF_LORA=0 switches this off)
-            spans.append((int(nxt.lora_b), int(nxt.N) * int(nxt.lora_r) * (4 if nxt.dtype == 0 else 2)))
+        # (round 6 also tried the next launch's LoRA up rows [N, R] in the free second slot -- they sit on the path between a tile's last MFMA and its epilogue --:
+        #  25.54 against 25.53 ms, profiles/r06_v_ab_pf_lora.log: all adapters' rows together are ~100 MB and stay in the Infinity Cache from step to step)
+        spans = [(p, b) for p, b in weight_spans(gemms[(i + 1) % len(gemms)]) if p and b >= min_bytes][:MAX_PREFETCH]
         if not spans:
             continue
         for s, (p, b) in enumerate(spans):

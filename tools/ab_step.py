@@ -23,7 +23,7 @@ from refiners_amd.engine import tuning  # noqa: E402
 from refiners_amd.engine.compiled import CompiledSDXL  # noqa: E402
 
 KEYS = ("REFINERS_AMD_LN_FUSE", "REFINERS_AMD_QKV_MERGE", "REFINERS_AMD_TUNING", "REFINERS_AMD_KBLOCK", "REFINERS_AMD_WEIGHT_PREFETCH", "REFINERS_AMD_TIME_BATCH", "REFINERS_AMD_ATTN_PIPE",
-        "REFINERS_AMD_GN_STATS", "REFINERS_AMD_TIME_TABLE", "REFINERS_AMD_CAT_FUSE", "REFINERS_AMD_TUNING_TABLE", "REFINERS_AMD_PF_BLOCKS", "REFINERS_AMD_LORA_G8", "REFINERS_AMD_CFG_SPLIT", "REFINERS_AMD_CFG_SPLIT_LEAD", "REFINERS_AMD_PF_LORA")
+        "REFINERS_AMD_GN_STATS", "REFINERS_AMD_TIME_TABLE", "REFINERS_AMD_CAT_FUSE", "REFINERS_AMD_TUNING_TABLE", "REFINERS_AMD_PF_BLOCKS", "REFINERS_AMD_LORA_G8", "REFINERS_AMD_CFG_SPLIT", "REFINERS_AMD_CFG_SPLIT_LEAD")
 
 
 def main() -> None:
