@@ -294,7 +294,7 @@ MI_DEV void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], const float* row
                             cs_a[e] += mok ? v[e] : 0.f;
                             cs_b[e] += mok ? v[e] * v[e] : 0.f;
                         }
-                        colsum16<RUN>(cs_a, cs_b, c16);
+                        if constexpr (RUN == 8 || RUN == 16) colsum16<RUN>(cs_a, cs_b, c16);  // (other runs: probing tiles only, never launched with column statistics)
                         const int blk = (m0 + wm * WME + 16 * (i - 1)) >> 5;  // (tiles start on multiples of 64 rows)
                         if ((RUN == 16 || c16 < 8) && (blk << 5) < p.M) {
                             f32x2 st = {cs_a[0], cs_b[0]};

@@ -755,6 +755,13 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
             }
         }
     }
+#ifdef MI355X_PROBE_T10  // (probing build, round 6: 128 x 96 tiles computed by four waves stacked along M -- wave tile 32 x 96 -- for plain launches: does the layout that a
+                         //  256-workgroup tile of N = 1280 (128 x 80) would need hold up against 64 x 64 tiles?  tools/probe_t10.py)
+    if constexpr (!CONV) {
+        if (g_tile == 10 || p.tile_hint == 10) return launch_cfg<T, 128, 96, 4, 1, false, 2>(p, stream);
+        if (g_tile == 11 || p.tile_hint == 11) return launch_cfg<T, 128, 96, 4, 1, false, 3>(p, stream);
+    }
+#endif
     switch (tile) {
         case 1: return launch_stages<T, 128, 128, CONV>(p, st, stream);
         case 2: return launch_stages<T, 128, 64, CONV>(p, st, stream);
