@@ -426,7 +426,10 @@ def test_every_tuned_signature_is_a_launch_of_the_lowered_step(monkeypatch):
     from refiners_amd.engine import tuning
 
     monkeypatch.setattr(tuning, "enabled", False)  # (signatures do not depend on the choice; this keeps tile-8 scratch off the meta device)
-    table = json.loads(tuning.TABLE_PATH.read_text())["choices"]
+    doc = json.loads(tuning.TABLE_PATH.read_text())
+    elsewhere = {k for keys in doc.get("other_workloads", {}).values() for k in keys}  # entries measured on another program (the SAM ViT-H encoder): listed by name
+    assert elsewhere <= set(doc["choices"])
+    table = {k: v for k, v in doc["choices"].items() if k not in elsewhere}
     seen = set()
     for B in (2, 8, 16):
         unet = SDXLUNet(4, device="meta", dtype=torch.bfloat16)

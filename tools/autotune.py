@@ -71,10 +71,24 @@ def main() -> None:
     dev = torch.device("cuda", 0)
     native.load()
     t_start = time.time()
-    unet, specs, bare_sd, pipe, _ = bench.build_pipeline(args.workload, args.images, 0, dev, torch.bfloat16, args.lora_mode, use_graph=False, broadcast=False)
-    pipe.step(0)
+    if args.workload == "sam":  # BASELINE configs[4]: the SAM ViT-H image encoder + HQ-SAM hook on one 1024 x 1024 image (its launches carry their own shape classes)
+        from refiners_amd.engine.sam import CompiledSAMViT
+        from refiners_amd.segment_anything import SAMViTAdapter, SAMViTH
+
+        vit = SAMViTH(device="meta")
+        bench.gpu_weights(vit, seed=11, dtype=torch.bfloat16, device=dev)
+        ad = SAMViTAdapter(vit).inject()
+        ad.set_context("hq_sam", {"early_vit_embedding": None})
+        fast = CompiledSAMViT(vit, use_graph=False)
+        with torch.no_grad():
+            fast(torch.rand(1, 3, 1024, 1024, device=dev).to(torch.bfloat16))
+        low = fast.low
+    else:
+        unet, specs, bare_sd, pipe, _ = bench.build_pipeline(args.workload, args.images, 0, dev, torch.bfloat16, args.lora_mode, use_graph=False, broadcast=False)
+        pipe.step(0)
+        low = pipe.engine.low
     torch.cuda.synchronize()
-    ops = pipe.engine.low.step
+    ops = low.step
     classes: dict[str, list] = {}
     for e in ops:
         if e[0] is not None and e[2].startswith("mi355x_gemm"):
@@ -112,7 +126,7 @@ def main() -> None:
                 a.tile, a.stages = tile, st
                 a.ksplit = 1 if tile in (7, 8, 9) else ks0
                 if tile == 8:
-                    native.attach_streamk(a, pipe.engine.low._sk)
+                    native.attach_streamk(a, low._sk)
 
         for tile, st in [(0, 0)] + candidates(a0, only):
             if ks0 > 1 and tile == 0:
