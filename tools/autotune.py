@@ -83,6 +83,16 @@ def main() -> None:
         with torch.no_grad():
             fast(torch.rand(1, 3, 1024, 1024, device=dev).to(torch.bfloat16))
         low = fast.low
+    elif args.workload == "vae":  # next-1 of SURVEY.md section 8(f): the SDXL VAE decoder on one 128 x 128 latent -> 1024 x 1024 image
+        from refiners_amd.engine.vae import CompiledVAEDecoder
+        from refiners_amd.latent_diffusion.vae import SDXLAutoencoder
+
+        vae = SDXLAutoencoder(device="meta")
+        bench.gpu_weights(vae, seed=7, dtype=torch.bfloat16, device=dev)
+        dec = CompiledVAEDecoder(vae)
+        with torch.no_grad():
+            dec(torch.randn(1, 4, 128, 128, device=dev).to(torch.bfloat16) * 0.13)
+        low = dec.low
     else:
         unet, specs, bare_sd, pipe, _ = bench.build_pipeline(args.workload, args.images, 0, dev, torch.bfloat16, args.lora_mode, use_graph=False, broadcast=False)
         pipe.step(0)
