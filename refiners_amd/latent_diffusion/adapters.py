@@ -88,31 +88,26 @@ class CrossAttentionAdapter(fl.Chain, Adapter[fl.Attention]):
         self.target.replace(both, both.layer("ScaledDotProductAttention", fl.ScaledDotProductAttention))
         super().eject()
 
-    @property
-    def image_cross_attention(self) -> ImageCrossAttention:
-        return self._image_cross_attention[0]
+    # -- the reference's accessor surface (image_prompt.py: CrossAttentionAdapter), one implementation behind it -----------------------------------
+    def _image_branch(self) -> ImageCrossAttention:
+        (branch,) = self._image_cross_attention  # (kept in a list so that it is not registered as a child: the target owns it once injected)
+        return branch
 
-    @property
-    def image_key_projection(self) -> fl.Linear:
-        return self.image_cross_attention.layer(("Distribute", 1, "Linear"), fl.Linear)
+    def _image_projection(self, slot: int) -> fl.Linear:
+        """The Linear of Distribute slot `slot` inside the image branch: 1 = keys, 2 = values (slot 0 passes the query through)."""
+        return self._image_branch().layer(("Distribute", slot, "Linear"), fl.Linear)
 
-    @property
-    def image_value_projection(self) -> fl.Linear:
-        return self.image_cross_attention.layer(("Distribute", 2, "Linear"), fl.Linear)
-
-    @property
-    def scale(self) -> float:
-        return self.image_cross_attention.scale
-
-    @scale.setter
-    def scale(self, value: float) -> None:
-        self.image_cross_attention.scale = value
+    image_cross_attention = property(_image_branch)
+    image_key_projection = property(lambda self: self._image_projection(1))
+    image_value_projection = property(lambda self: self._image_projection(2))
+    scale = property(lambda self: self._image_branch().scale, lambda self, value: setattr(self._image_branch(), "scale", value))
 
     def load_weights(self, key_tensor: Tensor, value_tensor: Tensor) -> None:
-        self.image_key_projection.weight = nn.Parameter(key_tensor)
-        self.image_value_projection.weight = nn.Parameter(value_tensor)
-        self.image_cross_attention.to(self.device, self.dtype)
-        bump_epoch()
+        """Adopt the checkpoint's to_k_ip / to_v_ip matrices (moved to this adapter's device / dtype with the rest of the image branch)."""
+        for slot, tensor in ((1, key_tensor), (2, value_tensor)):
+            self._image_projection(slot).weight = nn.Parameter(tensor)
+        self._image_branch().to(self.device, self.dtype)
+        bump_epoch()  # packed copies of the old matrices are stale
 
 
 class IPAdapter(fl.Chain, Adapter[fl.Chain]):
