@@ -64,9 +64,12 @@ namespace mi355x {
 // over VGPRs AND AGPRs (128 x 128: 181 + 128, 128 x 64: 141 + 64, 64 x 64: 117 + 32) and they end up ONE wave per SIMD below the un-adapted
 // tile of the same size -- a producer workgroup then owns a whole CU while it waits on its loads.  With the un-adapted tile's occupancy as the
 // floor the same code fits into 237 / 168 / 117 VGPRs, no AGPR copies, no scratch (hipcc -Rpass-analysis=kernel-resource-usage).
+#ifndef MI355X_LORA64_WAVES
+#define MI355X_LORA64_WAVES 4  // waves per SIMD the 64 x 64 LoRA instance leaves room for (the plain instance: 84 registers = 5; at 5 the LoRA instance spills 74 registers and the step loses 1.3 %: 24.15 -> 24.47 ms, profiles/r06_zf_ab_lora64_waves.log)
+#endif
 template <typename T, int BM, int BN, bool LORA> constexpr int gemm_min_waves() {
     if (!LORA || sizeof(T) != 2) return 1;
-    return BM * BN == 128 * 128 ? 2 : BM * BN == 64 * 64 ? 4 : BM == 128 ? 3 : 2;
+    return BM * BN == 128 * 128 ? 2 : BM * BN == 64 * 64 ? MI355X_LORA64_WAVES : BM == 128 ? 3 : 2;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, int KG = 1, bool LORA = false>
