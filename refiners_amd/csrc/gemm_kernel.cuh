@@ -763,6 +763,12 @@ int launch_tile(const GemmP& p, hipStream_t stream) {
     if constexpr (!CONV) {
         if (g_tile == 10 || p.tile_hint == 10) return launch_cfg<T, 128, 96, 4, 1, false, 2>(p, stream);
         if (g_tile == 11 || p.tile_hint == 11) return launch_cfg<T, 128, 96, 4, 1, false, 3>(p, stream);
+        // TWO-wave workgroups (128 threads): fewer LDS fragment reads per MFMA at the same tile -- 64 x 64 as 2 x (32 x 64): 0.75 instead of 1.0;
+        // 128 x 64 as 2 x (64 x 64): 0.5 instead of 0.75 -- and more workgroups per CU for the same LDS
+        if (g_tile == 12 || p.tile_hint == 12) return launch_cfg<T, 64, 64, 2, 1, false, 2>(p, stream);
+        if (g_tile == 13 || p.tile_hint == 13) return launch_cfg<T, 64, 64, 2, 1, false, 3>(p, stream);
+        if (g_tile == 14 || p.tile_hint == 14) return launch_cfg<T, 128, 64, 2, 1, false, 2>(p, stream);
+        if (g_tile == 15 || p.tile_hint == 15) return launch_cfg<T, 128, 64, 2, 1, false, 3>(p, stream);
     }
 #endif
     switch (tile) {

@@ -21,6 +21,9 @@ def main():
     # (M, K, N): N = 1536 = 16 x 96 -> 16 x 16 = 256 tiles of 128 x 96; the same FLOPs per tile as 128 x 80 x 1.2
     shapes = [("proj-like", 2048, 1280, 1536), ("FF2-like", 2048, 5120, 1536), ("proj", 2048, 1280, 1280), ("FF2", 2048, 5120, 1280)]
     tiles = [(0, 0), (1, 2), (2, 2), (3, 2), (4, 2), (6, 2), (10, 0), (11, 0)]
+    if "--two-waves" in sys.argv:  # 128-thread workgroups: 64 x 64 (ids 12 / 13: 2 / 3 stages) and 128 x 64 (14 / 15) against the 4-wave product tiles
+        shapes = shapes[2:] + [("QKV", 2048, 1280, 3840), ("640", 8192, 640, 640)]
+        tiles = [(4, 2), (2, 2), (1, 2), (12, 0), (13, 0), (14, 0), (15, 0)]
     if "--stages" in sys.argv:  # the product tiles with 3 / 4 LDS stages (the in-launch LoRA instances exist with two only)
         shapes = shapes[2:] + [("QKV", 2048, 1280, 3840), ("640", 8192, 640, 640)]
         tiles = [(4, 2), (4, 3), (4, 4), (3, 2), (3, 3), (3, 4), (2, 2), (2, 3), (1, 2), (1, 3)]
