@@ -36,6 +36,9 @@ def main():
     lib = native.load()
     shapes = [(2, 1024, 1280), (2, 4096, 640), (2, 16384, 320), (2, 1024, 2560), (8, 1024, 1280), (8, 4096, 640), (8, 16384, 320), (8, 16384, 640)]
     variants = [(512, 4), (1024, 4), (2048, 4), (4096, 4), (1024, 8), (2048, 8), (4096, 8)]
+    if "--vae" in sys.argv:  # the VAE decoder's large GroupNorms (one 1024 x 1024 image)
+        shapes = [(2, 16384, 320), (2, 4096, 640), (1, 262144, 256), (1, 1048576, 128)]
+        variants = [(2048, 4), (2048, 8), (8192, 4), (8192, 8)]
     for B, HW, C in shapes:
         xs = [torch.randn(B, HW, C, device=dev).to(dt) for _ in range(4)]
         o = torch.empty(B, HW, C, device=dev, dtype=dt)
