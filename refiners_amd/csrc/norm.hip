@@ -236,7 +236,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __restrict__ cs, const float* __restrict__ cs2, int C1, int HW, int C, int G,
                                                               const T* __restrict__ gamma, float eps, float* __restrict__ tab) {
     __shared__ double red[256 * 2];
-    __shared__ double mean_c[256], m2_c[256];
+    __shared__ double mean_c[256];
     __shared__ float stat[2];
     const int g = blockIdx.x, b = blockIdx.y;
     const int cg = C / G, nblk = HW / 32;
@@ -252,46 +252,54 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
         // the two sources keep their own [block][channel] tables: C1 channels wide for x, C - C1 for x2
         const int Cs = c < C1 ? C1 : C - C1;
         const f32x2* pp = c < C1 ? reinterpret_cast<const f32x2*>(cs) + ((int64_t)b * nblk * C1 + c) : reinterpret_cast<const f32x2*>(cs2) + ((int64_t)b * nblk * Cs + (c - C1));
-        int k = j;
-        for (; k + 7 * L < nblk; k += 8 * L) {
+        // eight independent loads in flight in EVERY batch: the tail of a thread's blocks is padded with re-reads of its first block at weight zero
+        // (round 6: a serial remainder loop -- the whole loop at 32 x 32 pixels, where 8 L exceeds the 32 blocks -- cost one L2 round trip per block)
+        for (int k = j; k < nblk; k += 8 * L) {
             f32x2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(k + u * L) * Cs];
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k + u * L;
+                v[u] = pp[(int64_t)(kk < nblk ? kk : k) * Cs];
+                if (kk >= nblk) v[u] = f32x2{0.f, 0.f};
+            }
             s1 += (((double)v[0][0] + (double)v[1][0]) + ((double)v[2][0] + (double)v[3][0])) + (((double)v[4][0] + (double)v[5][0]) + ((double)v[6][0] + (double)v[7][0]));
             s2 += (((double)v[0][1] + (double)v[1][1]) + ((double)v[2][1] + (double)v[3][1])) + (((double)v[4][1] + (double)v[5][1]) + ((double)v[6][1] + (double)v[7][1]));
-        }
-        for (; k < nblk; k += L) {
-            const f32x2 v = pp[(int64_t)k * Cs];
-            s1 += v[0];
-            s2 += v[1];
         }
     }
     red[t * 2 + 0] = s1;
     red[t * 2 + 1] = s2;
     __syncthreads();
     const double n = (double)HW;
+    double mc = 0.0, m2c = 0.0;  // threads 0 .. cg - 1: (mean, M2) of their channel
     if (on && j == 0) {
         double a1 = 0.0, a2 = 0.0;
         for (int q = 0; q < L; ++q) {
             a1 += red[(cl + cg * q) * 2 + 0];
             a2 += red[(cl + cg * q) * 2 + 1];
         }
-        mean_c[cl] = a1 / n;
+        mc = a1 / n;
         const double m2 = a2 - a1 * a1 / n;
-        m2_c[cl] = m2 > 0.0 ? m2 : 0.0;
+        m2c = m2 > 0.0 ? m2 : 0.0;
     }
-    __syncthreads();
-    if (t == 0) {
-        double mg = 0.0;
-        for (int q = 0; q < cg; ++q) mg += mean_c[q];
-        mg /= (double)cg;
-        double m2 = 0.0;
-        for (int q = 0; q < cg; ++q) {
-            const double d = mean_c[q] - mg;
-            m2 += m2_c[q] + n * d * d;
+    // the group's mean and M2 over its cg channels: two fixed-pairing tree reductions over 256 slots (deterministic; round 6: thread 0 walked the channels
+    // twice on its own -- 2 x 80 dependent LDS round trips at 2 560 channels)
+    auto block_sum = [&](double v) {
+        __syncthreads();
+        mean_c[t] = v;
+        __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) {
+            if (t < sft) mean_c[t] += mean_c[t + sft];
+            __syncthreads();
         }
+        return mean_c[0];
+    };
+    const bool mine = on && j == 0;
+    const double mg = block_sum(mine ? mc : 0.0) / (double)cg;
+    const double dm = mc - mg;
+    const double m2g = block_sum(mine ? m2c + n * dm * dm : 0.0);
+    if (t == 0) {
         stat[0] = (float)mg;
-        stat[1] = rsqrtf((float)(m2 / (n * (double)cg)) + eps);
+        stat[1] = rsqrtf((float)(m2g / (n * (double)cg)) + eps);
     }
     __syncthreads();
     if (t < cg) {
