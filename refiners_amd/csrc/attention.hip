@@ -45,6 +45,7 @@ struct AttnP {
     char* out;
     int64_t ldob, obsb;
     float c;  // scale * log2(e)
+    float thr;  // OPT bit 2: a tile leaves the running maximum alone while no score exceeds it by more than thr (= 8 / c: P <= 2^8)
     KvP kv[2];
     int qtiles;
     int xcd;  // 1 = XCD-aware block order
@@ -85,6 +86,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
     // RD = register sets of the register-staged loader = K/V tiles in flight (1 or 2)
     // OPT bit 0: the two cross-group reductions of the online softmax as v_permlane16/32_swap (VALU) instead of ds_bpermute round trips;
     //     bit 1: all K fragments of a tile read before its first MFMA, all V^T fragments before the softmax (one exposed LDS latency per phase)
+    //     bit 2 (bf16): LAZY running maximum -- every lane compares the maximum of its OWN 16 scores with (running maximum + thr); only when some lane of the
+    //         wave is above (wave-uniform branch) are the cross-lane maximum, the new running maximum and the O / l rescale done at all.  Otherwise the tile
+    //         is exponentiated against the old reference (P <= 2^8, exact in the quotient O / l): per tile and 16-query group 8 cross-lane / rescale
+    //         operations + 8 packed multiplies of O fall away -- the loop is bound by its vector instructions (34 v_exp + ~120 others against 32 MFMAs)
+    //     bit 3 (bf16): the row sums l come out of the matrix pipe -- one more MFMA per P^T fragment against a fragment of ones (l = sum of the ROUNDED P the
+    //         P V product uses) instead of 16 vector adds per 16-query group and tile; no cross-lane sum at the end
     // ABL (probing only, results are wrong): 1 = no K/V traffic after the first tile, 2 = no softmax, 4 = no P V product, 8 = no Q K^T product,
     //     16 = no output store, 32 = no Q load, 64 = no K/V load at all
     // KVS = 2: key-split workgroup for grids that leave the SIMDs with one wave each (a CFG pair's 1024-token self-attention): the NW waves
@@ -207,6 +214,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
         float mrun[NJQ], lsum[NJQ];
 #pragma unroll
         for (int jq = 0; jq < NJQ; ++jq) mrun[jq] = -INFINITY, lsum[jq] = 0.f;
+        constexpr bool LAZY = IS_BF16 && (OPT & 4) != 0 && KVS == 1 && !(ABL & 2);
+        constexpr bool ONES = IS_BF16 && (OPT & 8) != 0 && KVS == 1 && !(ABL & 6);
+        f32x4 lacc[NJQ];  // ONES: row sums as an MFMA accumulator (its four rows are equal)
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) lacc[jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const frag_t ones = frag_t{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
 
         // all waves must be done reading LDS of the previous stream before it is overwritten
         __syncthreads();
@@ -313,8 +326,49 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
                     }
             }
             // ---- online softmax (per lane: one query column per jq) ----
+            if constexpr (LAZY) {
+                float mloc[NJQ];
+                bool need = false;
 #pragma unroll
-            for (int jq = 0; jq < NJQ; ++jq) {
+                for (int jq = 0; jq < NJQ; ++jq) {
+                    float mx = st[0][jq][0];
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][jq][r]);
+                    mloc[jq] = mx;
+                    need |= mx > mrun[jq] + p.thr;  // first tile: running maximum = -inf
+                }
+                if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform: some query of this wave moves its reference
+#pragma unroll
+                    for (int jq = 0; jq < NJQ; ++jq) {
+                        const float mx = group_max<(OPT & 1) != 0>(mloc[jq]);
+                        const float mnew = fmaxf(mrun[jq], mx);
+                        const float alpha = fast_exp2((mrun[jq] - mnew) * p.c);
+                        mrun[jq] = mnew;
+                        if constexpr (ONES) lacc[jq] *= alpha;
+                        else lsum[jq] *= alpha;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
+                    }
+                }
+#pragma unroll
+                for (int jq = 0; jq < NJQ; ++jq) {
+                    const float mc = mrun[jq] * p.c;
+                    float ps = 0.f;
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = fast_exp2(st[t][jq][r] * p.c - mc);
+                            st[t][jq][r] = e;
+                            if constexpr (!ONES) ps += e;
+                        }
+                    if constexpr (!ONES) lsum[jq] += ps;
+                }
+            }
+#pragma unroll
+            for (int jq = 0; jq < (LAZY ? 0 : NJQ); ++jq) {
                 if constexpr (ABL & 2) {
                     float ps = 0.f;
 #pragma unroll
@@ -341,9 +395,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
                     for (int r = 0; r < 4; ++r) {
                         const float e = fast_exp2(st[t][jq][r] * p.c - mc);
                         st[t][jq][r] = e;
-                        ps += e;
+                        if constexpr (!ONES) ps += e;
                     }
-                lsum[jq] = lsum[jq] * alpha + ps;
+                if constexpr (ONES) lacc[jq] *= alpha;
+                else lsum[jq] = lsum[jq] * alpha + ps;
                 mrun[jq] = mnew;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
@@ -368,6 +423,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
                             pk[4 + r] = (bf16_t)st[2 * s2l + 1][jq][r];
                         }
                         pb[jq] = __builtin_bit_cast(frag_t, pk);
+                    }
+                    if constexpr (ONES) {
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(lacc[jq], ones, pb[jq]);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -447,7 +506,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
         // ---- finish this stream ----
 #pragma unroll
         for (int jq = 0; jq < NJQ; ++jq) {
-            const float l = group_sum<(OPT & 1) != 0>(lsum[jq]);
+            float l;
+            if constexpr (ONES) l = lacc[jq][0];
+            else l = group_sum<(OPT & 1) != 0>(lsum[jq]);
             const float inv = kv.out_scale / l;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -478,6 +539,353 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(sizeof(
 #pragma unroll
             for (int e = 0; e < EPC; ++e) ov.set(e, v[c * EPC + e]);
             store16<T>(op + c * EPC, ov);
+        }
+    }
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+MI_DEV rsrc_t make_rsrc(const char* base, int64_t bytes) {  // wave-uniform by construction; readfirstlane makes that provable (otherwise every load sits in a waterfall loop)
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const int64_t nb = bytes < 0x7ffffff0 ? bytes : 0x7ffffff0;
+    const int n = __builtin_amdgcn_readfirstlane((int)nb);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, n, 0x00020000);
+}
+// 16 bytes per lane, global -> LDS: lane i lands at lds_wave_base + 16 i; source = descriptor base + voff (per lane) + soff (scalar); bytes beyond the descriptor's range read as zero
+MI_DEV void blds16(rsrc_t rs, char* lds_wave_base, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- software-pipelined loop
+// attn_kernel's loop is a chain: Q K^T (MFMA) -> softmax (vector) -> P V (MFMA), and measured per wave-tile its time is the SUM of the matrix
+// pipe's and the vector unit's (32 MFMAs x 16 cycles + ~120-200 vector instructions; removing any part removes exactly its own time,
+// profiles/r06_r_probe_attn_ablate.log, r06_zi_probe_attn_opt.log): co-resident waves do not fill each other's gaps.  Here ONE wave keeps both
+// busy: K runs one tile ahead of V, and an iteration is
+//     phase 1      Q K^T of tile i + 1            ||  exponentials of tile i, query group 0
+//     phase 1 + j  P V of tile i, group j - 1     ||  exponentials of tile i, group j           (32-query waves: one such phase)
+//     last phase   P V of tile i, last group      ||  the maxima of tile i + 1 (the lazy running maximum's check)
+// with the order MFMA, a few vector instructions, MFMA ... pinned by sched_group_barrier; the rare rescale (a wave-uniform branch) sits between
+// the iterations.  Lazy running maximum and row sums from the matrix pipe as in attn_kernel's OPT bits 2 / 3.  bf16, one K/V stream, head_dim 64.
+//   LDS: K(j) in K buffer j & 1, V^T(j) in V buffer j & 1; iteration i reads K(i + 1) and V(i), and commits K(i + 2) (into the buffer K(i) left in
+//   iteration i - 1) and V(i + 1) (into the one V(i - 1) left) from registers loaded at its start; one barrier per iteration.
+// ABL (probing, wrong results): 1 = no exponentials, 2 = no Q K^T MFMAs, 4 = no P V MFMAs, 8 = no K/V loads and commits in the loop, 16 = no barrier in the loop, 32 = no maxima
+// DMA: K / V^T tiles go global -> LDS directly (buffer_load ... lds, issued at the START of the iteration into the buffers the previous iteration left:
+//      the one-tile lead of K means they are free a whole iteration before they are read -- no deeper ring, no staging registers, no ds_write)
+template <int NJQ, int SCHED, int ABL = 0, bool DMA = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_pipe_kernel(const AttnP p) {
+    using T = bf16_t;
+    constexpr int NW = 4, D = 64, BKV = 64, BQW = 16 * NJQ, ES = 2, ROWB = D * ES, CPR = ROWB / 16, NTHR = NW * 64, TILEB = 64 * ROWB;
+    constexpr int LI = 64 * CPR / NTHR, NS = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    const int g = lane >> 4, c16 = lane & 15;
+    int bid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int qt = bid % p.qtiles;
+    bid /= p.qtiles;
+    const int h = bid % p.H;
+    const int b = bid / p.H;
+    const int q0 = qt * (BQW * NW) + wid * BQW;
+
+    frag_t qf[NJQ][NS];
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) {
+        int qr = q0 + 16 * jq + c16;
+        qr = qr < p.Lq ? qr : p.Lq - 1;
+        const char* qp = p.q + (int64_t)b * p.qbsb + (int64_t)qr * p.ldqb + (int64_t)h * ROWB;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[jq][s] = *reinterpret_cast<const frag_t*>(qp + (4 * s + g) * 16);
+    }
+
+    const KvP& kv = p.kv[0];
+    const int Lk = kv.Lk;
+    const int ntile = (Lk + BKV - 1) / BKV;
+    const char* kbase = kv.k + (int64_t)b * kv.kbsb + (int64_t)h * ROWB;
+    const char* vbase = kv.vt + (int64_t)h * D * kv.ldvtb + (int64_t)b * kv.vtbsb;
+    char* const kbuf = smem;
+    char* const vbuf = smem + 2 * TILEB;
+    // loader: a tile's address = wave-uniform base (scalar registers) + a per-lane 32-bit offset that does not change along the keys, so a load costs the
+    // loop no vector arithmetic; the last tile's K rows beyond Lk are clamped through a second offset set
+    uint32_t koff[LI], koff_last[LI], voff[LI];
+#pragma unroll
+    for (int it = 0; it < LI; ++it) {
+        const int q = it * NTHR + tid, row = q / CPR, pch = q % CPR;
+        const int key = k_row_key(row);
+        const int coff = (pch ^ swz<ROWB>(row)) << 4;
+        const int last = Lk - 1 - (ntile - 1) * BKV;
+        koff[it] = (uint32_t)(key * (int)kv.ldkb + coff);
+        koff_last[it] = (uint32_t)((key < last ? key : last) * (int)kv.ldkb + coff);
+        const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
+        voff[it] = (uint32_t)((16 * a + 4 * j + bb) * (int)kv.ldvtb + coff);
+    }
+
+    const rsrc_t krs = make_rsrc(kbase, (int64_t)(Lk - 1) * kv.ldkb + ROWB);
+    const rsrc_t vrs = make_rsrc(vbase, (int64_t)(D - 1) * kv.ldvtb + (int64_t)ntile * BKV * ES);
+    auto dma_k = [&](int tile, int buf) {
+        const uint32_t soff = (uint32_t)(tile * BKV) * (uint32_t)kv.ldkb;
+        const bool lastt = tile == ntile - 1;
+#pragma unroll
+        for (int it = 0; it < LI; ++it) blds16(krs, kbuf + buf * TILEB + (it * NTHR + wid * 64) * 16, lastt ? koff_last[it] : koff[it], soff);
+    };
+    auto dma_v = [&](int tile, int buf) {
+        const uint32_t soff = (uint32_t)(tile * BKV * ES);
+#pragma unroll
+        for (int it = 0; it < LI; ++it) blds16(vrs, vbuf + buf * TILEB + (it * NTHR + wid * 64) * 16, voff[it], soff);
+    };
+    frag_t kr[LI], vr[LI];
+    auto load_k = [&](int tile) {
+        const char* base = kbase + (int64_t)tile * BKV * kv.ldkb;
+        const bool lastt = tile == ntile - 1;
+#pragma unroll
+        for (int it = 0; it < LI; ++it) kr[it] = *reinterpret_cast<const frag_t*>(base + (lastt ? koff_last[it] : koff[it]));
+    };
+    auto load_v = [&](int tile) {
+        const char* base = vbase + (int64_t)tile * BKV * ES;
+#pragma unroll
+        for (int it = 0; it < LI; ++it) vr[it] = *reinterpret_cast<const frag_t*>(base + voff[it]);
+    };
+    auto commit_k = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < LI; ++it) *reinterpret_cast<frag_t*>(kbuf + buf * TILEB + (it * NTHR + tid) * 16) = kr[it];
+    };
+    auto commit_v = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < LI; ++it) *reinterpret_cast<frag_t*>(vbuf + buf * TILEB + (it * NTHR + tid) * 16) = vr[it];
+    };
+
+    f32x4 o[4][NJQ], lacc[NJQ];
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) {
+        lacc[jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float mrun[NJQ];
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) mrun[jq] = -INFINITY;
+    const frag_t ones = frag_t{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
+
+    auto qk = [&](const char* ks, f32x4(&sn)[4][NJQ]) {
+        frag_t kf[4][NS];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) kf[t][s] = lds_read_frag(ks, tile_off<ROWB>(16 * t + c16, 4 * s + g));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int jq = 0; jq < NJQ; ++jq) sn[t][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int jq = 0; jq < NJQ; ++jq) {
+                    if constexpr (ABL & 2) sn[t][jq] += __builtin_bit_cast(f32x4, kf[t][s]);
+                    else mma_step<T>(sn[t][jq], kf[t][s], qf[jq][s]);
+                }
+        }
+    };
+    auto mask_tail = [&](int tile, f32x4(&sn)[4][NJQ]) {  // keys beyond Lk (last tile only)
+        const int kv0 = tile * BKV;
+        if (kv0 + BKV > Lk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kv0 + k_row_key(16 * t + 4 * g + r) >= Lk) {
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) sn[t][jq][r] = -INFINITY;
+                    }
+                }
+        }
+    };
+    auto local_max = [&](const f32x4(&sn)[4][NJQ], float(&mloc)[NJQ]) {
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) {
+            float mx = sn[0][jq][0];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sn[t][jq][r]);
+            asm volatile("" : "+v"(mx));
+            mloc[jq] = mx;
+        }
+    };
+    auto move_reference = [&](const float(&mloc)[NJQ]) {  // between iterations: every P V issued so far is in o / lacc
+        bool need = false;
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) need |= mloc[jq] > mrun[jq] + p.thr;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+            for (int jq = 0; jq < NJQ; ++jq) {
+                const float mx = group_max<true>(mloc[jq]);
+                const float mnew = fmaxf(mrun[jq], mx);
+                const float alpha = fast_exp2((mrun[jq] - mnew) * p.c);
+                mrun[jq] = mnew;
+                lacc[jq] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
+            }
+        }
+    };
+    auto expo = [&](f32x4(&sc)[4][NJQ], int jq, frag_t(&pb)[2]) {
+        const float mc = mrun[jq] * p.c;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (ABL & 1) {
+                    pk[r] = (bf16_t)sc[2 * s2][jq][r];
+                    pk[4 + r] = (bf16_t)sc[2 * s2 + 1][jq][r];
+                } else {
+                    pk[r] = (bf16_t)fast_exp2(sc[2 * s2][jq][r] * p.c - mc);
+                    pk[4 + r] = (bf16_t)fast_exp2(sc[2 * s2 + 1][jq][r] * p.c - mc);
+                }
+            }
+            pb[s2] = __builtin_bit_cast(frag_t, pk);
+            asm volatile("" : "+v"(pb[s2]));  // the packed fragment exists HERE (IR-level sinking otherwise moves the exponentials down to the P V product that uses them)
+        }
+    };
+    auto read_v = [&](const char* vs, frag_t(&vf)[2][4]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vf[s2][i] = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * s2 + g));
+    };
+    auto pv = [&](const frag_t(&vf)[2][4], int jq, const frag_t(&pb)[2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if constexpr (ABL & 4) {
+                lacc[jq] += __builtin_bit_cast(f32x4, pb[s2]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i][jq] += __builtin_bit_cast(f32x4, vf[s2][i]);
+                continue;
+            }
+            mma_step<T>(lacc[jq], ones, pb[s2]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma_step<T>(o[i][jq], vf[s2][i], pb[s2]);
+        }
+    };
+    // order of one phase: NDS LDS reads and HEADV vector instructions up front, then NM x { one MFMA, PERGAP vector instructions }
+    auto pin = [&](auto nds, auto headv, auto nm, auto pergap) {
+        if constexpr (SCHED != 0) {
+            if constexpr (decltype(nds)::value > 0) __builtin_amdgcn_sched_group_barrier(0x100, decltype(nds)::value, 0);
+            if constexpr (decltype(headv)::value > 0) __builtin_amdgcn_sched_group_barrier(0x402, decltype(headv)::value, 0);
+#pragma unroll
+            for (int m = 0; m < decltype(nm)::value; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (decltype(pergap)::value > 0) __builtin_amdgcn_sched_group_barrier(0x402, decltype(pergap)::value, 0);
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I8 = std::integral_constant<int, 8>;
+
+    // ---- prologue: K(0), V(0), K(1) ----
+    if constexpr (DMA) {
+        dma_k(0, 0);
+        dma_v(0, 0);
+        dma_k(ntile > 1 ? 1 : 0, 1);
+        wait_vm0();
+    } else {
+        load_k(0);
+        load_v(0);
+        commit_k(0);
+        commit_v(0);
+        load_k(ntile > 1 ? 1 : 0);
+        commit_k(1);
+    }
+    __syncthreads();
+    f32x4 sa[4][NJQ], sb[4][NJQ];
+    qk(kbuf, sa);
+    mask_tail(0, sa);
+    {
+        float mloc[NJQ];
+        local_max(sa, mloc);
+        move_reference(mloc);
+    }
+
+    // one iteration: `sc` = scores of tile i (in), `sn` = scores of tile i + 1 (out, NEXT only)
+    auto body = [&](int i, f32x4(&sc)[4][NJQ], f32x4(&sn)[4][NJQ], auto next) {
+        constexpr bool NEXT = decltype(next)::value;
+        if constexpr (NEXT && !(ABL & 8)) {
+            if constexpr (DMA) {
+                dma_k(i + 2 < ntile ? i + 2 : ntile - 1, i & 1);
+                dma_v(i + 1, (i + 1) & 1);
+            } else {
+                load_k(i + 2 < ntile ? i + 2 : ntile - 1);
+                load_v(i + 1);
+            }
+        }
+        frag_t pb[NJQ][2];
+        frag_t vf[2][4];
+        // phase 1
+        if constexpr (NEXT) qk(kbuf + ((i + 1) & 1) * TILEB, sn);
+        expo(sc, 0, pb[0]);
+        if constexpr (NEXT) pin(I8{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 8 * NJQ>{}, std::integral_constant<int, (NJQ == 2 ? 2 : 4)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        read_v(vbuf + (i & 1) * TILEB, vf);
+        // middle phases
+#pragma unroll
+        for (int jq = 1; jq < NJQ; ++jq) {
+            pv(vf, jq - 1, pb[jq - 1]);
+            expo(sc, jq, pb[jq]);
+            pin(I8{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // last phase
+        if constexpr (NEXT) mask_tail(i + 1, sn);  // (a wave-uniform branch: in front of the phase, not inside it)
+        pv(vf, NJQ - 1, pb[NJQ - 1]);
+        float mloc[NJQ];
+        if constexpr (NEXT && (ABL & 32)) {
+#pragma unroll
+            for (int jq = 0; jq < NJQ; ++jq) mloc[jq] = sn[0][jq][0];
+        }
+        if constexpr (NEXT && !(ABL & 32)) {
+            local_max(sn, mloc);
+            pin(std::integral_constant<int, (NJQ == 1 ? 8 : 0)>{}, I0{}, std::integral_constant<int, 10>{}, std::integral_constant<int, (NJQ == 2 ? 3 : 2)>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NEXT) {
+            move_reference(mloc);
+            if constexpr (!(ABL & 8)) {
+                if constexpr (DMA) {
+                    wait_vm0();
+                } else {
+                    commit_k(i & 1);
+                    commit_v((i + 1) & 1);
+                }
+            }
+            if constexpr (!(ABL & 16)) __syncthreads();
+        }
+    };
+    {
+        int i = 0;
+        for (; i + 2 < ntile; i += 2) {
+            body(i, sa, sb, std::true_type{});
+            body(i + 1, sb, sa, std::true_type{});
+        }
+        if (i + 1 < ntile) {  // two tiles left
+            body(i, sa, sb, std::true_type{});
+            body(i + 1, sb, sa, std::false_type{});
+        } else {
+            body(i, sa, sb, std::false_type{});
+        }
+    }
+
+    // ---- store: lane owns d = 16g + 4i + r (16 consecutive) of query 16jq + c16 ----
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) {
+        const int qr = q0 + 16 * jq + c16;
+        if (qr >= p.Lq) continue;
+        const float inv = kv.out_scale / lacc[jq][0];
+        T* op = reinterpret_cast<T*>(p.out + (int64_t)b * p.obsb + (int64_t)qr * p.ldob + (int64_t)h * ROWB) + 16 * g;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            Vec16<T> ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov.set(e, o[(c * 8 + e) >> 2][jq][e & 3] * inv);
+            store16<T>(op + c * 8, ov);
         }
     }
 }
@@ -723,7 +1131,7 @@ int launch_attn_short(const AttnP& p0, int xcd, hipStream_t stream) {
 int g_attn_glds = 0;   // register-staged K/V loader by default: measured faster than glds for attention (probe_attn3)
 int g_attn_depth = 1;  // K/V tiles in flight in the register-staged loader (mi355x_attention_set_pipeline); 2 measured no better (r02_j_probe_attn.log)
 int g_attn_xcd = 1;    // q-tiles of a head on one XCD
-int g_attn_opt = 1;    // OPT bits of attn_kernel (permlane reductions: +1-4 % on every self-attention shape, r02_k / r02_m probes)
+int g_attn_opt = 13;   // OPT bits of attn_kernel: permlane reductions (+1-4 % on every self-attention shape, r02_k / r02_m probes), lazy running maximum + row sums from the matrix pipe (bf16 one-stream launches: -11 ... -13 %, r06_zi_probe_attn_opt.log)
 int g_attn_abl = 0;    // ABL bits (probing)
 int g_attn_kvs = 0;    // short grids (see launch_attn_nw): 0 = 16-query waves where the grid is short, 1 = never, 2 = key-split workgroups always, 3 = 16-query waves always (single-stream launches)
 
@@ -745,6 +1153,25 @@ int launch_attn(const AttnP& p0, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
 }
 
+int g_attn_pipe = 3;  // software-pipelined loop (attn_pipe_kernel) for bf16 one-stream launches: 0 = off, 1 = register-staged K/V, 2 = the same without the pinned instruction order (probing), 3 = K/V by LDS-DMA (default: 1024 tokens 26.8 -> 19.2 us, 4096 tokens 133 -> 109 us, r06_zl_probe_attn_dma.log)
+
+template <int NJQ, int SCHED, int ABL = 0, bool DMA = false>
+int launch_attn_pipe(const AttnP& p0, hipStream_t stream) {
+    constexpr int LDS = 4 * 64 * 64 * 2;
+    auto kfn = attn_pipe_kernel<NJQ, SCHED, ABL, DMA>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    AttnP p = p0;
+    constexpr int BQ = 16 * NJQ * 4;
+    p.qtiles = (p.Lq + BQ - 1) / BQ;
+    p.xcd = g_attn_xcd;
+    hipLaunchKernelGGL(kfn, dim3(p.qtiles * p.H * p.B), dim3(256), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
+}
+
 int g_attn_nw = 0;  // 0 = heuristic, 2 / 4 = force the number of waves (32 queries each) per workgroup
 
 template <typename T, int NW, int OPT>
@@ -763,6 +1190,31 @@ int launch_attn_opt(const AttnP& p, hipStream_t stream) {
 
 template <typename T, int NW>
 int launch_attn_nw(const AttnP& p, hipStream_t stream) {
+    if constexpr (NW == 4 && sizeof(T) == 2) {
+#ifdef MI355X_ATTN_PIPE_ABL  // probing build (python -m refiners_amd.build_native --variant pipeabl MI355X_ATTN_PIPE_ABL=1)
+        if (g_attn_pipe && p.nstream == 1 && g_attn_abl != 0) {
+            switch (g_attn_abl) {
+                case 1: return launch_attn_pipe<2, 1, 1>(p, stream);
+                case 2: return launch_attn_pipe<2, 1, 2>(p, stream);
+                case 4: return launch_attn_pipe<2, 1, 4>(p, stream);
+                case 6: return launch_attn_pipe<2, 1, 6>(p, stream);
+                case 8: return launch_attn_pipe<2, 1, 8>(p, stream);
+                case 16: return launch_attn_pipe<2, 1, 16>(p, stream);
+                case 24: return launch_attn_pipe<2, 1, 24>(p, stream);
+                case 32: return launch_attn_pipe<2, 1, 32>(p, stream);
+                case 33: return launch_attn_pipe<2, 1, 33>(p, stream);
+                case 39: return launch_attn_pipe<2, 1, 39>(p, stream);
+                case 63: return launch_attn_pipe<2, 1, 63>(p, stream);
+                case 128: return launch_attn_pipe<2, 1, 0, true>(p, stream);
+                case 129: return launch_attn_pipe<2, 1, 1, true>(p, stream);
+                case 134: return launch_attn_pipe<2, 1, 6, true>(p, stream);
+                case 144: return launch_attn_pipe<2, 1, 16, true>(p, stream);
+                case 167: return launch_attn_pipe<2, 1, 39, true>(p, stream);
+                default: return MI355X_EARG;
+            }
+        }
+#endif
+    }
     if (g_attn_glds) {
         if (p.nstream == 2) return launch_attn<T, NW, 2, true>(p, stream);
         return launch_attn<T, NW, 1, true>(p, stream);
@@ -785,6 +1237,19 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
             }
         }
     }
+    if constexpr (NW == 4 && sizeof(T) == 2) {
+        if (g_attn_pipe && p.nstream == 1 && g_attn_abl == 0 && g_attn_kvs != 2) {
+            const int64_t wg128 = (int64_t)((p.Lq + 127) / 128) * p.H * p.B;
+            const bool q16 = g_attn_kvs == 3 || (g_attn_kvs == 0 && wg128 <= 384 && p.kv[0].Lk >= 256);
+            if (g_attn_pipe == 2) return q16 ? launch_attn_pipe<1, 0>(p, stream) : launch_attn_pipe<2, 0>(p, stream);
+            if (g_attn_pipe == 3) {
+                const bool dma_ok = (int64_t)p.kv[0].Lk * p.kv[0].ldkb < 0x7fffffff && 64 * p.kv[0].ldvtb < 0x7fffffff;  // 32-bit offsets inside one (batch, head) slice
+                if (dma_ok) return q16 ? launch_attn_pipe<1, 1, 0, true>(p, stream) : launch_attn_pipe<2, 1, 0, true>(p, stream);
+                // (otherwise the register-staged loader below)
+            }
+            return q16 ? launch_attn_pipe<1, 1>(p, stream) : launch_attn_pipe<2, 1>(p, stream);
+        }
+    }
     if constexpr (NW == 4) {
         // a grid of 128-query workgroups that leaves most SIMDs with a single wave (a CFG pair's 1024-token self-attention: 320 workgroups):
         // 64-query key-split workgroups instead -- twice the waves, each with half the dependent chain per tile
@@ -793,10 +1258,30 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
         // round 6: such grids run 64-query workgroups of four 16-QUERY waves (twice the waves, each with half the softmax / MFMA chain per tile AND per-wave state small
         // enough for 5-7 resident workgroups): in the step 24.40 -> 24.31 ms against the key-split workgroups of rounds 3-5, which stay available (mode 2)
         // and beat the plain 128-query workgroups (24.48) -- profiles/r06_s_ab_attn_q16.log
-        if (p.nstream == 1 && (g_attn_kvs == 3 || (g_attn_kvs == 0 && short_grid))) return launch_attn<T, 4, 1, false, 1, 1, 1>(p, stream);
+        if (p.nstream == 1 && (g_attn_kvs == 3 || (g_attn_kvs == 0 && short_grid))) {
+            if constexpr (sizeof(T) == 2) {
+                switch (g_attn_opt) {
+                    case 5: return launch_attn<T, 4, 1, false, 1, 1, 5>(p, stream);
+                    case 9: return launch_attn<T, 4, 1, false, 1, 1, 9>(p, stream);
+                    case 13: return launch_attn<T, 4, 1, false, 1, 1, 13>(p, stream);
+                    default: break;
+                }
+            }
+            return launch_attn<T, 4, 1, false, 1, 1, 1>(p, stream);
+        }
         if (p.nstream == 1 && g_attn_kvs == 2) return (g_attn_opt & 1) ? launch_attn<T, 4, 1, false, 2, 1, 1, 0, 2>(p, stream) : launch_attn<T, 4, 1, false, 2, 1, 0, 0, 2>(p, stream);
     }
-    switch (g_attn_opt) {
+    if constexpr (NW == 4 && sizeof(T) == 2) {  // bf16 only: lazy running maximum (bit 2), row sums from the matrix pipe (bit 3)
+        if (p.nstream == 1) {
+            switch (g_attn_opt) {
+                case 5: return launch_attn<T, 4, 1, false, 2, 1, 5>(p, stream);
+                case 9: return launch_attn<T, 4, 1, false, 2, 1, 9>(p, stream);
+                case 13: return launch_attn<T, 4, 1, false, 2, 1, 13>(p, stream);
+                default: break;
+            }
+        }
+    }
+    switch (g_attn_opt & 3) {
         case 1: return launch_attn_opt<T, NW, 1>(p, stream);
         case 2: return launch_attn_opt<T, NW, 2>(p, stream);
         case 3: return launch_attn_opt<T, NW, 3>(p, stream);
@@ -836,13 +1321,14 @@ extern "C" int mi355x_attention_set_glds(int v) {
 
 extern "C" int mi355x_attention_set_pipeline(int tiles_in_flight, int xcd_aware) {  // probing / A-B only, not part of the stable contract
     // tiles_in_flight: bits 0-3 = 1 | 2, bits 4-7 = OPT bits of attn_kernel, bits 8-15 = ABL bits (timing probes, wrong results),
-    // bits 16-17 = key-split workgroups: 0 auto, 1 never, 2 always; bit 18 = 1: no short-K/V kernel
+    // bits 16-17 = key-split workgroups: 0 auto, 1 never, 2 always; bit 18 = 1: no short-K/V kernel; bits 19-20 = software-pipelined loop (g_attn_pipe)
     const int d = tiles_in_flight & 15;
     if (d == 1 || d == 2) g_attn_depth = d;
     g_attn_opt = (tiles_in_flight >> 4) & 15;
     g_attn_abl = (tiles_in_flight >> 8) & 255;
     g_attn_kvs = (tiles_in_flight >> 16) & 3;
     g_attn_short = ((tiles_in_flight >> 18) & 1) ? 0 : 1;
+    g_attn_pipe = (tiles_in_flight >> 19) & 3;
     if (xcd_aware >= 0) g_attn_xcd = xcd_aware ? 1 : 0;
     return MI355X_OK;
 }
@@ -867,6 +1353,7 @@ extern "C" int mi355x_attention(const mi355x_attn_args* a, void* stream) {
     p.ldob = a->ldo * es;
     p.obsb = a->o_batch_stride * es;
     p.c = a->scale * 1.44269504088896340736f;
+    p.thr = p.c > 0.f ? 8.0f / p.c : 0.f;
     for (int s = 0; s < a->nstream; ++s) {
         const mi355x_kv_stream& k = a->kv[s];
         if (!k.k || !k.vt || k.Lk <= 0) return MI355X_ESHAPE;

@@ -974,6 +974,18 @@ def all_cases():
         for nm, args, kw in (("self_1024", (2, 4, 1024, 1024), {}), ("spike", (1, 2, 256, 512), {"spike": True}), ("Lk20", (1, 2, 96, 20), {"seed": 76}),
                              ("Lk257_Lq130", (1, 2, 130, 257), {"seed": 74}), ("Lk300_Lq200", (2, 3, 200, 300), {"seed": 78}), ("Lq_edge_40", (1, 2, 40, 320), {"seed": 82})):
             cases.append((f"attn_{tag}_q16waves_{nm}", lambda dt=dt, args=args, kw=kw: attention_case(*args, dt, pipe=0x30011, **kw)))
+        # round 6: lazy running maximum / row sums from the matrix pipe (OPT bits 2 / 3 of attn_kernel: 0x51, 0x91, 0xd1; bf16 one-stream launches) and the
+        # software-pipelined loop (attn_pipe_kernel: bits 19-20 = 1 register-staged K/V, 2 the same with a free instruction order, 3 LDS-DMA = the default),
+        # each with 32-query waves (0x10000: the short-grid switch off) and 16-query waves (0x30000), 0x40000 = few-tile shapes stay off the short kernel:
+        # one tile, two tiles (the loop body never runs with a successor), odd / even tile counts, ragged last tiles, Lq edges, late score spikes
+        if dt == torch.bfloat16:
+            shapes = (("self_1024", (2, 4, 1024, 1024), {}), ("spike", (1, 2, 256, 512), {"spike": True}), ("Lk20", (1, 2, 96, 20), {"seed": 76}), ("Lk64", (1, 3, 160, 64), {"seed": 71}),
+                      ("Lk77", (2, 10, 256, 77), {"seed": 83}), ("Lk128", (1, 2, 200, 128), {}), ("Lk257_Lq130", (1, 2, 130, 257), {"seed": 74}), ("Lk300_Lq200", (2, 3, 200, 300), {"seed": 78}),
+                      ("3tiles", (2, 2, 192, 192), {"seed": 72}), ("Lq_edge_40", (1, 2, 40, 320), {"seed": 82}), ("spike_1000", (1, 2, 100, 1000), {"spike": True, "seed": 84}))
+            for nm, args, kw in shapes:
+                for code in (0x51, 0x91, 0xD1, 0x800D1, 0x1000D1, 0x1800D1):
+                    for q in (0x10000, 0x30000):
+                        cases.append((f"attn_{tag}_r6_{code | q | 0x40000:06x}_{nm}", lambda dt=dt, args=args, kw=kw, c=code | q | 0x40000: attention_case(*args, dt, pipe=c, **kw)))
         # launches of at most three K/V tiles take the all-tiles-up-front kernel by default (the cases above: cross_77, cross_77_ip4, 1tile, 3tiles,
         # Lq_edge_200); 0x40000 switches it off, so the same shapes also run through the general tile loop; and its remaining slot layouts
         cases += [
