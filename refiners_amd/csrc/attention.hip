@@ -571,6 +571,8 @@ MI_DEV void blds16(rsrc_t rs, char* lds_wave_base, uint32_t voff, uint32_t soff)
 // ABL (probing, wrong results): 1 = no exponentials, 2 = no Q K^T MFMAs, 4 = no P V MFMAs, 8 = no K/V loads and commits in the loop, 16 = no barrier in the loop, 32 = no maxima
 // DMA: K / V^T tiles go global -> LDS directly (buffer_load ... lds, issued at the START of the iteration into the buffers the previous iteration left:
 //      the one-tile lead of K means they are free a whole iteration before they are read -- no deeper ring, no staging registers, no ds_write)
+// Registers: 32-query waves 182 (2 waves per SIMD), 16-query waves 108 (4).  Measured and dropped (profiles/r06_zn_probe_attn_occ.log): budgets squeezed to 168 / 96 registers
+// (a few spilled dwords: level at best, 2x slower for the 16-query waves), V^T fragments requested together with the K fragments (level).
 template <int NJQ, int SCHED, int ABL = 0, bool DMA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_pipe_kernel(const AttnP p) {
     using T = bf16_t;
@@ -895,9 +897,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 // kernel walks them as a chain of load -> barrier -> compute -> barrier per tile and per stream (seven barriers and three dependent memory
 // round trips for a few hundred MFMAs); here every tile of every stream is requested up front, lands in its own LDS slot behind ONE barrier,
 // and the tiles are then consumed back to back.  Same arithmetic, same order of operations per stream as attn_kernel.
-template <typename T, int NSTREAM>
+// NJQ = 16-query groups per wave: 2 = 128-query workgroups; 1 = 64-query workgroups (twice the workgroups, half the chain per wave) for grids of few 128-query workgroups
+template <typename T, int NSTREAM, int NJQ = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 2 : 1))) void attn_short_kernel(const AttnP p) {
-    constexpr int D = 64, BKV = 64, NJQ = 2, NW = 4, BQW = 16 * NJQ, SLOTS = 3;
+    constexpr int D = 64, BKV = 64, NW = 4, BQW = 16 * NJQ, SLOTS = 3;
     constexpr int ES = sizeof(T);
     constexpr int ROWB = D * ES;
     constexpr int CPR = ROWB / 16;
@@ -1112,17 +1115,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     }
 }
 
-template <typename T, int NSTREAM>
+int g_attn_short_q16 = 0;  // short-K/V kernel with 64-query workgroups: 0 = where the grid of 128-query workgroups is short (<= 384), 1 = never, 2 = always
+
+template <typename T, int NSTREAM, int NJQ = 2>
 int launch_attn_short(const AttnP& p0, int xcd, hipStream_t stream) {
     constexpr int LDS = 3 * 2 * 64 * 64 * sizeof(T);
-    auto kfn = attn_short_kernel<T, NSTREAM>;
+    auto kfn = attn_short_kernel<T, NSTREAM, NJQ>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     AttnP p = p0;
-    p.qtiles = (p.Lq + 127) / 128;
+    constexpr int BQ = 64 * NJQ;
+    p.qtiles = (p.Lq + BQ - 1) / BQ;
     p.xcd = xcd;
     hipLaunchKernelGGL(kfn, dim3(p.qtiles * p.H * p.B), dim3(256), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? MI355X_OK : MI355X_ELAUNCH;
@@ -1296,7 +1302,12 @@ int launch_attn_t(const AttnP& p, hipStream_t stream) {
     if (g_attn_short && !g_attn_glds && g_attn_nw == 0 && g_attn_abl == 0 && g_attn_kvs != 2) {
         int tiles = 0;
         for (int s = 0; s < p.nstream; ++s) tiles += (p.kv[s].Lk + 63) / 64;
-        if (tiles <= 3) return p.nstream == 2 ? launch_attn_short<T, 2>(p, g_attn_xcd, stream) : launch_attn_short<T, 1>(p, g_attn_xcd, stream);
+        if (tiles <= 3) {
+            const int64_t wg128 = (int64_t)((p.Lq + 127) / 128) * p.H * p.B;
+            if (g_attn_short_q16 == 2 || (g_attn_short_q16 == 0 && wg128 <= 384))
+                return p.nstream == 2 ? launch_attn_short<T, 2, 1>(p, g_attn_xcd, stream) : launch_attn_short<T, 1, 1>(p, g_attn_xcd, stream);
+            return p.nstream == 2 ? launch_attn_short<T, 2>(p, g_attn_xcd, stream) : launch_attn_short<T, 1>(p, g_attn_xcd, stream);
+        }
     }
     int nw = g_attn_nw;  // 2 / 4: waves of 32 queries; 14 / 18: 4 / 8 waves of 16 queries
     if (nw == 0) nw = 4;  // 2-wave workgroups never won on MI355X (profiles/r01_c_probe_attention.log)
@@ -1329,6 +1340,7 @@ extern "C" int mi355x_attention_set_pipeline(int tiles_in_flight, int xcd_aware)
     g_attn_kvs = (tiles_in_flight >> 16) & 3;
     g_attn_short = ((tiles_in_flight >> 18) & 1) ? 0 : 1;
     g_attn_pipe = (tiles_in_flight >> 19) & 3;
+    g_attn_short_q16 = (tiles_in_flight >> 23) & 3;
     if (xcd_aware >= 0) g_attn_xcd = xcd_aware ? 1 : 0;
     return MI355X_OK;
 }
