@@ -573,7 +573,11 @@ MI_DEV void blds16(rsrc_t rs, char* lds_wave_base, uint32_t voff, uint32_t soff)
 //      the one-tile lead of K means they are free a whole iteration before they are read -- no deeper ring, no staging registers, no ds_write)
 // Registers: 32-query waves 182 (2 waves per SIMD), 16-query waves 108 (4).  Measured and dropped (profiles/r06_zn_probe_attn_occ.log): budgets squeezed to 168 / 96 registers
 // (a few spilled dwords: level at best, 2x slower for the 16-query waves), V^T fragments requested together with the K fragments (level).
-template <int NJQ, int SCHED, int ABL = 0, bool DMA = false>
+// FOLD: the exponent's subtraction rides in the Q K^T product -- Q is scaled by c = scale * log2(e) once (rounded to bf16 again: a score error of ~1e-3, below the
+//      rounding of P), the accumulators of tile i + 1 START at -(reference maximum, scaled) instead of 0, and P = exp2(accumulator): one v_exp per score, no v_fma
+//      (32 of ~116 vector instructions per tile of a 32-query wave).  The reference only ever moves between iterations; a move subtracts its step from the scores
+//      already computed against the old reference (the rare path).
+template <int NJQ, int SCHED, int ABL = 0, bool DMA = false, bool FOLD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_pipe_kernel(const AttnP p) {
     using T = bf16_t;
     constexpr int NW = 4, D = 64, BKV = 64, BQW = 16 * NJQ, ES = 2, ROWB = D * ES, CPR = ROWB / 16, NTHR = NW * 64, TILEB = 64 * ROWB;
@@ -596,7 +600,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         qr = qr < p.Lq ? qr : p.Lq - 1;
         const char* qp = p.q + (int64_t)b * p.qbsb + (int64_t)qr * p.ldqb + (int64_t)h * ROWB;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) qf[jq][s] = *reinterpret_cast<const frag_t*>(qp + (4 * s + g) * 16);
+        for (int s = 0; s < NS; ++s) {
+            qf[jq][s] = *reinterpret_cast<const frag_t*>(qp + (4 * s + g) * 16);
+            if constexpr (FOLD) {
+                bf16x8 qv = __builtin_bit_cast(bf16x8, qf[jq][s]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qv[e] = (bf16_t)((float)qv[e] * p.c);
+                qf[jq][s] = __builtin_bit_cast(frag_t, qv);
+            }
+        }
     }
 
     const KvP& kv = p.kv[0];
@@ -662,9 +674,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float mrun[NJQ];
+    float mrun[NJQ];  // the reference maximum: raw score units, -inf before the first tile; FOLD: scaled units (c * score), 0 before the first tile
 #pragma unroll
-    for (int jq = 0; jq < NJQ; ++jq) mrun[jq] = -INFINITY;
+    for (int jq = 0; jq < NJQ; ++jq) mrun[jq] = FOLD ? 0.f : -INFINITY;
     const frag_t ones = frag_t{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
 
     auto qk = [&](const char* ks, f32x4(&sn)[4][NJQ]) {
@@ -676,7 +688,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int jq = 0; jq < NJQ; ++jq) sn[t][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int jq = 0; jq < NJQ; ++jq) {
+                const float c0 = FOLD ? -mrun[jq] : 0.f;
+                sn[t][jq] = f32x4{c0, c0, c0, c0};
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -712,20 +727,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             mloc[jq] = mx;
         }
     };
-    auto move_reference = [&](const float(&mloc)[NJQ]) {  // between iterations: every P V issued so far is in o / lacc
-        bool need = false;
+    auto move_reference = [&](const float(&mloc)[NJQ], f32x4(&sn)[4][NJQ], bool first) {  // between iterations: every P V issued so far is in o / lacc
+        bool need = first;
 #pragma unroll
-        for (int jq = 0; jq < NJQ; ++jq) need |= mloc[jq] > mrun[jq] + p.thr;
+        for (int jq = 0; jq < NJQ; ++jq) need |= FOLD ? mloc[jq] > 8.0f : mloc[jq] > mrun[jq] + p.thr;
         if (__builtin_amdgcn_ballot_w64(need) != 0) {
 #pragma unroll
             for (int jq = 0; jq < NJQ; ++jq) {
                 const float mx = group_max<true>(mloc[jq]);
-                const float mnew = fmaxf(mrun[jq], mx);
-                const float alpha = fast_exp2((mrun[jq] - mnew) * p.c);
-                mrun[jq] = mnew;
-                lacc[jq] *= alpha;
+                if constexpr (FOLD) {
+                    const float d = first ? mx : fmaxf(mx, 0.f);  // the scores of `sn` were taken against the old reference: d is the reference's step
+                    const float alpha = fast_exp2(-d);
+                    mrun[jq] += d;
+                    lacc[jq] *= alpha;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
+                    for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) sn[t][jq] -= d;
+                } else {
+                    const float mnew = fmaxf(mrun[jq], mx);
+                    const float alpha = fast_exp2((mrun[jq] - mnew) * p.c);
+                    mrun[jq] = mnew;
+                    lacc[jq] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
+                }
             }
         }
     };
@@ -739,6 +765,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 if constexpr (ABL & 1) {
                     pk[r] = (bf16_t)sc[2 * s2][jq][r];
                     pk[4 + r] = (bf16_t)sc[2 * s2 + 1][jq][r];
+                } else if constexpr (FOLD) {
+                    pk[r] = (bf16_t)fast_exp2(sc[2 * s2][jq][r]);
+                    pk[4 + r] = (bf16_t)fast_exp2(sc[2 * s2 + 1][jq][r]);
                 } else {
                     pk[r] = (bf16_t)fast_exp2(sc[2 * s2][jq][r] * p.c - mc);
                     pk[4 + r] = (bf16_t)fast_exp2(sc[2 * s2 + 1][jq][r] * p.c - mc);
@@ -804,7 +833,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     {
         float mloc[NJQ];
         local_max(sa, mloc);
-        move_reference(mloc);
+        move_reference(mloc, sa, true);
     }
 
     // one iteration: `sc` = scores of tile i (in), `sn` = scores of tile i + 1 (out, NEXT only)
@@ -849,7 +878,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NEXT) {
-            move_reference(mloc);
+            move_reference(mloc, sn, false);
             if constexpr (!(ABL & 8)) {
                 if constexpr (DMA) {
                     wait_vm0();
@@ -1161,10 +1190,12 @@ int launch_attn(const AttnP& p0, hipStream_t stream) {
 
 int g_attn_pipe = 3;  // software-pipelined loop (attn_pipe_kernel) for bf16 one-stream launches: 0 = off, 1 = register-staged K/V, 2 = the same without the pinned instruction order (probing), 3 = K/V by LDS-DMA (default: 1024 tokens 26.8 -> 19.2 us, 4096 tokens 133 -> 109 us, r06_zl_probe_attn_dma.log)
 
-template <int NJQ, int SCHED, int ABL = 0, bool DMA = false>
+int g_attn_pipe_fold = 0;  // attn_pipe_kernel's FOLD (LDS-DMA instances)
+
+template <int NJQ, int SCHED, int ABL = 0, bool DMA = false, bool FOLD = false>
 int launch_attn_pipe(const AttnP& p0, hipStream_t stream) {
     constexpr int LDS = 4 * 64 * 64 * 2;
-    auto kfn = attn_pipe_kernel<NJQ, SCHED, ABL, DMA>;
+    auto kfn = attn_pipe_kernel<NJQ, SCHED, ABL, DMA, FOLD>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1250,6 +1281,7 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
             if (g_attn_pipe == 2) return q16 ? launch_attn_pipe<1, 0>(p, stream) : launch_attn_pipe<2, 0>(p, stream);
             if (g_attn_pipe == 3) {
                 const bool dma_ok = (int64_t)p.kv[0].Lk * p.kv[0].ldkb < 0x7fffffff && 64 * p.kv[0].ldvtb < 0x7fffffff;  // 32-bit offsets inside one (batch, head) slice
+                if (dma_ok && g_attn_pipe_fold) return q16 ? launch_attn_pipe<1, 1, 0, true, true>(p, stream) : launch_attn_pipe<2, 1, 0, true, true>(p, stream);
                 if (dma_ok) return q16 ? launch_attn_pipe<1, 1, 0, true>(p, stream) : launch_attn_pipe<2, 1, 0, true>(p, stream);
                 // (otherwise the register-staged loader below)
             }
@@ -1340,6 +1372,7 @@ extern "C" int mi355x_attention_set_pipeline(int tiles_in_flight, int xcd_aware)
     g_attn_kvs = (tiles_in_flight >> 16) & 3;
     g_attn_short = ((tiles_in_flight >> 18) & 1) ? 0 : 1;
     g_attn_pipe = (tiles_in_flight >> 19) & 3;
+    g_attn_pipe_fold = (tiles_in_flight >> 21) & 1;
     g_attn_short_q16 = (tiles_in_flight >> 23) & 3;
     if (xcd_aware >= 0) g_attn_xcd = xcd_aware ? 1 : 0;
     return MI355X_OK;

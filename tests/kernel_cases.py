@@ -983,7 +983,7 @@ def all_cases():
                       ("Lk77", (2, 10, 256, 77), {"seed": 83}), ("Lk128", (1, 2, 200, 128), {}), ("Lk257_Lq130", (1, 2, 130, 257), {"seed": 74}), ("Lk300_Lq200", (2, 3, 200, 300), {"seed": 78}),
                       ("3tiles", (2, 2, 192, 192), {"seed": 72}), ("Lq_edge_40", (1, 2, 40, 320), {"seed": 82}), ("spike_1000", (1, 2, 100, 1000), {"spike": True, "seed": 84}))
             for nm, args, kw in shapes:
-                for code in (0x51, 0x91, 0xD1, 0x800D1, 0x1000D1, 0x1800D1):
+                for code in (0x51, 0x91, 0xD1, 0x800D1, 0x1000D1, 0x1800D1, 0x3800D1):  # (0x200000: the exponent's subtraction folded into Q K^T)
                     for q in (0x10000, 0x30000):
                         cases.append((f"attn_{tag}_r6_{code | q | 0x40000:06x}_{nm}", lambda dt=dt, args=args, kw=kw, c=code | q | 0x40000: attention_case(*args, dt, pipe=c, **kw)))
         # launches of at most three K/V tiles take the all-tiles-up-front kernel by default (the cases above: cross_77, cross_77_ip4, 1tile, 3tiles,

@@ -10,7 +10,7 @@ def family(kernel: str):
     m = re.search(r"gemm_kernelI\w+?Li\d+ELi\d+ELi\d+ELi\d+ELb([01])E", kernel)
     if m:
         return "mi355x_gemm(conv)" if m.group(1) == "1" else "mi355x_gemm"
-    if "attn_kernel" in kernel or "attn_general_kernel" in kernel:
+    if re.search(r"attn_(pipe_|short_|general_)?kernel", kernel):
         return "mi355x_attention"
     if "layernorm_kernel" in kernel:
         return "mi355x_layernorm"

@@ -31,7 +31,8 @@ def main():
     lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
     dt = torch.bfloat16
     variants = [("opt 1 (round 5)", 1 << 4), ("opt 5 lazy", 5 << 4), ("opt 9 ones", 9 << 4), ("opt 13 lazy+ones", 13 << 4), ("pipelined", (13 << 4) | (1 << 19)),
-                ("pipelined, order free", (13 << 4) | (2 << 19)), ("pipelined, LDS-DMA", (13 << 4) | (3 << 19)), ("  16-query waves", (13 << 4) | (3 << 19) | (3 << 16)), ("  32-query waves", (13 << 4) | (3 << 19) | (1 << 16))]
+                ("pipelined, order free", (13 << 4) | (2 << 19)), ("pipelined, LDS-DMA", (13 << 4) | (3 << 19)), ("  16-query waves", (13 << 4) | (3 << 19) | (3 << 16)), ("  32-query waves", (13 << 4) | (3 << 19) | (1 << 16)),
+                ("pipelined, LDS-DMA, folded", (13 << 4) | (3 << 19) | (1 << 21)), ("  16-query waves", (13 << 4) | (3 << 19) | (1 << 21) | (3 << 16)), ("  32-query waves", (13 << 4) | (3 << 19) | (1 << 21) | (1 << 16))]
     if "--short" in sys.argv:
         variants = [v for v in variants if "opt" not in v[0] and "order free" not in v[0]]
     shapes = ((2, 20, 1024, 1024), (2, 10, 4096, 4096), (8, 20, 1024, 1024), (8, 10, 4096, 4096), (2, 20, 1000, 1000))

@@ -45,7 +45,7 @@ def family(kernel: str) -> str | None:
         return "mi355x_gemm(conv)" if m.group(1) == "1" else "mi355x_gemm"
     if "splitk_reduce_kernel" in kernel:
         return "mi355x_gemm(conv)"
-    if "attn_kernel" in kernel or "attn_general_kernel" in kernel:
+    if re.search(r"attn_(pipe_|short_|general_)?kernel", kernel):
         return "mi355x_attention"
     if "layernorm_kernel" in kernel:
         return "mi355x_layernorm"
