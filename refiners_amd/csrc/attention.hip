@@ -1144,12 +1144,217 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     }
 }
 
-int g_attn_short_q16 = 0;  // short-K/V kernel with 64-query workgroups: 0 = where the grid of 128-query workgroups is short (<= 384), 1 = never, 2 = always
+// Round 6: the bf16 form of the short-K/V kernel.  Same arithmetic as attn_short_kernel (results agree to the last bf16 digit or one next to it: the compiler pairs
+// the row sum's additions differently when a half tile has 8 scores per lane instead of 16), but
+//   * every K / V^T tile goes global -> LDS by LDS-DMA (buffer_load ... lds; no staging registers, no ds_write): the kernel was moving 48 KB per workgroup through
+//     registers for 10 KB of live keys;
+//   * lanes whose keys lie beyond Lk carry the out-of-range offset, for which the hardware writes ZEROS (K rows, whole 8-key chunks of V^T): nothing beyond Lk is
+//     read from memory, and nothing depends on what the V^T padding holds except inside the last partly valid chunk;
+//   * a tile with at most 32 valid keys (the text stream's second tile: 13 of 64; the image-prompt stream: 4 of 64) is a HALF tile: K rows 32 .. 63 are not
+//     requested, Q K^T runs on two 16-key blocks, the softmax on 8 scores per lane and P V on one 32-key step.
+template <int NSTREAM, int NJQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_short_dma_kernel(const AttnP p) {
+    using T = bf16_t;
+    constexpr int D = 64, BKV = 64, NW = 4, BQW = 16 * NJQ, SLOTS = 3, ES = 2, ROWB = D * ES, CPR = ROWB / 16, NTHR = NW * 64, TILEB = 64 * ROWB, STAGE = 2 * TILEB;
+    constexpr int LI = 64 * CPR / NTHR, NS = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
-template <typename T, int NSTREAM, int NJQ = 2>
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    const int g = lane >> 4, c16 = lane & 15;
+    int bid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int qt = bid % p.qtiles;
+    bid /= p.qtiles;
+    const int h = bid % p.H;
+    const int b = bid / p.H;
+    const int q0 = qt * (BQW * NW) + wid * BQW;
+
+    const int nt0 = (p.kv[0].Lk + BKV - 1) / BKV;
+    const int nt1 = NSTREAM > 1 ? (p.kv[1].Lk + BKV - 1) / BKV : 0;
+    const int ntot = nt0 + nt1;  // <= SLOTS (checked by the host)
+
+    // ---- every tile of every stream: LDS-DMA into its own slot ----
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        if (sl < ntot) {
+            const int sidx = (NSTREAM > 1 && sl >= nt0) ? 1 : 0;
+            const KvP& kv = p.kv[sidx];
+            const int kv0 = (sidx ? sl - nt0 : sl) * BKV;
+            const bool half = kv.Lk - kv0 <= 32;
+            const rsrc_t krs = make_rsrc(kv.k + (int64_t)b * kv.kbsb + (int64_t)h * ROWB + (int64_t)kv0 * kv.ldkb, (int64_t)63 * kv.ldkb + ROWB);
+            const rsrc_t vrs = make_rsrc(kv.vt + (int64_t)h * D * kv.ldvtb + (int64_t)b * kv.vtbsb + (int64_t)kv0 * ES, (int64_t)(D - 1) * kv.ldvtb + BKV * ES);
+            char* ks = smem + sl * STAGE;
+#pragma unroll
+            for (int it = 0; it < LI; ++it) {
+                const int q = it * NTHR + tid, row = q / CPR, pch = q % CPR;
+                const int cl = pch ^ swz<ROWB>(row);  // the logical chunk this lane's physical slot holds
+                const int key = k_row_key(row);       // LDS rows 0 .. 31 hold keys 0 .. 31 of the tile
+                if (!(half && it * NTHR >= 32 * CPR)) {  // wave-uniform: a half tile has no second K iteration
+                    const uint32_t ko = kv0 + key < kv.Lk ? (uint32_t)(key * (int)kv.ldkb + cl * 16) : 0x80000000u;
+                    blds16(krs, ks + (it * NTHR + wid * 64) * 16, ko, 0);
+                }
+                const int j = row >> 4, a = (row >> 2) & 3, bb = row & 3;
+                const int vrow = 16 * a + 4 * j + bb;
+                const uint32_t vo = kv0 + cl * 8 < kv.Lk ? (uint32_t)(vrow * (int)kv.ldvtb + cl * 16) : 0x80000000u;
+                blds16(vrs, ks + TILEB + (it * NTHR + wid * 64) * 16, vo, 0);
+            }
+        }
+    }
+
+    frag_t qf[NJQ][NS];
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) {
+        int qr = q0 + 16 * jq + c16;
+        qr = qr < p.Lq ? qr : p.Lq - 1;
+        const char* qp = p.q + (int64_t)b * p.qbsb + (int64_t)qr * p.ldqb + (int64_t)h * ROWB;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[jq][s] = *reinterpret_cast<const frag_t*>(qp + (4 * s + g) * 16);
+    }
+    wait_vm0();
+    __syncthreads();
+
+    f32x4 res[4][NJQ], o[4][NJQ];
+    float mrun[NJQ], lsum[NJQ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) res[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f}, o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) mrun[jq] = -INFINITY, lsum[jq] = 0.f;
+
+    auto finish = [&](float out_scale) {
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) {
+            const float l = group_sum<true>(lsum[jq]);
+            const float inv = out_scale / l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                res[i][jq] += o[i][jq] * inv;
+                o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            mrun[jq] = -INFINITY, lsum[jq] = 0.f;
+        }
+    };
+
+    auto tile = [&](const char* ks, int kv0, int Lk, auto halfc) {
+        constexpr int TT = decltype(halfc)::value ? 2 : 4;  // 16-key blocks of the tile that hold valid keys
+        const char* vs = ks + TILEB;
+        f32x4 st[TT][NJQ];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+#pragma unroll
+            for (int jq = 0; jq < NJQ; ++jq) st[t][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const frag_t kf = lds_read_frag(ks, tile_off<ROWB>(16 * t + c16, 4 * s + g));
+#pragma unroll
+                for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(st[t][jq], kf, qf[jq][s]);
+            }
+        }
+        if (kv0 + BKV > Lk) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kv0 + k_row_key(16 * t + 4 * g + r) >= Lk) {
+#pragma unroll
+                        for (int jq = 0; jq < NJQ; ++jq) st[t][jq][r] = -INFINITY;
+                    }
+                }
+        }
+#pragma unroll
+        for (int jq = 0; jq < NJQ; ++jq) {
+            float mx = st[0][jq][0];
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][jq][r]);
+            mx = group_max<true>(mx);
+            const float mnew = fmaxf(mrun[jq], mx);
+            const float alpha = fast_exp2((mrun[jq] - mnew) * p.c);
+            const float mc = mnew * p.c;
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fast_exp2(st[t][jq][r] * p.c - mc);
+                    st[t][jq][r] = e;
+                    ps += e;
+                }
+            lsum[jq] = lsum[jq] * alpha + ps;
+            mrun[jq] = mnew;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i][jq] *= alpha;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < TT / 2; ++s2) {
+            frag_t pb[NJQ];
+#pragma unroll
+            for (int jq = 0; jq < NJQ; ++jq) {
+                bf16x8 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pk[r] = (bf16_t)st[2 * s2][jq][r];
+                    pk[4 + r] = (bf16_t)st[2 * s2 + 1][jq][r];
+                }
+                pb[jq] = __builtin_bit_cast(frag_t, pk);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const frag_t vf = lds_read_frag(vs, tile_off<ROWB>(16 * i + c16, 4 * s2 + g));
+#pragma unroll
+                for (int jq = 0; jq < NJQ; ++jq) mma_step<T>(o[i][jq], vf, pb[jq]);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        if (sl < ntot) {
+            const int sidx = (NSTREAM > 1 && sl >= nt0) ? 1 : 0;
+            if (NSTREAM > 1 && sl == nt0) finish(p.kv[0].out_scale);  // first tile of the second stream: close the first
+            const int Lk = p.kv[sidx].Lk;
+            const int kv0 = (sidx ? sl - nt0 : sl) * BKV;
+            if (Lk - kv0 <= 32) tile(smem + sl * STAGE, kv0, Lk, std::true_type{});
+            else tile(smem + sl * STAGE, kv0, Lk, std::false_type{});
+        }
+    }
+    finish(p.kv[NSTREAM - 1].out_scale);
+
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) {
+        const int qr = q0 + 16 * jq + c16;
+        if (qr >= p.Lq) continue;
+        T* op = reinterpret_cast<T*>(p.out + (int64_t)b * p.obsb + (int64_t)qr * p.ldob + (int64_t)h * ROWB) + 16 * g;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            Vec16<T> ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov.set(e, res[(c * 8 + e) >> 2][jq][e & 3]);
+            store16<T>(op + c * 8, ov);
+        }
+    }
+}
+
+int g_attn_short_q16 = 0;  // short-K/V kernel with 64-query workgroups: 0 = where the grid of 128-query workgroups is short (<= 640), 1 = never, 2 = always
+
+int g_attn_short_dma = 1;  // bf16 launches of the short-K/V kernel take attn_short_dma_kernel (0: the register-staged attn_short_kernel)
+
+template <typename T, int NSTREAM, int NJQ, bool DMA>
+auto short_kernel_of() {
+    if constexpr (DMA) return attn_short_dma_kernel<NSTREAM, NJQ>;
+    else return attn_short_kernel<T, NSTREAM, NJQ>;
+}
+
+template <typename T, int NSTREAM, int NJQ = 2, bool DMA = false>
 int launch_attn_short(const AttnP& p0, int xcd, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2 && !DMA) {
+        bool ok = g_attn_short_dma != 0;
+        for (int s = 0; s < p0.nstream; ++s) ok = ok && 64 * p0.kv[s].ldkb < 0x7fffffff && 64 * p0.kv[s].ldvtb < 0x7fffffff;  // 32-bit offsets inside a tile
+        if (ok) return launch_attn_short<T, NSTREAM, NJQ, true>(p0, xcd, stream);
+    }
     constexpr int LDS = 3 * 2 * 64 * 64 * sizeof(T);
-    auto kfn = attn_short_kernel<T, NSTREAM, NJQ>;
+    auto kfn = short_kernel_of<T, NSTREAM, NJQ, DMA>();
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1277,7 +1482,7 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
     if constexpr (NW == 4 && sizeof(T) == 2) {
         if (g_attn_pipe && p.nstream == 1 && g_attn_abl == 0 && g_attn_kvs != 2) {
             const int64_t wg128 = (int64_t)((p.Lq + 127) / 128) * p.H * p.B;
-            const bool q16 = g_attn_kvs == 3 || (g_attn_kvs == 0 && wg128 <= 384 && p.kv[0].Lk >= 256);
+            const bool q16 = g_attn_kvs == 3 || (g_attn_kvs == 0 && wg128 <= 640 && p.kv[0].Lk >= 256);  // (<= 384 for attn_kernel; this loop's 16-query waves win by 2 % at 640 as well)
             if (g_attn_pipe == 2) return q16 ? launch_attn_pipe<1, 0>(p, stream) : launch_attn_pipe<2, 0>(p, stream);
             if (g_attn_pipe == 3) {
                 const bool dma_ok = (int64_t)p.kv[0].Lk * p.kv[0].ldkb < 0x7fffffff && 64 * p.kv[0].ldvtb < 0x7fffffff;  // 32-bit offsets inside one (batch, head) slice
@@ -1336,7 +1541,7 @@ int launch_attn_t(const AttnP& p, hipStream_t stream) {
         for (int s = 0; s < p.nstream; ++s) tiles += (p.kv[s].Lk + 63) / 64;
         if (tiles <= 3) {
             const int64_t wg128 = (int64_t)((p.Lq + 127) / 128) * p.H * p.B;
-            if (g_attn_short_q16 == 2 || (g_attn_short_q16 == 0 && wg128 <= 384))
+            if (g_attn_short_q16 == 2 || (g_attn_short_q16 == 0 && wg128 <= 640))  // (r06_zt_probe_attn_short_dma.log: 2 x 10 x 4096 queries = 640: 12.8 -> 11.6 us; 1280: 21.4 -> 22.3)
                 return p.nstream == 2 ? launch_attn_short<T, 2, 1>(p, g_attn_xcd, stream) : launch_attn_short<T, 1, 1>(p, g_attn_xcd, stream);
             return p.nstream == 2 ? launch_attn_short<T, 2>(p, g_attn_xcd, stream) : launch_attn_short<T, 1>(p, g_attn_xcd, stream);
         }
@@ -1374,6 +1579,7 @@ extern "C" int mi355x_attention_set_pipeline(int tiles_in_flight, int xcd_aware)
     g_attn_pipe = (tiles_in_flight >> 19) & 3;
     g_attn_pipe_fold = (tiles_in_flight >> 21) & 1;
     g_attn_short_q16 = (tiles_in_flight >> 23) & 3;
+    g_attn_short_dma = ((tiles_in_flight >> 25) & 1) ? 0 : 1;
     if (xcd_aware >= 0) g_attn_xcd = xcd_aware ? 1 : 0;
     return MI355X_OK;
 }

@@ -17,8 +17,9 @@ def main():
     lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
     dt = torch.bfloat16
     base = 1 | (13 << 4) | (3 << 19)
-    variants = [("128-query workgroups", base | (1 << 23)), ("64-query workgroups", base | (2 << 23)), ("default", base)]
-    for (B, H, Lq, Lk, Lk2) in ((2, 20, 1024, 77, 4), (2, 10, 4096, 77, 4), (2, 20, 1024, 77, 0), (8, 20, 1024, 77, 4), (8, 10, 4096, 77, 4)):
+    variants = [("register-staged, 128-query", base | (1 << 23) | (1 << 25)), ("register-staged, 64-query", base | (2 << 23) | (1 << 25)), ("LDS-DMA + half tiles, 128-query", base | (1 << 23)),
+                ("LDS-DMA + half tiles, 64-query", base | (2 << 23)), ("default", base)]
+    for (B, H, Lq, Lk, Lk2) in ((2, 20, 1024, 77, 4), (2, 10, 4096, 77, 4), (2, 20, 1024, 77, 0), (8, 20, 1024, 77, 4), (8, 10, 4096, 77, 4), (2, 20, 1000, 128, 33), (2, 4, 200, 20, 100)):
         Cc = H * 64
         sets = []
         for _ in range(6):
@@ -38,7 +39,7 @@ def main():
             us = time_us(fns)
             o = sets[0][1].float().clone()
             ref = o if ref is None else ref
-            line += f"\n    {name:24s} {us:7.1f} us   max |d| vs first {(o - ref).abs().max().item():.1e}"
+            line += f"\n    {name:34s} {us:7.1f} us   max |d| vs first {(o - ref).abs().max().item():.1e}"
         native.attention_pipeline_from_env()
         print(line, flush=True)
 
