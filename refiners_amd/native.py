@@ -345,12 +345,12 @@ def load(path: Optional[Path] = None) -> C.CDLL:
 
 
 def attention_pipeline_from_env() -> None:
-    """A/B: REFINERS_AMD_ATTN_PIPE="<K/V tiles in flight 1|2>,<XCD-aware block order 0|1>,<OPT bits of attn_kernel>,<short grids: 0 auto = 16-query waves where the grid is short|1 never|2 key-split workgroups always|3 16-query waves always>,<software-pipelined loop 0 off|1 register-staged|2 = 1 without the pinned order|3 LDS-DMA>"
-    (default 1,1,13,0,3); read at launch / capture time."""
+    """A/B: REFINERS_AMD_ATTN_PIPE="<K/V tiles in flight 1|2>,<XCD-aware block order 0|1>,<OPT bits of attn_kernel>,<short grids: 0 auto = 16-query waves where the grid is short|1 never|2 key-split workgroups always|3 16-query waves always>,<software-pipelined loop 0 off|1 register-staged|2 = 1 without the pinned order|3 LDS-DMA>,<short-K/V kernel: 0 default|1 128-query workgroups|2 64-query workgroups, +4 = the register-staged form>"
+    (default 1,1,13,0,3,0; "/" separates as well); read at launch / capture time."""
     import os
 
-    d, x, o, k, sp = (os.environ.get("REFINERS_AMD_ATTN_PIPE", "").replace("/", ",").split(",") + ["", "", "", "", ""])[:5]
-    _lib.mi355x_attention_set_pipeline(int(d or 1) | (int(o or 13) << 4) | (int(k or 0) << 16) | (int(sp or 3) << 19), int(x or 1))
+    d, x, o, k, sp, sh = (os.environ.get("REFINERS_AMD_ATTN_PIPE", "").replace("/", ",").split(",") + ["", "", "", "", "", ""])[:6]
+    _lib.mi355x_attention_set_pipeline(int(d or 1) | (int(o or 13) << 4) | (int(k or 0) << 16) | (int(sp or 3) << 19) | (int(sh or 0) << 23), int(x or 1))
 
 
 def available() -> bool:

@@ -986,6 +986,14 @@ def all_cases():
                 for code in (0x51, 0x91, 0xD1, 0x800D1, 0x1000D1, 0x1800D1, 0x3800D1):  # (0x200000: the exponent's subtraction folded into Q K^T)
                     for q in (0x10000, 0x30000):
                         cases.append((f"attn_{tag}_r6_{code | q | 0x40000:06x}_{nm}", lambda dt=dt, args=args, kw=kw, c=code | q | 0x40000: attention_case(*args, dt, pipe=c, **kw)))
+        # round 6: the short-K/V kernel's LDS-DMA form (bf16): half tiles (<= 32 valid keys) against full ones on both sides of the boundary, zero-filled lanes beyond Lk,
+        # 128- / 64-query workgroups (0x800000 / 0x1000000), and the register-staged form it replaced (0x2000000)
+        if dt == torch.bfloat16:
+            for nm, args, kw in (("Lk32", (1, 2, 100, 32), {"seed": 85}), ("Lk33", (1, 2, 100, 33), {"seed": 86}), ("Lk96_ip32", (2, 3, 130, 96), {"ip_tokens": 32, "seed": 87}),
+                                 ("Lk97_ip33", (2, 3, 130, 97), {"ip_tokens": 33, "seed": 88}), ("Lk77_ip4", (2, 10, 512, 77), {"ip_tokens": 4}), ("Lk128_ip64", (1, 2, 70, 128), {"ip_tokens": 64, "seed": 89}),
+                                 ("Lk1_ip1", (1, 2, 64, 1), {"ip_tokens": 1, "seed": 90}), ("Lk190", (1, 2, 200, 190), {"seed": 91}), ("Lk17_ip1_spike", (2, 3, 300, 17), {"ip_tokens": 1, "spike": True, "seed": 80})):
+                for code in (0x8000D1, 0x10000D1, 0x28000D1, 0x30000D1):
+                    cases.append((f"attn_{tag}_short_r6_{code:07x}_{nm}", lambda dt=dt, args=args, kw=kw, c=code: attention_case(*args, dt, pipe=c, **kw)))
         # launches of at most three K/V tiles take the all-tiles-up-front kernel by default (the cases above: cross_77, cross_77_ip4, 1tile, 3tiles,
         # Lq_edge_200); 0x40000 switches it off, so the same shapes also run through the general tile loop; and its remaining slot layouts
         cases += [
