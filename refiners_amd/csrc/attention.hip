@@ -1452,6 +1452,10 @@ int launch_attn_nw(const AttnP& p, hipStream_t stream) {
                 case 134: return launch_attn_pipe<2, 1, 6, true>(p, stream);
                 case 144: return launch_attn_pipe<2, 1, 16, true>(p, stream);
                 case 167: return launch_attn_pipe<2, 1, 39, true>(p, stream);
+                case 136: return launch_attn_pipe<2, 1, 8, true>(p, stream);
+                case 152: return launch_attn_pipe<2, 1, 24, true>(p, stream);
+                case 175: return launch_attn_pipe<2, 1, 47, true>(p, stream);
+                case 191: return launch_attn_pipe<2, 1, 63, true>(p, stream);
                 default: return MI355X_EARG;
             }
         }

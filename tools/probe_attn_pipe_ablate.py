@@ -24,7 +24,11 @@ def main():
                 ("- all MFMAs", (13 << 4) | (1 << 19) | (6 << 8)), ("- K/V loads + commits", (13 << 4) | (1 << 19) | (8 << 8)), ("- barrier", (13 << 4) | (1 << 19) | (16 << 8)),
                 ("- loads - barrier", (13 << 4) | (1 << 19) | (24 << 8)), ("- all vector work - all MFMAs", (13 << 4) | (1 << 19) | (39 << 8)), ("LDS reads + loop only", (13 << 4) | (1 << 19) | (63 << 8)),
                 ("LDS-DMA", (13 << 4) | (1 << 19) | (128 << 8)), ("LDS-DMA - exponentials", (13 << 4) | (1 << 19) | (129 << 8)), ("LDS-DMA - all MFMAs", (13 << 4) | (1 << 19) | (134 << 8)),
-                ("LDS-DMA - barrier", (13 << 4) | (1 << 19) | (144 << 8)), ("LDS-DMA - all vector work - all MFMAs", (13 << 4) | (1 << 19) | (167 << 8))]
+                ("LDS-DMA - barrier", (13 << 4) | (1 << 19) | (144 << 8)), ("LDS-DMA - all vector work - all MFMAs", (13 << 4) | (1 << 19) | (167 << 8)),
+                ("LDS-DMA - loads", (13 << 4) | (1 << 19) | (136 << 8)), ("LDS-DMA - loads - barrier", (13 << 4) | (1 << 19) | (152 << 8)),
+                ("LDS-DMA - vector - MFMAs - loads", (13 << 4) | (1 << 19) | (175 << 8)), ("LDS-DMA: LDS reads + loop only", (13 << 4) | (1 << 19) | (191 << 8))]
+    if "--dma" in sys.argv:
+        variants = [v for v in variants if "LDS-DMA" in v[0]]
     for (B, H, Lq, Lk) in ((8, 10, 4096, 4096), (2, 10, 4096, 4096)):
         Cc = H * 64
         sets = []
