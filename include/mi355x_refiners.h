@@ -229,6 +229,10 @@ int mi355x_epoch_bump(int32_t* epoch, void* stream);
  * V is passed TRANSPOSED (produced that way by mi355x_gemm with the operands swapped): element (h*D + d, b, key) at
  * vt + (h*D + d)*ldvt + b*vt_batch_stride + key; every V^T row must be readable (and finite) up to the next
  * multiple of 64 keys.  D must be 64 (every SDXL attention); other head shapes go through mi355x_attention_general.
+ * Kernels behind it (csrc/attention.hip): at most three 64-key tiles over all streams (the step's cross-attentions) -- attn_short_dma_kernel (bf16) /
+ * attn_short_kernel (float32); more tiles, bf16, one stream (the self-attentions) -- attn_pipe_kernel, whose running maximum is LAZY (a tile whose scores stay
+ * within 2^8 of the reference is exponentiated against the old reference: same quotient O / l, last-digit differences against a per-tile maximum) and whose
+ * row sums are taken over the bf16-rounded P; float32 (the 1e-3 parity mode) and two-stream launches with more tiles -- attn_kernel with a per-tile maximum.
  */
 typedef struct {
     const void* k;
