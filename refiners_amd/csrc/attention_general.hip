@@ -29,12 +29,26 @@ struct GAttnP {
     char* out;
     int64_t ldqb, qbsb, ldkb, kbsb, ldvtb, vtbsb, ldob, obsb;  // bytes
     float c;          // scale * log2(e)
+    float thr;        // FAST: a tile leaves the running maximum alone while no score exceeds it by more than thr = 8 / c
     float out_scale;
     int qtiles;
 };
 
-template <typename T, int NS, int ND>
+// lane <-> lane ^ 16 / lane ^ 32 as row / half swaps (gfx950; see attention.hip): the maximum over a query's four lane groups without an LDS round trip
+MI_DEV float group_max4(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b), b = a;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
+// FAST (bf16, round 6; the measures of attention.hip's self-attention loop that do not depend on its pipelining): lazy running maximum (cross-lane maximum and the
+// O / l rescale only when some lane of the wave sees a score above reference + thr: P <= 2^8 otherwise, exact in the quotient), row sums l from the matrix pipe
+// (one more MFMA per P^T fragment against a fragment of ones: l = sum of the ROUNDED P), permlane reductions instead of ds_bpermute.
+template <typename T, int NS, int ND, bool FAST = false>
 __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
+    static_assert(!FAST || sizeof(T) == 2, "FAST is the bf16 path");
     constexpr int ES = sizeof(T);
     constexpr int EPC = DT<T>::EPC;
     constexpr int NW = 4, NTHR = 256, BQW = 32, BKV = 64;
@@ -114,6 +128,8 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
         for (int jq = 0; jq < 2; ++jq) o[i][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mrun[2] = {-INFINITY, -INFINITY};
     float lsum[2] = {0.f, 0.f};
+    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // FAST: row sums as an MFMA accumulator (its four rows are equal)
+    const frag_t ones = frag_t{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
 
     int ntile = (p.Lk + BKV - 1) / BKV;
     if (p.causal) {  // keys beyond the last query of this workgroup never contribute
@@ -163,8 +179,42 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
                 }
         }
         // ---- online softmax ----
+        if constexpr (FAST) {
+            float mloc[2];
+            bool need = false;
 #pragma unroll
-        for (int jq = 0; jq < 2; ++jq) {
+            for (int jq = 0; jq < 2; ++jq) {
+                float mx = st[0][jq][0];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][jq][r]);
+                mloc[jq] = mx;
+                need |= mx > mrun[jq] + p.thr;  // (reference still -inf: any finite score)
+            }
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform
+#pragma unroll
+                for (int jq = 0; jq < 2; ++jq) {
+                    const float mnew = fmaxf(mrun[jq], group_max4(mloc[jq]));
+                    const float mref = mnew == -INFINITY ? 0.f : mnew;  // (a fully masked prefix: see below)
+                    const float alpha = fast_exp2((mrun[jq] - mref) * p.c);
+                    mrun[jq] = mnew;
+                    lacc[jq] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) o[i][jq] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) {
+                const float mc = (mrun[jq] == -INFINITY ? 0.f : mrun[jq]) * p.c;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[t][jq][r] = fast_exp2(st[t][jq][r] * p.c - mc);
+            }
+        }
+#pragma unroll
+        for (int jq = 0; jq < (FAST ? 0 : 2); ++jq) {
             float mx = st[0][jq][0];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -206,6 +256,10 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
                     }
                     pb[jq] = __builtin_bit_cast(frag_t, pk);
                 }
+                if constexpr (FAST) {
+                    mma_step<T>(lacc[0], ones, pb[0]);
+                    mma_step<T>(lacc[1], ones, pb[1]);
+                }
 #pragma unroll
                 for (int i = 0; i < ND; ++i) {
                     const frag_t vf = lds_read_frag(vs, tile_off<VROWB>(16 * i + c16, 4 * s2 + g));  // one chunk = the lane's 8 consecutive keys
@@ -236,8 +290,12 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
         const int qr = q0 + 16 * jq + c16;
         if (qr >= p.Lq) continue;
         float l = lsum[jq];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        if constexpr (FAST) {
+            l = lacc[jq][0];
+        } else {
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = p.out_scale / l;
         T* op = reinterpret_cast<T*>(p.out + (int64_t)b * p.obsb + (int64_t)qr * p.ldob) + (int64_t)h * p.Dv;
 #pragma unroll
@@ -261,11 +319,16 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const GAttnP p) {
     }
 }
 
-template <typename T, int NS, int ND>
+int g_gattn_fast = 1;  // bf16 launches take the FAST instance (mi355x_attention_general_set_fast: A/B and tests)
+
+template <typename T, int NS, int ND, bool FAST = false>
 int launch_general(const GAttnP& p0, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2 && !FAST) {
+        if (g_gattn_fast) return launch_general<T, NS, ND, true>(p0, stream);
+    }
     constexpr int ES = sizeof(T);
     constexpr int LDS = 2 * (NS * 64 * 64 + ND * 16 * 64 * ES);
-    auto kfn = attn_general_kernel<T, NS, ND>;
+    auto kfn = attn_general_kernel<T, NS, ND, FAST>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -299,6 +362,11 @@ inline bool al16g(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 
 }  // namespace
 
+extern "C" int mi355x_attention_general_set_fast(int v) {  // probing / A-B only, not part of the stable contract
+    g_gattn_fast = v ? 1 : 0;
+    return MI355X_OK;
+}
+
 extern "C" int mi355x_attention_general(const mi355x_attn_general_args* a, void* stream) {
     if (!a || !a->q || !a->k || !a->vt || !a->out) return MI355X_EARG;
     if (a->dtype != MI355X_F32 && a->dtype != MI355X_BF16) return MI355X_EDTYPE;
@@ -314,6 +382,7 @@ extern "C" int mi355x_attention_general(const mi355x_attn_general_args* a, void*
     p.ldqb = a->ldq * es, p.qbsb = a->q_batch_stride * es, p.ldkb = a->ldk * es, p.kbsb = a->k_batch_stride * es;
     p.ldvtb = a->ldvt * es, p.vtbsb = a->vt_batch_stride * es, p.ldob = a->ldo * es, p.obsb = a->o_batch_stride * es;
     p.c = a->scale * 1.44269504088896340736f;
+    p.thr = p.c > 0.f ? 8.0f / p.c : 0.f;
     p.out_scale = a->out_scale;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return a->dtype == MI355X_F32 ? dispatch_general<float>(p, st) : dispatch_general<bf16_t>(p, st);

@@ -335,6 +335,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
     lib.mi355x_relpos_pack.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.mi355x_attention_set_glds.argtypes = [C.c_int]
+    lib.mi355x_attention_general_set_fast.argtypes = [C.c_int]
     lib.mi355x_attention_set_pipeline.argtypes = [C.c_int, C.c_int]
     if lib.mi355x_abi_version() != 7:
         raise NativeError("libmi355x_refiners.so ABI version mismatch")

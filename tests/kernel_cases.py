@@ -272,8 +272,9 @@ def attention_case(B, H, Lq, Lk, dtype, *, ip_tokens=0, ip_scale=0.7, spike=Fals
     return _cmp(out, ref, dtype)
 
 
-def attention_general_case(B, H, Lq, Lk, Dqk, Dv, dtype, *, causal=False, spike=False, seed=170):
-    """softmax(Q K^T / sqrt(Dqk) [causal]) V with Dqk != Dv allowed, against torch in fp32."""
+def attention_general_case(B, H, Lq, Lk, Dqk, Dv, dtype, *, causal=False, spike=False, seed=170, fast=None):
+    """softmax(Q K^T / sqrt(Dqk) [causal]) V with Dqk != Dv allowed, against torch in fp32.  fast = 0: the bf16 launch takes the round-5 instance
+    (per-tile maximum, vector row sums) instead of the lazy one."""
     q = _rand(B, Lq, H * Dqk, dtype=dtype, seed=seed)
     k = _rand(B, Lk, H * Dqk, dtype=dtype, seed=seed + 1)
     v = _rand(B, Lk, H * Dv, dtype=dtype, seed=seed + 2)
@@ -290,7 +291,13 @@ def attention_general_case(B, H, Lq, Lk, Dqk, Dv, dtype, *, causal=False, spike=
         logits = logits.masked_fill(~keep, float("-inf"))
     ref = (torch.softmax(logits, dim=-1) @ vh).transpose(1, 2).reshape(B, Lq, H * Dv)
     out = torch.full((B, Lq, H * Dv), float("nan"), dtype=dtype, device=DEV)
-    native.attention_general(q, k, _vt_from_v(v, Lkp), out, H, Lk, causal=causal)
+    if fast is not None:
+        native.load().mi355x_attention_general_set_fast(int(fast))
+    try:
+        native.attention_general(q, k, _vt_from_v(v, Lkp), out, H, Lk, causal=causal)
+    finally:
+        if fast is not None:
+            native.load().mi355x_attention_general_set_fast(1)
     return _cmp(out, ref, dtype)
 
 
@@ -994,6 +1001,11 @@ def all_cases():
                                  ("Lk1_ip1", (1, 2, 64, 1), {"ip_tokens": 1, "seed": 90}), ("Lk190", (1, 2, 200, 190), {"seed": 91}), ("Lk17_ip1_spike", (2, 3, 300, 17), {"ip_tokens": 1, "spike": True, "seed": 80})):
                 for code in (0x8000D1, 0x10000D1, 0x28000D1, 0x30000D1):
                     cases.append((f"attn_{tag}_short_r6_{code:07x}_{nm}", lambda dt=dt, args=args, kw=kw, c=code: attention_case(*args, dt, pipe=c, **kw)))
+        if dt == torch.bfloat16:  # the general kernel's round-5 instance (fast = 0) stays covered
+            cases += [(f"attng_{tag}_r5_d40_self", lambda dt=dt: attention_general_case(2, 8, 1024, 1024, 40, 40, dt, fast=0)),
+                      (f"attng_{tag}_r5_d80_spike", lambda dt=dt: attention_general_case(2, 8, 256, 256, 80, 80, dt, spike=True, fast=0)),
+                      (f"attng_{tag}_r5_d64_causal", lambda dt=dt: attention_general_case(2, 12, 77, 77, 64, 64, dt, causal=True, fast=0)),
+                      (f"attng_{tag}_r5_qk208_v80", lambda dt=dt: attention_general_case(1, 2, 512, 512, 208, 80, dt, fast=0))]
         # launches of at most three K/V tiles take the all-tiles-up-front kernel by default (the cases above: cross_77, cross_77_ip4, 1tile, 3tiles,
         # Lq_edge_200); 0x40000 switches it off, so the same shapes also run through the general tile loop; and its remaining slot layouts
         cases += [
@@ -1020,6 +1032,8 @@ def all_cases():
             (f"attng_{tag}_d80_causal_long", lambda dt=dt: attention_general_case(1, 4, 300, 300, 80, 80, dt, causal=True)),
             (f"attng_{tag}_qk112_v80", lambda dt=dt: attention_general_case(2, 4, 196, 196, 112, 80, dt)),
             (f"attng_{tag}_qk208_v80", lambda dt=dt: attention_general_case(1, 2, 512, 512, 208, 80, dt)),
+            (f"attng_{tag}_d40_long_spike", lambda dt=dt: attention_general_case(1, 4, 100, 1000, 40, 40, dt, spike=True, seed=171)),
+            (f"attng_{tag}_d80_causal_1000", lambda dt=dt: attention_general_case(1, 2, 1000, 1000, 80, 80, dt, causal=True, seed=172)),
             (f"attng_{tag}_relpos_14x14", lambda dt=dt: attention_relpos_case(2, 4, 14, 14, 80, dt)),
             (f"attng_{tag}_relpos_32x32", lambda dt=dt: attention_relpos_case(1, 2, 32, 32, 80, dt)),
             (f"layernorm_{tag}_640", lambda dt=dt: layernorm_case(1000, 640, dt)),
