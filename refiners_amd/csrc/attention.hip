@@ -829,6 +829,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     __syncthreads();
     f32x4 sa[4][NJQ], sb[4][NJQ];
     qk(kbuf, sa);
+#ifndef MI355X_ATTN_NO_PROLOGUE_BARRIER  // (probing build: what this barrier costs)
+    __syncthreads();  // iteration 0 re-fills K buffer 0: every wave's fragment reads of tile 0 come first (inside the loop the end-of-iteration barrier orders them)
+#endif
     mask_tail(0, sa);
     {
         float mloc[NJQ];

@@ -49,6 +49,24 @@ def test_buffers_are_never_written_in_the_iteration_that_reads_them(ntile):
     assert pv_done == list(range(ntile))
 
 
+@pytest.mark.parametrize("ntile", [1, 2, 3, 6])
+def test_no_interval_between_two_barriers_reads_and_writes_one_buffer(ntile):
+    """The kernel's LDS traffic as intervals between barriers: waves of a workgroup drift inside an interval, so a buffer that one wave still reads
+    must not be (DMA-)written by another in the same interval.  The prologue's Q K^T of tile 0 reads K buffer 0, iteration 0 re-fills it: they are
+    separate intervals (the barrier after the prologue's fragment reads)."""
+    intervals = [{"w": {("K", 0), ("V", 0), ("K", 1)}, "r": set()},            # prologue DMA; vmcnt(0); barrier
+                 {"w": set(), "r": {("K", 0)}}]                                 # Q K^T of tile 0; barrier
+    for i in range(ntile):
+        nxt = i + 1 < ntile
+        it = {"w": set(), "r": {("V", i & 1)}}
+        if nxt:
+            it["w"] |= {("K", i & 1), ("V", (i + 1) & 1)}
+            it["r"] |= {("K", (i + 1) & 1)}
+        intervals.append(it)                                                    # (NEXT: vmcnt(0); barrier)
+    for n, it in enumerate(intervals):
+        assert not (it["w"] & it["r"]), f"interval {n} reads and writes {it['w'] & it['r']}"
+
+
 # ---------------------------------------------------------------------------------------------------------------------------- arithmetic
 def bf16_round(x):
     """Round-to-nearest-even to bfloat16, returned as float32 values."""
