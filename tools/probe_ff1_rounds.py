@@ -1,0 +1,59 @@
+"""Pricing of "FF1 as two full rounds of two tile heights"  with what exists: GEGLU launches that are EXACTLY one dispatch round of the 8-wave loop
+-- 256 tiles of 192 x 256 (1536 x 8192 x 1280) and 256 tiles of 256 x 256 (2048 x 8192) -- and exactly two (512 tiles: 3072 x 8192 / 4096 x 8192), hot, against the CFG pair's FF1
+(2048 x 10240: 440 tiles of 192 rows = 1.72 rounds).  t(128-row round) is read off as t(256-row round) / 2 + the fixed part (fill + epilogue) the one- / two-round pairs give."""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+from refiners_amd import native  # noqa: E402
+
+dev, dt = "cuda", torch.bfloat16
+
+
+def run(M, N, K, tile, n=5):
+    sets = []
+    for _ in range(6):
+        x = torch.randn(M, K, device=dev).to(dt)
+        w = native.KBlocked((torch.randn(N, K, device=dev) * K ** -0.5).to(dt))
+        o = torch.empty(M, N // 2, device=dev, dtype=dt)
+        sets.append((x, w, o))
+    best = 1e9
+    for _ in range(3):
+        for x, w, o in sets:
+            native.gemm([(x, w)], o, geglu=True, tile=tile)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            for x, w, o in sets:
+                native.gemm([(x, w)], o, geglu=True, tile=tile)
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) / (n * len(sets)) * 1e3)
+    return best
+
+
+def main():
+    native.load()
+    K = 1280
+    rows = [("FF1 as it runs: 2048 x 10240, tile 9 (440 tiles of 192 rows)", 2048, 10240, 9), ("FF1 on tile 7 (320 tiles of 256 rows)", 2048, 10240, 7),
+            ("one round of 192-row tiles: 1536 x 8192", 1536, 8192, 9), ("two rounds of 192-row tiles: 3072 x 8192", 3072, 8192, 9),
+            ("one round of 256-row tiles: 2048 x 8192", 2048, 8192, 7), ("two rounds of 256-row tiles: 4096 x 8192", 4096, 8192, 7)]
+    t = {}
+    for name, M, N, tile in rows:
+        t[name] = run(M, N, K, tile)
+        print(f"{name:64s} {t[name]:7.1f} us  {2.0 * M * N * K / t[name] / 1e6:6.0f} TF", flush=True)
+    r192, r192x2 = t[rows[2][0]], t[rows[3][0]]
+    r256, r256x2 = t[rows[4][0]], t[rows[5][0]]
+    loop192, fix192 = r192x2 - r192, 2 * r192 - r192x2
+    loop256, fix256 = r256x2 - r256, 2 * r256 - r256x2
+    print(f"per round: 192-row tiles {loop192:.1f} us + {fix192:.1f} fixed; 256-row tiles {loop256:.1f} us + {fix256:.1f} fixed")
+    est = fix192 + loop192 + loop256 / 2 * 1.08  # a 128-row round: half a 256-row round's loop, +8 % for the smaller tile's worse reads-per-MFMA ratio
+    print(f"estimate for one launch of 256 x (192 x 256) + 256 x (128 x 256): {est:.1f} us against {t[rows[0][0]]:.1f} today")
+
+
+if __name__ == "__main__":
+    main()
