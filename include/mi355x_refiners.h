@@ -118,7 +118,9 @@ typedef struct {
                                workgroup per CU, each taking an equal share of (output tiles x K tiles), partial tiles summed in a fixed order
                                through sk_ws -- for launches whose 256x256 tiles do not fill a whole number of rounds (needs sk_ws / sk_flags;
                                falls back to 7 without them);  9: the same loop on 192x256 tiles (wave tile 96x64), whole tiles only and no transposed
-                               part: for launches whose 256-row tiles leave CUs idle in their only round (M = 8192, N = 1280: 160 tiles / 215).
+                               part: for launches whose 256-row tiles leave CUs idle in their only round (M = 8192, N = 1280: 160 tiles / 215);
+                               10: the same loop on 128x256 tiles (wave tile 64x64; bf16 GEMMs only, float32 / conv requests run on the library's choice):
+                               measured as the second round of a two-height launch, 780 TFLOP/s in a full round.
                                In-launch LoRA on this loop: ONE column group of a plain one-segment GEMM without out_t,
                                as whole tiles (8 with LoRA runs as 7) -- t = x A^T comes from producer workgroups at the head of the grid (one per
                                32 rows, two to a workgroup for stacked ranks 32 / 64; the 4-wave tiles' producers with this launch's larger LDS ring),

@@ -240,8 +240,8 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tile_req = g_tile ? g_tile : a->tile;
-    const int g8_mt = tile_req == 9 ? 6 : 8;  // tile 9: the same loop on 192 x 256 tiles (whole tiles only)
-    const bool want_g8 = tile_req == 7 || tile_req == 8 || tile_req == 9;
+    const int g8_mt = tile_req == 9 ? 6 : tile_req == 10 ? 4 : 8;  // tile 9: the same loop on 192 x 256 tiles (whole tiles only); 10: on 128 x 256 tiles (bf16 GEMMs)
+    const bool want_g8 = tile_req == 7 || tile_req == 8 || tile_req == 9 || (tile_req == 10 && a->dtype == MI355X_BF16 && !a->conv);
     if (want_g8 && p.ksplit > 1) {
         // a caller that split K for want of tiles AND asks for the 8-wave loop (native._fill_split: the measured table replaced a heuristic split): the loop needs
         // no split (whole tiles or stream-K) -- take it unsplit where it can run, otherwise keep the split on the 128 x 128 tile of the 4-wave kernel

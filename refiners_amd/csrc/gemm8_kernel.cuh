@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     // MT = 16-row blocks per wave: 8 = the 256 x 256 tile of the header; 6 = a 192 x 256 tile (wave tile 96 x 64, 12 MFMAs per phase) for launches whose 256-row tiles
     // leave CUs idle in their only dispatch round (M = 8192, N = 1280: 160 tiles of 256 rows on 256 CUs, 215 of 192 rows).  Everything row-related below is written in
     // WR = rows per wave row (128 / 96) and QR = rows of one X half tile per wave row (64 / 48); the W side does not change.
-    static_assert(MT == 8 || MT == 6, "wave tile rows");
+    static_assert(MT == 8 || MT == 6 || MT == 4, "wave tile rows");  // (MT = 4: 128 x 256 tiles, wave tile 64 x 64, 8 MFMAs per phase -- tile id 10, round 6: the second round of a two-height FF1)
     constexpr int BM = 32 * MT, BN = 256, NTHR = 512, NT = 4, WR = 16 * MT, QR = 8 * MT, XW = QR / 8;  // XW = waves that stage an X half tile (8 rows each)
     constexpr int XB = BM * 128, BUFB = (BM + BN) * 128;  // bytes: X tile, one LDS buffer (X tile + W tile)
     constexpr uint32_t OOB = 0x80000000u;                  // per-lane offset beyond every descriptor's num_records: the load writes zeros
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     auto lgkm0 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     auto lgkm8 = [&]() __attribute__((always_inline)) {  // the X reads of the phase (MT: issued behind the four W reads) may stay outstanding, the W reads may not
         if constexpr (MT == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if constexpr (MT == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
     };
 
     int ts_n = 0;
@@ -668,7 +669,7 @@ extern int g_g8_persist;  // 1 = launches with more tiles than CUs run as one pe
 
 template <typename T, bool CONV, bool LORA, int MT>
 int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
-    constexpr int LDS = 2 * (32 * MT + 256) * 128 + 2 * (256 * 8 + 2 * 256 * 4) + 2048;  // two stage buffers + two sets of epilogue vectors + the spare landing area
+    constexpr int LDS = 2 * (32 * MT + 256) * 128 + 2 * (256 * 8 + 2 * 256 * 4) + (MT == 4 ? 4096 : 2048);  // two stage buffers + two sets of epilogue vectors + the spare landing area (1 KB per wave without X rows)
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kfn = gemm8_kernel<T, CONV, LORA, MT>;
     static bool attr_set[64] = {};
@@ -739,7 +740,10 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
 }
 
 template <typename T, bool CONV>
-int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk, int mt) {  // mt: 8 = 256-row tiles (tile ids 7 / 8), 6 = 192-row tiles (tile id 9)
+int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk, int mt) {  // mt: 8 = 256-row tiles (tile ids 7 / 8), 6 = 192-row tiles (tile id 9), 4 = 128-row tiles (tile id 10: bf16 GEMMs only)
+    if constexpr (!CONV && sizeof(T) == 2) {
+        if (mt == 4) return p.lora_b ? launch_gemm8_impl<T, false, true, 4>(p, stream, false) : launch_gemm8_impl<T, false, false, 4>(p, stream, false);
+    }
     if constexpr (!CONV) {
         if (p.lora_b) {  // (its own instance: the LoRA roles cost the plain one registers it does not have)
             return mt == 6 ? launch_gemm8_impl<T, false, true, 6>(p, stream, false) : launch_gemm8_impl<T, false, true, 8>(p, stream, streamk);
@@ -751,7 +755,8 @@ int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk, int mt) {  //
 // Can this launch run on the 8-phase loop?  (No in-launch LoRA, no split-K workspace protocol, transposed column groups from a multiple of 256; every operand below
 // 2 GB: 32-bit buffer offsets with 0x80000000 as the out-of-range marker.)
 inline bool gemm8_ok(const GemmP& p, bool conv = false, int mt = 8) {
-    if (mt == 6 && p.out_t) return false;  // (the 192-row tile has no transposed form)
+    if (mt != 8 && p.out_t) return false;  // (the 192- and 128-row tiles have no transposed form)
+    if (mt == 4 && conv) return false;  // (tile id 10 is instantiated for bf16 GEMMs: gemm.hip keeps float32 launches off it)
     if (p.ksplit > 1 || !p.vec_ok || p.N % 16) return false;  // (the epilogue instances of this loop are the vectorised ones)
     if (p.lora_b && (conv || p.lora_groups != 1 || p.nseg != 1 || p.out_t || (p.lora_r != 32 && p.lora_r != 64 && p.lora_r != 128) || !p.lora_t || !p.lora_flags || !p.lora_epoch)) return false;  // in-launch LoRA here: one column group of a plain GEMM
     if (p.out_t && p.nt_begin % 256) return false;  // a tile is either stored row-major or transposed

@@ -41,7 +41,7 @@ def lookup(signature: str, stages: int = 0) -> tuple[int, int]:
         got = table().get(signature)
         if got is None and signature.endswith("lora"):  # the LoRA producers leave the tiles' K loop untouched: same choice as the un-adapted launch
             got = table().get(signature[: -len("lora")])
-            if got is not None and got[0] in (7, 8, 9):
+            if got is not None and got[0] in (7, 8, 9, 10):
                 # the 8-wave loop takes the LoRAs of a plain one-segment GEMM with one column group (whole tiles: no stream-K); a launch it cannot
                 # take -- several groups, a transposed group, a convolution -- gets the 128 x 128 tile of the 4-wave kernel
                 kind, _, _, seg, flags = signature.split(":")

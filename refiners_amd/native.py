@@ -922,7 +922,7 @@ def _fill_split(a: GemmArgs, tile: int, ksplit: int, ws: Optional[Tensor], stage
         from .engine import tuning
 
         t8, _ = tuning.lookup(gemm_signature(a), 0)
-        if t8 in (7, 8, 9):
+        if t8 in (7, 8, 9, 10):
             tile = t8
     a.tile, a.ksplit, a.stages = tile, ksplit, stages
     if tile == 8 or os.environ.get("REFINERS_AMD_FORCE_TILE") == "8":

@@ -1206,6 +1206,21 @@ def all_cases():
             (f"conv_gn_{tag}_tile9", lambda dt=dt: conv_groupnorm_chain_case(2, 320, 320, 32, 32, dt, tile=9)),
             (f"conv_{tag}_tile9_s2_ups_shortcut", lambda dt=dt: conv_forced_tile_case(dt, 9)),
             (f"gemm_{tag}_tile9_lora1_2048x1280x1280", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, tile=9), 2)),
+        ]
+        if dt == torch.bfloat16:  # tile id 10: the 8-wave loop on 128 x 256 tiles (bf16 GEMMs; float32 / convolutions asking for it run on the library's choice)
+            cases += [(f"gemm_{tag}_tile10_{nkt}ktiles", lambda dt=dt, nkt=nkt: on_g8(lambda: gemm_tile_case(300, nkt * (128 // 2), 528, dt, 10, 0, seed=540 + nkt), 2)) for nkt in (1, 2, 3, 4, 5, 8)]
+            cases += [
+                (f"gemm_{tag}_tile10_one_round", lambda dt=dt: on_g8(lambda: gemm_tile_case(1024, 256, 8192, dt, 10, 0, seed=549))),  # 8 x 32 = 256 tiles
+                (f"gemm_{tag}_tile10_many_tiles", lambda dt=dt: on_g8(lambda: gemm_tile_case(2048, 256, 10240, dt, 10, 0, seed=550))),  # 640 tiles: persistent, 2.5 rounds
+                (f"gemm_{tag}_tile10_ragged_rows", lambda dt=dt: gemm_tile_case(129 + 64 + 17, 320, 272, dt, 10, 0, seed=552)),
+                (f"gemm_{tag}_tile10_two_segments", lambda dt=dt: on_g8(lambda: gemm_multiseg_case(600, 640, 320 + 64, 528, dt, 10))),
+                (f"gemm_{tag}_tile10_geglu", lambda dt=dt: on_g8(lambda: gemm_geglu_case(1024, 640, 2560, dt, tile=10))),
+                (f"gemm_{tag}_tile10_ln_chain_geglu", lambda dt=dt: gemm_ln_chain_case(512, 640, 5120, dt, geglu=True, tile1=1, tile2=10)),
+                (f"colstats_{tag}_tile10", lambda dt=dt: on_g8(lambda: colstats_case(600, 384, 640, dt, tile=10))),
+                (f"gemm_{tag}_tile10_lora1_2048x1280x1280", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, tile=10), 2)),
+                (f"gemm_{tag}_tile10_lora1_rank8_edges", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(300, 640, 208, dt, ranks=(8,), tile=10), 2)),
+            ]
+        cases += [
             (f"gemm_{tag}_tile9_lora1_rank8_edges", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(300, 640, 208, dt, ranks=(8,), tile=9), 2)),
             (f"gemm_{tag}_tile9_lora1_rank128", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, ranks=(128,), tile=9), 2)),
             (f"gemm_{tag}_tile9_lora1_geglu", lambda dt=dt: on_tile9(lambda: on_g8_lora(lambda: gemm_lora_inlaunch_case(512, 640, 2560, dt, geglu=True, tile=9)))),

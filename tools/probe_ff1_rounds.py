@@ -41,7 +41,9 @@ def main():
     K = 1280
     rows = [("FF1 as it runs: 2048 x 10240, tile 9 (440 tiles of 192 rows)", 2048, 10240, 9), ("FF1 on tile 7 (320 tiles of 256 rows)", 2048, 10240, 7),
             ("one round of 192-row tiles: 1536 x 8192", 1536, 8192, 9), ("two rounds of 192-row tiles: 3072 x 8192", 3072, 8192, 9),
-            ("one round of 256-row tiles: 2048 x 8192", 2048, 8192, 7), ("two rounds of 256-row tiles: 4096 x 8192", 4096, 8192, 7)]
+            ("one round of 256-row tiles: 2048 x 8192", 2048, 8192, 7), ("two rounds of 256-row tiles: 4096 x 8192", 4096, 8192, 7),
+            ("one round of 128-row tiles (tile 10): 1024 x 8192", 1024, 8192, 10), ("two rounds of 128-row tiles: 2048 x 8192", 2048, 8192, 10),
+            ("FF1 on tile 10 (640 tiles of 128 rows)", 2048, 10240, 10)]
     t = {}
     for name, M, N, tile in rows:
         t[name] = run(M, N, K, tile)
@@ -53,6 +55,19 @@ def main():
     print(f"per round: 192-row tiles {loop192:.1f} us + {fix192:.1f} fixed; 256-row tiles {loop256:.1f} us + {fix256:.1f} fixed")
     est = fix192 + loop192 + loop256 / 2 * 1.08  # a 128-row round: half a 256-row round's loop, +8 % for the smaller tile's worse reads-per-MFMA ratio
     print(f"estimate for one launch of 256 x (192 x 256) + 256 x (128 x 256): {est:.1f} us against {t[rows[0][0]]:.1f} today")
+    r128, r128x2 = t[rows[6][0]], t[rows[7][0]]
+    loop128, fix128 = r128x2 - r128, 2 * r128 - r128x2
+    print(f"MEASURED 128-row tiles per round: {loop128:.1f} us + {fix128:.1f} fixed  ->  192-row round + 128-row round in one launch: {fix192 + loop192 + loop128:.1f} us")
+    # correctness of the 128-row instance on this very shape (GEGLU epilogue, 2.5 rounds, persistent)
+    x = torch.randn(2048, K, device=dev).to(dt)
+    wd = (torch.randn(10240, K, device=dev) * K ** -0.5).to(dt)
+    w = native.KBlocked(wd)
+    o10 = torch.empty(2048, 5120, device=dev, dtype=dt)
+    o9 = torch.empty_like(o10)
+    native.gemm([(x, w)], o10, geglu=True, tile=10)
+    native.gemm([(x, w)], o9, geglu=True, tile=9)
+    torch.cuda.synchronize()
+    print(f"tile 10 against tile 9 on FF1: max |d| {(o10.float() - o9.float()).abs().max().item():.3e} (bit-equal expected: same K order per output)")
 
 
 if __name__ == "__main__":
