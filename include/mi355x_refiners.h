@@ -120,7 +120,9 @@ typedef struct {
                                falls back to 7 without them);  9: the same loop on 192x256 tiles (wave tile 96x64), whole tiles only and no transposed
                                part: for launches whose 256-row tiles leave CUs idle in their only round (M = 8192, N = 1280: 160 tiles / 215);
                                10: the same loop on 128x256 tiles (wave tile 64x64; bf16 GEMMs only, float32 / conv requests run on the library's choice):
-                               measured as the second round of a two-height launch, 780 TFLOP/s in a full round.
+                               780 TFLOP/s in a full round;  11: 192-row tiles for a whole number of rounds + 128-row tiles for a whole number of
+                               rounds in ONE launch, for shapes that admit such a split on this GPU (a CFG pair's FF1, 2048 x 10240: 256 + 256 tiles on
+                               256 CUs; bf16 GEMMs; anything else asking for it runs as 9): -7 % hot, not in the measured table.
                                In-launch LoRA on this loop: ONE column group of a plain one-segment GEMM without out_t,
                                as whole tiles (8 with LoRA runs as 7) -- t = x A^T comes from producer workgroups at the head of the grid (one per
                                32 rows, two to a workgroup for stacked ranks 32 / 64; the 4-wave tiles' producers with this launch's larger LDS ring),

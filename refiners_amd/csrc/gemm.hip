@@ -61,7 +61,7 @@ extern "C" int mi355x_set_option(const char* name, int value) {
     return MI355X_EARG;
 }
 
-static int g_stat_g8 = 0, g_stat_g8_lora = 0, g_stat_g9 = 0;
+static int g_stat_g8 = 0, g_stat_g8_lora = 0, g_stat_g9 = 0, g_stat_g11 = 0;
 extern "C" int mi355x_get_stat(const char* name);
 extern "C" int mi355x_get_stat(const char* name) {
     // launches since the library was loaded (tests: did the configuration asked for really run?); like mi355x_set_option not part of the stable contract
@@ -69,6 +69,7 @@ extern "C" int mi355x_get_stat(const char* name) {
     if (!name) return MI355X_EARG;
     if (name[0] == 'g' && name[1] == '8') return name[2] == 'l' ? g_stat_g8_lora : g_stat_g8;
     if (name[0] == 'g' && name[1] == '9') return g_stat_g9;
+    if (name[0] == 'g' && name[1] == '1' && name[2] == '1') return g_stat_g11;
     return MI355X_EARG;
 }
 
@@ -240,8 +241,15 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tile_req = g_tile ? g_tile : a->tile;
-    const int g8_mt = tile_req == 9 ? 6 : tile_req == 10 ? 4 : 8;  // tile 9: the same loop on 192 x 256 tiles (whole tiles only); 10: on 128 x 256 tiles (bf16 GEMMs)
-    const bool want_g8 = tile_req == 7 || tile_req == 8 || tile_req == 9 || (tile_req == 10 && a->dtype == MI355X_BF16 && !a->conv);
+    int g8_mt = tile_req == 9 ? 6 : tile_req == 10 ? 4 : 8;  // tile 9: the same loop on 192 x 256 tiles (whole tiles only); 10: on 128 x 256 tiles (bf16 GEMMs)
+    bool want_g8 = tile_req == 7 || tile_req == 8 || tile_req == 9 || (tile_req == 10 && a->dtype == MI355X_BF16 && !a->conv);
+    if (tile_req == 11) {  // 192-row tiles for a whole number of rounds + 128-row tiles for a whole number of rounds (bf16 GEMMs whose shape admits it: plan_mix); else tile 9
+        int rb, cb, nb, ns, dev = 0, ncu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        want_g8 = true;
+        g8_mt = a->dtype == MI355X_BF16 && !a->conv && g_sk_g == 0 && plan_mix(p.M, p.N, ncu, rb, cb, nb, ns) ? 11 : 6;
+    }
     if (want_g8 && p.ksplit > 1) {
         // a caller that split K for want of tiles AND asks for the 8-wave loop (native._fill_split: the measured table replaced a heuristic split): the loop needs
         // no split (whole tiles or stream-K) -- take it unsplit where it can run, otherwise keep the split on the 128 x 128 tile of the 4-wave kernel
@@ -256,6 +264,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_args* a, void* stream) {
         ++g_stat_g8;
         if (p.lora_b) ++g_stat_g8_lora;
         if (g8_mt == 6) ++g_stat_g9;
+        if (g8_mt == 11) ++g_stat_g11;
         const bool sk = tile_req == 8 && a->sk_ws && a->sk_flags && a->sk_slots > 0 && (reinterpret_cast<uintptr_t>(a->sk_ws) & 15) == 0;
         p.sk_ws = static_cast<float*>(a->sk_ws);
         p.sk_flags = a->sk_flags;

@@ -82,6 +82,34 @@ MI_DEV void tile_coords(const GemmP& p, int bx, int& tm, int& tn) {
 }
 
 // Prefetch role (GemmP::pf_ptr): the first pf_blocks workgroups touch every 64 bytes of the next launch's weights
+// Tile -> (first row, first column) of a two-height launch (GemmP::mix_*), XCD-aware: tile t runs on XCD t % 8 (persistent workgroup b takes tiles b, b + 256, ... and
+// producer / prefetch workgroups come in multiples of 8).  Every XCD owns cb8 = mix_cb / 8 "early" column tiles and ca8 = (tiles_n - mix_cb) / 8 "late" ones:
+//   192-row tiles (t < mix_nbig):  the XCD's early column tiles x the mix_rb / 192 row tiles of rows [0, mix_rb);
+//   128-row tiles, first the rows [mix_rb, M) under the SAME early column tiles (their W panels are in this XCD's L2 from the 192-row tiles),
+//                  then the XCD's late column tiles over ALL rows in 128-row tiles (one new W panel per late column tile).
+MI_DEV void mix_coords(const GemmP& p, int t, int& m0, int& n0) {
+    const int cb8 = p.mix_cb >> 3;
+    if (t < p.mix_nbig) {
+        const int x = t & 7, idx = t >> 3;
+        const int tm = idx / cb8;
+        m0 = tm * 192;
+        n0 = (cb8 * x + (idx - tm * cb8)) * 256;
+        return;
+    }
+    const int u = t - p.mix_nbig, x = u & 7, idx = u >> 3;
+    const int nb8 = ((p.M - p.mix_rb) >> 7) * cb8;
+    if (idx < nb8) {
+        const int tm = idx / cb8;
+        m0 = p.mix_rb + tm * 128;
+        n0 = (cb8 * x + (idx - tm * cb8)) * 256;
+    } else {
+        const int j = idx - nb8, ca8 = (p.tiles_n - p.mix_cb) >> 3;
+        const int tm = j / ca8;
+        m0 = tm * 128;
+        n0 = (p.mix_cb + ca8 * x + (j - tm * ca8)) * 256;
+    }
+}
+
 template <int NTHR_ALL> MI_DEV void prefetch_role(const GemmP& p, int tid_all) {
     int acc = 0;
     const int64_t stride = (int64_t)p.pf_blocks * NTHR_ALL * 64;
@@ -112,14 +140,18 @@ template <int NTHR_ALL> MI_DEV void prefetch_role(const GemmP& p, int tid_all) {
 #define MI355X_G8_PRIO 1  // s_setprio 1 around every MFMA cluster (guide T5: +21..39 % on this schedule)
 #endif
 
-template <typename T, bool CONV, bool LORA, int MT>
+template <typename T, bool CONV, bool LORA, int MTK, int MT2 = 0>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
+    // MT2 != 0 (round 6): a launch of TWO tile heights -- tiles [0, p.mix_nbig) are 32 MTK rows high, the rest 32 MT2: FF1 of a CFG pair (2048 x 10240) is exactly 256 tiles of
+    // 192 x 256 + 256 tiles of 128 x 256, one of each per CU, where 440 tiles of 192 rows are 1.72 dispatch rounds paid as two (mix_coords below).
+    // The body of a segment is a generic lambda over the tile height; the LDS partition (stage buffers, epilogue vectors, spare area) is the larger tile's.
     // MT = 16-row blocks per wave: 8 = the 256 x 256 tile of the header; 6 = a 192 x 256 tile (wave tile 96 x 64, 12 MFMAs per phase) for launches whose 256-row tiles
     // leave CUs idle in their only dispatch round (M = 8192, N = 1280: 160 tiles of 256 rows on 256 CUs, 215 of 192 rows).  Everything row-related below is written in
     // WR = rows per wave row (128 / 96) and QR = rows of one X half tile per wave row (64 / 48); the W side does not change.
-    static_assert(MT == 8 || MT == 6 || MT == 4, "wave tile rows");  // (MT = 4: 128 x 256 tiles, wave tile 64 x 64, 8 MFMAs per phase -- tile id 10, round 6: the second round of a two-height FF1)
-    constexpr int BM = 32 * MT, BN = 256, NTHR = 512, NT = 4, WR = 16 * MT, QR = 8 * MT, XW = QR / 8;  // XW = waves that stage an X half tile (8 rows each)
-    constexpr int XB = BM * 128, BUFB = (BM + BN) * 128;  // bytes: X tile, one LDS buffer (X tile + W tile)
+    static_assert(MTK == 8 || MTK == 6 || MTK == 4, "wave tile rows");  // (MT = 4: 128 x 256 tiles, wave tile 64 x 64, 8 MFMAs per phase -- tile id 10, round 6: the second round of a two-height FF1)
+    static_assert(MT2 == 0 || (MT2 == 4 && MTK == 6 && !CONV), "two-height launches: 192-row + 128-row tiles of a plain GEMM");
+    constexpr int BN = 256, NTHR = 512, NT = 4;
+    constexpr int BUFB = (32 * MTK + BN) * 128;  // bytes of one LDS stage buffer (X tile + W tile) of the LARGER tile: the launch's LDS partition
     constexpr uint32_t OOB = 0x80000000u;                  // per-lane offset beyond every descriptor's num_records: the load writes zeros
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // per-tile vectors of the epilogue, TWO sets used alternately by consecutive segments of a persistent workgroup: the waves that finish a tile's epilogue first
@@ -180,12 +212,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
     auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     auto bar = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_barrier(); };
     auto lgkm0 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    auto lgkm8 = [&]() __attribute__((always_inline)) {  // the X reads of the phase (MT: issued behind the four W reads) may stay outstanding, the W reads may not
-        if constexpr (MT == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        else if constexpr (MT == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-    };
-
     int ts_n = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
         if constexpr ((MI355X_G8_ABL & 4) != 0) {
@@ -231,19 +257,34 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             tile_next += p.sk_g;
             more = tile_next < p.grid0;
         }
-        int tm, tn;
-        if (p.sk_mode == 1) {  // tiles in row-major (sk_order 0) or column-major order along the unit axis
-            if (p.sk_order == 0) {
-                tm = tile / p.tiles_n;
-                tn = tile - tm * p.tiles_n;
-            } else {
-                tn = tile / p.tiles_m;
-                tm = tile - tn * p.tiles_m;
-            }
+        const bool small_tile = MT2 != 0 && p.mix_nbig > 0 && tile >= p.mix_nbig;
+        auto segment = [&](auto mtc) __attribute__((always_inline)) {
+        constexpr int MT = decltype(mtc)::value;
+        constexpr int BM = 32 * MT, WR = 16 * MT, QR = 8 * MT, XW = QR / 8;  // XW = waves that stage an X half tile (8 rows each)
+        constexpr int XB = BM * 128;                                          // bytes of the X tile inside a stage buffer (the buffers keep the larger tile's pitch BUFB)
+        auto lgkm8 = [&]() __attribute__((always_inline)) {  // the X reads of the phase (MT: issued behind the four W reads) may stay outstanding, the W reads may not
+            if constexpr (MT == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else if constexpr (MT == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        };
+
+        int tm = 0, tn = 0, m0, n0;
+        if (MT2 != 0 && p.mix_nbig > 0) {
+            mix_coords(p, tile, m0, n0);
         } else {
-            tile_coords(p, tile, tm, tn);
+            if (p.sk_mode == 1) {  // tiles in row-major (sk_order 0) or column-major order along the unit axis
+                if (p.sk_order == 0) {
+                    tm = tile / p.tiles_n;
+                    tn = tile - tm * p.tiles_n;
+                } else {
+                    tn = tile / p.tiles_m;
+                    tm = tile - tn * p.tiles_m;
+                }
+            } else {
+                tile_coords(p, tile, tm, tn);
+            }
+            m0 = tm * BM, n0 = tn * BN;
         }
-        const int m0 = tm * BM, n0 = tn * BN;
 
         // transposed tile (columns >= nt_begin, stored as out_t[n][m]): the tile of the TRANSPOSED problem -- the LDS slot that normally holds activation
         // rows is filled from the weight rows n0 + R, the slot that normally holds (permuted) weight rows from the activation rows m0 + perm(R).  The K
@@ -540,7 +581,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(p.sk_flags + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
+            return;
         }
         if (kfirst > 0) {
             // collect: workgroups bid - 1, bid - 2, ... hold the K tiles [.., kfirst) of this tile
@@ -660,6 +701,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmP p) {
             __builtin_amdgcn_s_barrier();
         }
 #endif
+        };  // segment
+        if constexpr (MT2 != 0) {
+            if (small_tile) segment(std::integral_constant<int, MT2>{});
+            else segment(std::integral_constant<int, MTK>{});
+        } else {
+            segment(std::integral_constant<int, MTK>{});
+        }
     }
 }
 
@@ -667,11 +715,29 @@ extern int g_sk_g;        // probing: number of stream-K / persistent workgroups
 extern int g_lora_dbg;    // probing bits of the in-launch LoRA (gemm.hip; bit 0 = the hand-over's producers exit at once)
 extern int g_g8_persist;  // 1 = launches with more tiles than CUs run as one persistent workgroup per CU
 
-template <typename T, bool CONV, bool LORA, int MT>
+// Geometry of a two-height launch (tile id 11) for n_cu CUs, or false: rows [0, rb) in 192-row tiles over the first cb column tiles = a whole number of rounds, everything else in
+// 128-row tiles = a whole number of rounds, each XCD with whole column tiles of every region (mix_coords).
+inline bool plan_mix(int M, int N, int n_cu, int& rb, int& cb, int& nbig, int& nsmall) {
+    if (M <= 0 || N <= 0 || M % 128 || N % 256 || n_cu <= 0 || n_cu % 8) return false;
+    const int tn = N / 256;
+    if (tn % 8) return false;
+    for (rb = M / 384 * 384; rb >= 384; rb -= 384) {
+        if ((M - rb) % 128) continue;
+        const int rows_big = rb / 192;
+        for (cb = tn / 8 * 8 - 8; cb >= 8; cb -= 8) {
+            nbig = rows_big * cb;
+            nsmall = (rb / 128) * (tn - cb) + ((M - rb) / 128) * tn;
+            if (nbig % n_cu == 0 && nsmall % n_cu == 0) return true;
+        }
+    }
+    return false;
+}
+
+template <typename T, bool CONV, bool LORA, int MT, int MT2 = 0>
 int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
-    constexpr int LDS = 2 * (32 * MT + 256) * 128 + 2 * (256 * 8 + 2 * 256 * 4) + (MT == 4 ? 4096 : 2048);  // two stage buffers + two sets of epilogue vectors + the spare landing area (1 KB per wave without X rows)
+    constexpr int LDS = 2 * (32 * MT + 256) * 128 + 2 * (256 * 8 + 2 * 256 * 4) + (MT == 4 || MT2 == 4 ? 4096 : 2048);  // two stage buffers + two sets of epilogue vectors + the spare landing area (1 KB per wave without X rows)
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kfn = gemm8_kernel<T, CONV, LORA, MT>;
+    auto kfn = gemm8_kernel<T, CONV, LORA, MT, MT2>;
     static bool attr_set[64] = {};
     static int n_cu[64] = {};
     int dev = 0;
@@ -731,6 +797,16 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
             }
         }
     }
+    q.mix_nbig = q.mix_rb = q.mix_cb = 0;
+    if constexpr (MT2 != 0) {  // two tile heights: every CU one 192-row tile, then one 128-row tile (or whole multiples); the caller checked plan_mix
+        int rb, cb, nbig, nsmall;
+        if (!plan_mix(q.M, q.N, ncu, rb, cb, nbig, nsmall)) return MI355X_ESHAPE;
+        q.mix_nbig = nbig, q.mix_rb = rb, q.mix_cb = cb;
+        q.tiles_n = q.N / 256;
+        q.grid0 = nbig + nsmall;
+        q.sk_mode = 0;
+        q.sk_g = ncu;
+    }
     // several whole tiles per workgroup: b, b + ncu, ... (the same XCD each time).  LoRA launches too (round 6): their producers leave the CU after a quarter of a tile's
     // time, and the persistent workgroups that start behind them are the highest ids -- the ones with the fewest tiles
     if (q.sk_mode == 0 && g_g8_persist && q.grid0 > ncu && ncu % 8 == 0) q.sk_g = ncu;
@@ -740,8 +816,9 @@ int launch_gemm8_impl(const GemmP& p, hipStream_t stream, bool streamk) {
 }
 
 template <typename T, bool CONV>
-int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk, int mt) {  // mt: 8 = 256-row tiles (tile ids 7 / 8), 6 = 192-row tiles (tile id 9), 4 = 128-row tiles (tile id 10: bf16 GEMMs only)
+int launch_gemm8(const GemmP& p, hipStream_t stream, bool streamk, int mt) {  // mt: 8 = 256-row tiles (tile ids 7 / 8), 6 = 192-row tiles (tile id 9), 4 = 128-row tiles (tile id 10: bf16 GEMMs only), 11 = 192- and 128-row tiles in one launch (tile id 11)
     if constexpr (!CONV && sizeof(T) == 2) {
+        if (mt == 11) return p.lora_b ? launch_gemm8_impl<T, false, true, 6, 4>(p, stream, false) : launch_gemm8_impl<T, false, false, 6, 4>(p, stream, false);
         if (mt == 4) return p.lora_b ? launch_gemm8_impl<T, false, true, 4>(p, stream, false) : launch_gemm8_impl<T, false, false, 4>(p, stream, false);
     }
     if constexpr (!CONV) {

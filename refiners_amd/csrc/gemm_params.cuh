@@ -85,6 +85,9 @@ struct GemmP {
     // tiles x sk_nk units evenly, partial tiles meet in sk_ws ([sk_cap][256 x 256] float32) behind sk_flags ([sk_cap] = 1 while a deposit waits for
     // its owner, 0 between launches; word sk_cap = error flag); sk_order: tile order along the unit axis (0 row-major, 1 column-major)
     int sk_g, sk_nk, sk_order, sk_cap, sk_mode;  // sk_mode 0: workgroup b takes the whole tiles b, b + sk_g, ...; 1: stream-K
+    // two-height launches of the 8-wave loop (tile id 11; gemm8_kernel.cuh mix_coords): tiles [0, mix_nbig) are 192 x 256 and cover rows [0, mix_rb) x column tiles [0, mix_cb);
+    // the others are 128 x 256 and cover the rest (rows [0, mix_rb) x column tiles [mix_cb, tiles_n), then rows [mix_rb, M) x every column tile).  0: off
+    int mix_nbig, mix_rb, mix_cb;
     float* sk_ws;
     int* sk_flags;
 };

@@ -825,6 +825,11 @@ def on_g8(fn, launches=1):
     return _on_path(b"g8", "on the 8-wave loop", fn, launches)
 
 
+def on_tile11(fn, launches=1):
+    """... ran the 8-wave loop as a two-height launch (192-row tiles + 128-row tiles, tile id 11)."""
+    return _on_path(b"g11", "as a two-height launch of the 8-wave loop", fn, launches)
+
+
 def on_tile9(fn, launches=1):
     """... ran the 8-wave loop on 192-row tiles."""
     return _on_path(b"g9", "on 192-row tiles of the 8-wave loop", fn, launches)
@@ -1219,6 +1224,14 @@ def all_cases():
                 (f"colstats_{tag}_tile10", lambda dt=dt: on_g8(lambda: colstats_case(600, 384, 640, dt, tile=10))),
                 (f"gemm_{tag}_tile10_lora1_2048x1280x1280", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(2048, 1280, 1280, dt, tile=10), 2)),
                 (f"gemm_{tag}_tile10_lora1_rank8_edges", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(300, 640, 208, dt, ranks=(8,), tile=10), 2)),
+                # tile id 11: 192-row tiles for a whole number of rounds + 128-row tiles for a whole number of rounds in ONE launch (csrc/gemm8_kernel.cuh plan_mix / mix_coords):
+                # FF1 of a CFG pair = 256 + 256 tiles; 4096 x 10240 = 512 + 512 (another row / column split); every epilogue FF1 uses; shapes without such a split run as tile 9
+                (f"gemm_{tag}_tile11_ff1_plain", lambda dt=dt: on_tile11(lambda: gemm_tile_case(2048, 256, 10240, dt, 11, 0, seed=560))),
+                (f"gemm_{tag}_tile11_ff1_geglu", lambda dt=dt: on_tile11(lambda: gemm_geglu_case(2048, 320, 5120, dt, seed=561, tile=11))),
+                (f"gemm_{tag}_tile11_ff1_ln_chain_geglu", lambda dt=dt: on_tile11(lambda: gemm_ln_chain_case(2048, 640, 10240, dt, geglu=True, tile1=1, tile2=11, seed=562))),
+                (f"gemm_{tag}_tile11_ff1_lora1_geglu", lambda dt=dt: on_tile11(lambda: gemm_lora_inlaunch_case(2048, 640, 10240, dt, tile=11, geglu=True, seed=563))),
+                (f"gemm_{tag}_tile11_4096x10240", lambda dt=dt: on_tile11(lambda: gemm_tile_case(4096, 192, 10240, dt, 11, 0, seed=564))),
+                (f"gemm_{tag}_tile11_no_split_runs_as_tile9", lambda dt=dt: on_tile9(lambda: gemm_tile_case(1000, 256, 1280, dt, 11, 0, seed=565))),
             ]
         cases += [
             (f"gemm_{tag}_tile9_lora1_rank8_edges", lambda dt=dt: on_g8_lora(lambda: gemm_lora_inlaunch_case(300, 640, 208, dt, ranks=(8,), tile=9), 2)),

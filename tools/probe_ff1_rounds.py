@@ -43,7 +43,7 @@ def main():
             ("one round of 192-row tiles: 1536 x 8192", 1536, 8192, 9), ("two rounds of 192-row tiles: 3072 x 8192", 3072, 8192, 9),
             ("one round of 256-row tiles: 2048 x 8192", 2048, 8192, 7), ("two rounds of 256-row tiles: 4096 x 8192", 4096, 8192, 7),
             ("one round of 128-row tiles (tile 10): 1024 x 8192", 1024, 8192, 10), ("two rounds of 128-row tiles: 2048 x 8192", 2048, 8192, 10),
-            ("FF1 on tile 10 (640 tiles of 128 rows)", 2048, 10240, 10)]
+            ("FF1 on tile 10 (640 tiles of 128 rows)", 2048, 10240, 10), ("FF1 on tile 11: 256 x (192 x 256) + 256 x (128 x 256) in ONE launch", 2048, 10240, 11)]
     t = {}
     for name, M, N, tile in rows:
         t[name] = run(M, N, K, tile)
@@ -64,10 +64,17 @@ def main():
     w = native.KBlocked(wd)
     o10 = torch.empty(2048, 5120, device=dev, dtype=dt)
     o9 = torch.empty_like(o10)
+    o11 = torch.full_like(o10, float("nan"))
     native.gemm([(x, w)], o10, geglu=True, tile=10)
     native.gemm([(x, w)], o9, geglu=True, tile=9)
+    lib = native.load()
+    import ctypes
+    lib.mi355x_get_stat.argtypes = [ctypes.c_char_p]
+    n0 = lib.mi355x_get_stat(b"g11")
+    native.gemm([(x, w)], o11, geglu=True, tile=11)
     torch.cuda.synchronize()
     print(f"tile 10 against tile 9 on FF1: max |d| {(o10.float() - o9.float()).abs().max().item():.3e} (bit-equal expected: same K order per output)")
+    print(f"tile 11 against tile 9 on FF1: max |d| {(o11.float() - o9.float()).abs().max().item():.3e}, nan {int(torch.isnan(o11.float()).sum())}, launches on the two-height path {lib.mi355x_get_stat(b'g11') - n0}")
 
 
 if __name__ == "__main__":
